@@ -1,0 +1,274 @@
+"""
+TEST INFRASTRUCTURE ONLY -- pure-Python-int oracle for the BabyJubJub hot path.
+
+This file restates, with arbitrary-precision Python ints, the algorithm of the
+reference crate arnaucube/babyjubjub-rs v0.0.11 for the one path this repo
+accelerates (Fr arithmetic -> PointProjective::add -> Point::mul_scalar ->
+Poseidon t=6 -> verify).  It is the *slow* oracle: used for small cases, for
+pinning the C oracle (oracle/bjj_ref.c) and for generating tests/golden/.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+anything from oracle/.  The product (libbjj_hip.so) never does.
+
+Parity status: PINNED.  Every known-answer test the reference holds for this
+path is reproduced by tests/test_oracle_kat.py (reference src/lib.rs:421-552,
+689-738).  The Poseidon constants live in the third-party crate poseidon-rs
+0.0.8 (Cargo.toml:20), which is not vendored under /root/reference; they are
+regenerated here with the Poseidon paper's Grain-LFSR procedure and pinned by
+the reference's own verify() vector (src/lib.rs:689-738) plus the public
+circomlib Poseidon values.
+
+Reference citations use `lib.rs:N` for /root/reference/src/lib.rs line N.
+"""
+
+# ---------------------------------------------------------------------------
+# Constants (lib.rs:28-60)
+# ---------------------------------------------------------------------------
+Q = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # lib.rs:33-36
+A = 168700  # lib.rs:30
+D = 168696  # lib.rs:28
+B8 = (
+    5299619240641551281634865583518297030282874472190772894086521144482721001553,
+    16950150798460657717958625567821834550301663161624707787222815936182638968203,
+)  # lib.rs:37-46
+ORDER = 21888242871839275222246405745257275088614511777268538073601725287587578984328  # lib.rs:47-50
+SUBORDER = ORDER >> 3  # lib.rs:53-58
+
+
+def finv(a):
+    return pow(a % Q, Q - 2, Q)
+
+
+# ---------------------------------------------------------------------------
+# PointProjective (lib.rs:62-132)
+# ---------------------------------------------------------------------------
+def proj_add(p, q):
+    """PointProjective::add, add-2008-bbjlp, exact op order of lib.rs:88-131."""
+    x1, y1, z1 = p
+    x2, y2, z2 = q
+    a = z1 * z2 % Q            # lib.rs:91-92
+    b = a * a % Q              # lib.rs:93-94
+    c = x1 * x2 % Q            # lib.rs:95-96
+    d = y1 * y2 % Q            # lib.rs:97-98
+    e = D * c % Q              # lib.rs:99-100
+    e = e * d % Q              # lib.rs:101
+    f = (b - e) % Q            # lib.rs:102-103
+    g = (b + e) % Q            # lib.rs:104-105
+    x1y1 = (x1 + y1) % Q       # lib.rs:106-107
+    x2y2 = (x2 + y2) % Q       # lib.rs:108-109
+    aux = x1y1 * x2y2 % Q      # lib.rs:110-111
+    aux = (aux - c) % Q        # lib.rs:112
+    aux = (aux - d) % Q        # lib.rs:113
+    x3 = a * f % Q             # lib.rs:114-115
+    x3 = x3 * aux % Q          # lib.rs:116
+    ac = A * c % Q             # lib.rs:117-118
+    dac = (d - ac) % Q         # lib.rs:119-120
+    y3 = a * g % Q             # lib.rs:121-122
+    y3 = y3 * dac % Q          # lib.rs:123
+    z3 = f * g % Q             # lib.rs:124-125
+    return (x3, y3, z3)
+
+
+def proj_affine(p):
+    """PointProjective::affine, lib.rs:70-85 (z == 0 -> (0, 0))."""
+    x, y, z = p
+    if z % Q == 0:
+        return (0, 0)
+    zi = finv(z)
+    return (x * zi % Q, y * zi % Q)
+
+
+# ---------------------------------------------------------------------------
+# Point (lib.rs:134-190)
+# ---------------------------------------------------------------------------
+def mul_scalar(pt, n):
+    """Point::mul_scalar, lib.rs:149-164: LSB-first double-and-add over
+    n.bits() bits, sign of n dropped (to_bytes_le discards it), doubling done
+    with the unified add, one affine() at the end."""
+    n = abs(n)
+    r = (0, 1, 1)
+    exp = (pt[0] % Q, pt[1] % Q, 1)
+    for i in range(n.bit_length()):
+        if (n >> i) & 1:
+            r = proj_add(r, exp)
+        exp = proj_add(exp, exp)
+    return proj_affine(r)
+
+
+def on_curve(pt):
+    x, y = pt
+    return (A * x * x + y * y - 1 - D * x * x * y * y) % Q == 0
+
+
+def compress(pt):
+    """Point::compress, lib.rs:166-178 (used only for the G4 golden vector)."""
+    x, y = pt
+    b = bytearray(y.to_bytes(32, "little"))
+    if x > (Q >> 1):
+        b[31] |= 0x80
+    return bytes(b)
+
+
+# ---------------------------------------------------------------------------
+# Poseidon (third-party poseidon-rs 0.0.8)
+# ---------------------------------------------------------------------------
+_RP_TABLE = [56, 57, 56, 60, 60, 63, 64, 63]  # t = 2..9
+_RF = 8
+
+
+class _Grain:
+    """Grain LFSR of the Poseidon reference parameter generator."""
+
+    def __init__(self, t, rp, n=254, field=1, sbox=0, rf=_RF):
+        bits = []
+
+        def put(v, w):
+            bits.extend(((v >> (w - 1 - i)) & 1) for i in range(w))
+
+        put(field, 2)
+        put(sbox, 4)
+        put(n, 12)
+        put(t, 12)
+        put(rf, 10)
+        put(rp, 10)
+        bits.extend([1] * 30)
+        assert len(bits) == 80
+        self.s = bits
+        for _ in range(160):
+            self._step()
+
+    def _step(self):
+        s = self.s
+        nb = s[62] ^ s[51] ^ s[38] ^ s[23] ^ s[13] ^ s[0]
+        s.pop(0)
+        s.append(nb)
+        return nb
+
+    def bit(self):
+        while True:
+            b1 = self._step()
+            b2 = self._step()
+            if b1:
+                return b2
+
+    def word(self, n=254):
+        v = 0
+        for _ in range(n):
+            v = (v << 1) | self.bit()
+        return v
+
+
+_POSEIDON_CACHE = {}
+
+
+def poseidon_params(t):
+    """(C, M): round constants C[68*t] (rejection-sampled < Q) and the Cauchy
+    MDS matrix M[i][j] = 1/(x_i + y_j) (samples reduced mod Q)."""
+    if t in _POSEIDON_CACHE:
+        return _POSEIDON_CACHE[t]
+    rp = _RP_TABLE[t - 2]
+    g = _Grain(t, rp)
+    C = []
+    while len(C) < (_RF + rp) * t:
+        v = g.word()
+        if v < Q:
+            C.append(v)
+    xs = [g.word() % Q for _ in range(t)]
+    ys = [g.word() % Q for _ in range(t)]
+    M = [[finv(xs[i] + ys[j]) for j in range(t)] for i in range(t)]
+    _POSEIDON_CACHE[t] = (C, M, rp)
+    return _POSEIDON_CACHE[t]
+
+
+def poseidon(inputs):
+    """Poseidon::hash (poseidon-rs 0.0.8) as called at lib.rs:400-404:
+    state = [0, in...]; (RF + RP) rounds of ark, x^5 s-box (all / first
+    element), state <- M . state; returns state[0]."""
+    t = len(inputs) + 1
+    C, M, rp = poseidon_params(t)
+    st = [0] + [v % Q for v in inputs]
+    nr = _RF + rp
+    for r in range(nr):
+        st = [(st[j] + C[r * t + j]) % Q for j in range(t)]
+        if r < _RF // 2 or r >= _RF // 2 + rp:
+            st = [pow(v, 5, Q) for v in st]
+        else:
+            st[0] = pow(st[0], 5, Q)
+        st = [sum(M[i][j] * st[j] for j in range(t)) % Q for i in range(t)]
+    return st[0]
+
+
+# ---------------------------------------------------------------------------
+# verify (lib.rs:395-412)
+# ---------------------------------------------------------------------------
+def verify(pk, sig_r, sig_s, msg):
+    """verify(pk, Signature{r_b8, s}, msg) -> bool, lib.rs:395-412."""
+    if msg > Q:                                   # lib.rs:396-398
+        return False
+    msg_fr = msg % Q                              # lib.rs:399 (from_str wraps msg == Q to 0)
+    hm = poseidon([sig_r[0], sig_r[1], pk[0], pk[1], msg_fr])  # lib.rs:400-404
+    l = mul_scalar(B8, sig_s)                     # lib.rs:405
+    t = mul_scalar(pk, 8 * hm)                    # lib.rs:410
+    r = proj_add((sig_r[0] % Q, sig_r[1] % Q, 1), (t[0], t[1], 1))  # lib.rs:407-410
+    ra = proj_affine(r)                           # lib.rs:411
+    return l[0] == ra[0] and l[1] == ra[1]
+
+
+def sign_with_scalars(k, rho, msg):
+    """Algebraic equivalent of PrivateKey::sign (lib.rs:308-342) given the
+    already-derived secret scalar k (= scalar_key() << 3 >> 3 ... i.e. the
+    value whose 8x is used at lib.rs:335) and nonce rho: A = k*B8 ... NOTE the
+    reference computes public() = B8 * scalar_key() (lib.rs:304-306) and
+    S = r + hm * (scalar_key() << 3) (lib.rs:335-339).  Here `k` plays the
+    role of scalar_key().  Used only to synthesise valid signatures for tests
+    and the benchmark (SURVEY.md 8d cfg 4)."""
+    Apt = mul_scalar(B8, k)
+    R = mul_scalar(B8, rho)
+    hm = poseidon([R[0], R[1], Apt[0], Apt[1], msg % Q])
+    S = (rho + hm * (k << 3)) % SUBORDER
+    return Apt, R, S
+
+
+# ---------------------------------------------------------------------------
+# SplitMix64: the one synthetic-input generator
+# ---------------------------------------------------------------------------
+MASK64 = (1 << 64) - 1
+SEED_SCALARS = 0x424A4A5F5343414C
+SEED_POINTS = 0x424A4A5F504F494E
+SEED_MSGS = 0x424A4A5F4D534753
+SEED_KEYS = 0x424A4A5F4B455953
+SEED_NONCES = 0x424A4A5F4E4F4E43
+SEED_BAD = 0x424A4A5F42414421
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & MASK64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+    def u256(self):
+        """4 x u64, little-endian limbs -> one 256-bit integer."""
+        v = 0
+        for i in range(4):
+            v |= self.next() << (64 * i)
+        return v
+
+
+# order-8 torsion point (SURVEY.md 8d cfg 3)
+T8 = (
+    4342719913949491028786768530115087822524712248835451589697801404893164183326,
+    4826523245007015323400664741523384119579596407052839571721035538011798951543,
+)
+
+
+def to_le32(v):
+    return int(v).to_bytes(32, "little")
+
+
+def from_le32(b):
+    return int.from_bytes(bytes(b), "little")

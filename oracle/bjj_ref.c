@@ -1,0 +1,357 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU restatement ("port") of the reference
+ * algorithm of arnaucube/babyjubjub-rs v0.0.11 for the hot path this repo
+ * accelerates.  Not shipped, not linked into libbjj_hip.so.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * What it follows (file:line into /root/reference):
+ *   constants              src/lib.rs:28-60
+ *   PointProjective::affine src/lib.rs:70-85
+ *   PointProjective::add   src/lib.rs:88-131   (add-2008-bbjlp, same op order)
+ *   Point::mul_scalar      src/lib.rs:149-164  (LSB-first, bit-serial, unified
+ *                                               add also used for doubling)
+ *   test_bit               src/lib.rs:188-190
+ *   verify                 src/lib.rs:395-412
+ *   Fr                     third-party ff_ce 0.11 derive (Cargo.toml:12): 4 x u64
+ *                          Montgomery limbs, R = 2^256; restated from the
+ *                          published algorithm
+ *   Poseidon::hash         third-party poseidon-rs 0.0.8 (Cargo.toml:20);
+ *                          restated from the published algorithm (SURVEY.md
+ *                          Appendix B), constants from gen_oracle_constants.py
+ *
+ * Parity status: PINNED.  tests/test_oracle_kat.py checks this library against
+ * every known-answer vector the reference's tests hold for the path
+ * (src/lib.rs:421-552, 689-738) and against oracle/bjj_oracle.py.
+ *
+ * All values cross this file's C boundary as 32-byte little-endian canonical
+ * integers (exactly Fr::into_repr().0 as [u64;4]).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdlib.h>
+#include <pthread.h>
+#include "bjj_ref_constants.h"
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fr_t;            /* Montgomery form, value < r */
+typedef struct { fr_t x, y, z; } proj_t;           /* lib.rs:62-67 */
+typedef struct { fr_t x, y; } point_t;             /* lib.rs:134-138 */
+
+/* r = Q, lib.rs:33-36 */
+static const fr_t MODULUS = {{0x43e1f593f0000001ULL, 0x2833e84879b97091ULL,
+                              0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+#define INV64 0xc2e1f593efffffffULL /* -r^-1 mod 2^64 */
+static const fr_t R1 = {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL,
+                         0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}}; /* 2^256 mod r */
+static const fr_t R2 = {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL,
+                         0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}}; /* 2^512 mod r */
+static const fr_t ZERO = {{0, 0, 0, 0}};
+
+/* ---- Fr (ff_ce-style) -------------------------------------------------- */
+static int fr_geq(const fr_t *a, const fr_t *b) {
+  for (int i = 3; i >= 0; i--) {
+    if (a->l[i] > b->l[i]) return 1;
+    if (a->l[i] < b->l[i]) return 0;
+  }
+  return 1;
+}
+static int fr_is_zero(const fr_t *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static int fr_eq(const fr_t *a, const fr_t *b) { return memcmp(a, b, sizeof(fr_t)) == 0; }
+static uint64_t add_nc(fr_t *a, const fr_t *b) { /* a += b, returns carry */
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)a->l[i] + b->l[i]; a->l[i] = (uint64_t)c; c >>= 64; }
+  return (uint64_t)c;
+}
+static uint64_t sub_nb(fr_t *a, const fr_t *b) { /* a -= b, returns borrow */
+  uint64_t br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a->l[i] - b->l[i] - br;
+    a->l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1;
+  }
+  return br;
+}
+static void fr_add(fr_t *a, const fr_t *b) { /* add_assign */
+  add_nc(a, b);
+  if (fr_geq(a, &MODULUS)) sub_nb(a, &MODULUS);
+}
+static void fr_sub(fr_t *a, const fr_t *b) { /* sub_assign */
+  if (!fr_geq(a, b)) add_nc(a, &MODULUS);
+  sub_nb(a, b);
+}
+static void fr_mul(fr_t *a, const fr_t *b) { /* mul_assign: schoolbook + Montgomery reduce */
+  uint64_t t[8] = {0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a->l[i] * b->l[j] + t[i + j];
+      t[i + j] = (uint64_t)c; c >>= 64;
+    }
+    t[i + 4] = (uint64_t)c;
+  }
+  uint64_t carry2 = 0;
+  for (int i = 0; i < 4; i++) {
+    uint64_t m = t[i] * INV64;
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)m * MODULUS.l[j] + t[i + j];
+      t[i + j] = (uint64_t)c; c >>= 64;
+    }
+    c += (u128)t[i + 4] + carry2;
+    t[i + 4] = (uint64_t)c; carry2 = (uint64_t)(c >> 64);
+  }
+  fr_t r = {{t[4], t[5], t[6], t[7]}};
+  if (carry2 || fr_geq(&r, &MODULUS)) sub_nb(&r, &MODULUS);
+  *a = r;
+}
+static void fr_square(fr_t *a) { fr_t b = *a; fr_mul(a, &b); }
+static void div2(fr_t *a) {
+  for (int i = 0; i < 3; i++) a->l[i] = (a->l[i] >> 1) | (a->l[i + 1] << 63);
+  a->l[3] >>= 1;
+}
+/* Fr::inverse: binary extended Euclid as published in ff_ce's derive output;
+ * works directly on the Montgomery representation (b starts at R2). Returns 0
+ * for zero input ("None"). */
+static int fr_inverse(fr_t *out, const fr_t *a) {
+  if (fr_is_zero(a)) return 0;
+  static const fr_t ONE_REPR = {{1, 0, 0, 0}};
+  fr_t u = *a, v = MODULUS, b = R2, c = ZERO;
+  while (!fr_eq(&u, &ONE_REPR) && !fr_eq(&v, &ONE_REPR)) {
+    while ((u.l[0] & 1) == 0) {
+      div2(&u);
+      if ((b.l[0] & 1) == 0) div2(&b);
+      else { uint64_t cy = add_nc(&b, &MODULUS); div2(&b); b.l[3] |= cy << 63; }
+    }
+    while ((v.l[0] & 1) == 0) {
+      div2(&v);
+      if ((c.l[0] & 1) == 0) div2(&c);
+      else { uint64_t cy = add_nc(&c, &MODULUS); div2(&c); c.l[3] |= cy << 63; }
+    }
+    if (!fr_geq(&v, &u)) { sub_nb(&u, &v); fr_sub(&b, &c); }
+    else { sub_nb(&v, &u); fr_sub(&c, &b); }
+  }
+  *out = fr_eq(&u, &ONE_REPR) ? b : c;
+  return 1;
+}
+static void fr_from_le(fr_t *o, const uint8_t *b) { /* reduces mod r like from_str's wrap */
+  fr_t t;
+  memcpy(t.l, b, 32);
+  /* value < 2^256 < 6r: bring below r, then to Montgomery form */
+  while (fr_geq(&t, &MODULUS)) sub_nb(&t, &MODULUS);
+  fr_mul(&t, &R2);
+  *o = t;
+}
+static void fr_to_le(uint8_t *b, const fr_t *a) { /* into_repr */
+  fr_t t = *a;
+  static const fr_t ONE_REPR = {{1, 0, 0, 0}};
+  fr_mul(&t, &ONE_REPR);
+  memcpy(b, t.l, 32);
+}
+static void fr_from_u64(fr_t *o, uint64_t v) {
+  fr_t t = {{v, 0, 0, 0}};
+  fr_mul(&t, &R2);
+  *o = t;
+}
+
+/* ---- lazily initialised constants (lib.rs:28-60) ----------------------- */
+static fr_t C_A, C_D;
+static point_t C_B8;
+static fr_t PC[408], PM[36];
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+static void init_consts(void) {
+  fr_from_u64(&C_A, 168700); /* lib.rs:30 */
+  fr_from_u64(&C_D, 168696); /* lib.rs:28 */
+  static const uint64_t b8x[4] = {0x2893f3f6bb957051ULL, 0x2ab8d8010534e0b6ULL,
+                                  0x4eacb2e09d6277c1ULL, 0x0bb77a6ad63e739bULL};
+  static const uint64_t b8y[4] = {0x4b3c257a872d7d8bULL, 0xfce0051fb9e13377ULL,
+                                  0x25572e1cd16bf9edULL, 0x25797203f7a0b249ULL};
+  fr_from_le(&C_B8.x, (const uint8_t *)b8x); /* lib.rs:37-46 */
+  fr_from_le(&C_B8.y, (const uint8_t *)b8y);
+  for (int i = 0; i < 408; i++) fr_from_le(&PC[i], (const uint8_t *)BJJREF_POSEIDON_C[i]);
+  for (int i = 0; i < 36; i++) fr_from_le(&PM[i], (const uint8_t *)BJJREF_POSEIDON_M[i]);
+}
+static void ensure_init(void) { pthread_once(&g_once, init_consts); }
+
+/* ---- PointProjective ---------------------------------------------------- */
+static void proj_add(proj_t *o, const proj_t *p, const proj_t *q) { /* lib.rs:88-131 */
+  fr_t a = p->z;  fr_mul(&a, &q->z);
+  fr_t b = a;     fr_square(&b);
+  fr_t c = p->x;  fr_mul(&c, &q->x);
+  fr_t d = p->y;  fr_mul(&d, &q->y);
+  fr_t e = C_D;   fr_mul(&e, &c); fr_mul(&e, &d);
+  fr_t f = b;     fr_sub(&f, &e);
+  fr_t g = b;     fr_add(&g, &e);
+  fr_t x1y1 = p->x; fr_add(&x1y1, &p->y);
+  fr_t x2y2 = q->x; fr_add(&x2y2, &q->y);
+  fr_t aux = x1y1; fr_mul(&aux, &x2y2); fr_sub(&aux, &c); fr_sub(&aux, &d);
+  fr_t x3 = a;    fr_mul(&x3, &f); fr_mul(&x3, &aux);
+  fr_t ac = C_A;  fr_mul(&ac, &c);
+  fr_t dac = d;   fr_sub(&dac, &ac);
+  fr_t y3 = a;    fr_mul(&y3, &g); fr_mul(&y3, &dac);
+  fr_t z3 = f;    fr_mul(&z3, &g);
+  o->x = x3; o->y = y3; o->z = z3;
+}
+static void proj_affine(point_t *o, const proj_t *p) { /* lib.rs:70-85 */
+  if (fr_is_zero(&p->z)) { o->x = ZERO; o->y = ZERO; return; }
+  fr_t zinv; fr_inverse(&zinv, &p->z);
+  o->x = p->x; fr_mul(&o->x, &zinv);
+  o->y = p->y; fr_mul(&o->y, &zinv);
+}
+static int test_bit(const uint8_t *b, size_t i) { return (b[i / 8] & (1 << (i % 8))) != 0; } /* lib.rs:188-190 */
+static size_t bit_length(const uint8_t *b, size_t nbytes) {
+  for (size_t i = nbytes; i-- > 0;)
+    if (b[i]) { size_t n = i * 8; uint8_t v = b[i]; while (v) { n++; v >>= 1; } return n; }
+  return 0;
+}
+static void mul_scalar(point_t *o, const point_t *p, const uint8_t *n, size_t nbytes) { /* lib.rs:149-164 */
+  proj_t r = {ZERO, R1, R1};
+  proj_t exp = {p->x, p->y, R1};
+  size_t bits = bit_length(n, nbytes);
+  for (size_t i = 0; i < bits; i++) {
+    if (test_bit(n, i)) { proj_t t; proj_add(&t, &r, &exp); r = t; }
+    proj_t t2; proj_add(&t2, &exp, &exp); exp = t2;
+  }
+  proj_affine(o, &r);
+}
+
+/* ---- Poseidon t=6 ------------------------------------------------------- */
+static void sbox5(fr_t *x) { fr_t x2 = *x; fr_square(&x2); fr_t x4 = x2; fr_square(&x4); fr_mul(x, &x4); }
+static void poseidon5(fr_t *out, const fr_t in[5]) {
+  fr_t st[6];
+  st[0] = ZERO;
+  for (int i = 0; i < 5; i++) st[i + 1] = in[i];
+  for (int r = 0; r < 68; r++) {
+    for (int j = 0; j < 6; j++) fr_add(&st[j], &PC[r * 6 + j]);
+    if (r < 4 || r >= 64) { for (int j = 0; j < 6; j++) sbox5(&st[j]); }
+    else sbox5(&st[0]);
+    fr_t nw[6];
+    for (int i = 0; i < 6; i++) {
+      nw[i] = ZERO;
+      for (int j = 0; j < 6; j++) { fr_t t = PM[i * 6 + j]; fr_mul(&t, &st[j]); fr_add(&nw[i], &t); }
+    }
+    memcpy(st, nw, sizeof(st));
+  }
+  *out = st[0];
+}
+
+/* ---- verify (lib.rs:395-412) ------------------------------------------- */
+static int verify1(const uint8_t *pk, const uint8_t *rb8, const uint8_t *s, const uint8_t *msg) {
+  fr_t m; memcpy(m.l, msg, 32);
+  /* msg > Q -> false (lib.rs:396-398); msg == Q passes and wraps to 0 (lib.rs:399) */
+  if (fr_geq(&m, &MODULUS) && !fr_eq(&m, &MODULUS)) return 0;
+  point_t A_, R_;
+  fr_from_le(&A_.x, pk); fr_from_le(&A_.y, pk + 32);
+  fr_from_le(&R_.x, rb8); fr_from_le(&R_.y, rb8 + 32);
+  fr_t in[5] = {R_.x, R_.y, A_.x, A_.y, ZERO};
+  fr_from_le(&in[4], msg);
+  fr_t hm; poseidon5(&hm, in);                       /* lib.rs:400-404 */
+  point_t l; mul_scalar(&l, &C_B8, s, 32);           /* lib.rs:405 */
+  uint8_t hm8[33]; uint8_t hmb[32];
+  fr_to_le(hmb, &hm);                                /* lib.rs:406 */
+  unsigned carry = 0;                                /* 8 * hm_b, lib.rs:410 */
+  for (int i = 0; i < 32; i++) { unsigned v = ((unsigned)hmb[i] << 3) | carry; hm8[i] = (uint8_t)v; carry = v >> 8; }
+  hm8[32] = (uint8_t)carry;
+  point_t t; mul_scalar(&t, &A_, hm8, 33);
+  proj_t rp = {R_.x, R_.y, R1}, tp = {t.x, t.y, R1}, sum;
+  proj_add(&sum, &rp, &tp);                          /* lib.rs:407-410 */
+  point_t ra; proj_affine(&ra, &sum);                /* lib.rs:411 */
+  return fr_eq(&l.x, &ra.x) && fr_eq(&l.y, &ra.y);   /* lib.rs:180-185 */
+}
+
+/* ======================= exported C entry points ======================== */
+#define EXPORT __attribute__((visibility("default")))
+
+EXPORT void bjjref_fr_mul(const uint8_t *a, const uint8_t *b, uint8_t *o) {
+  fr_t x, y; fr_from_le(&x, a); fr_from_le(&y, b); fr_mul(&x, &y); fr_to_le(o, &x);
+}
+EXPORT void bjjref_fr_add(const uint8_t *a, const uint8_t *b, uint8_t *o) {
+  fr_t x, y; fr_from_le(&x, a); fr_from_le(&y, b); fr_add(&x, &y); fr_to_le(o, &x);
+}
+EXPORT void bjjref_fr_sub(const uint8_t *a, const uint8_t *b, uint8_t *o) {
+  fr_t x, y; fr_from_le(&x, a); fr_from_le(&y, b); fr_sub(&x, &y); fr_to_le(o, &x);
+}
+EXPORT int bjjref_fr_inverse(const uint8_t *a, uint8_t *o) {
+  fr_t x, r; fr_from_le(&x, a);
+  if (!fr_inverse(&r, &x)) { memset(o, 0, 32); return 0; }
+  fr_to_le(o, &r); return 1;
+}
+/* p, q, out: 96-byte projective (x,y,z) */
+EXPORT void bjjref_proj_add(const uint8_t *p, const uint8_t *q, uint8_t *out) {
+  ensure_init();
+  proj_t a, b, o;
+  fr_from_le(&a.x, p); fr_from_le(&a.y, p + 32); fr_from_le(&a.z, p + 64);
+  fr_from_le(&b.x, q); fr_from_le(&b.y, q + 32); fr_from_le(&b.z, q + 64);
+  proj_add(&o, &a, &b);
+  fr_to_le(out, &o.x); fr_to_le(out + 32, &o.y); fr_to_le(out + 64, &o.z);
+}
+EXPORT void bjjref_proj_affine(const uint8_t *p, uint8_t *out) {
+  ensure_init();
+  proj_t a; point_t o;
+  fr_from_le(&a.x, p); fr_from_le(&a.y, p + 32); fr_from_le(&a.z, p + 64);
+  proj_affine(&o, &a);
+  fr_to_le(out, &o.x); fr_to_le(out + 32, &o.y);
+}
+/* pt: 64-byte affine point, or NULL for B8; scalar: nbytes little-endian */
+EXPORT void bjjref_mul_scalar(const uint8_t *pt, const uint8_t *scalar, size_t nbytes, uint8_t *out) {
+  ensure_init();
+  point_t p, o;
+  if (pt) { fr_from_le(&p.x, pt); fr_from_le(&p.y, pt + 32); } else p = C_B8;
+  mul_scalar(&o, &p, scalar, nbytes);
+  fr_to_le(out, &o.x); fr_to_le(out + 32, &o.y);
+}
+EXPORT void bjjref_poseidon5(const uint8_t *in, uint8_t *out) {
+  ensure_init();
+  fr_t v[5], h;
+  for (int i = 0; i < 5; i++) fr_from_le(&v[i], in + 32 * i);
+  poseidon5(&h, v);
+  fr_to_le(out, &h);
+}
+EXPORT int bjjref_verify(const uint8_t *pk, const uint8_t *rb8, const uint8_t *s, const uint8_t *msg) {
+  ensure_init();
+  return verify1(pk, rb8, s, msg);
+}
+
+/* ---- threaded batch drivers (CPU baseline + bulk expected values) ------ */
+typedef struct {
+  int kind; /* 0 fixed-base, 1 var-base, 2 poseidon5, 3 verify */
+  const uint8_t *a, *b, *c, *d; uint8_t *out; size_t lo, hi;
+} job_t;
+static void *worker(void *arg) {
+  job_t *j = (job_t *)arg;
+  for (size_t i = j->lo; i < j->hi; i++) {
+    switch (j->kind) {
+      case 0: bjjref_mul_scalar(NULL, j->a + 32 * i, 32, j->out + 64 * i); break;
+      case 1: bjjref_mul_scalar(j->a + 64 * i, j->b + 32 * i, 32, j->out + 64 * i); break;
+      case 2: bjjref_poseidon5(j->a + 160 * i, j->out + 32 * i); break;
+      case 3: j->out[i] = (uint8_t)verify1(j->a + 64 * i, j->b + 64 * i, j->c + 32 * i, j->d + 32 * i); break;
+    }
+  }
+  return NULL;
+}
+static void run_batch(int kind, const uint8_t *a, const uint8_t *b, const uint8_t *c, const uint8_t *d,
+                      uint8_t *out, size_t n, int nthreads) {
+  ensure_init();
+  if (nthreads < 1) nthreads = 1;
+  if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+  job_t *jobs = (job_t *)malloc(sizeof(job_t) * nthreads);
+  for (int t = 0; t < nthreads; t++) {
+    jobs[t] = (job_t){kind, a, b, c, d, out, n * t / nthreads, n * (t + 1) / nthreads};
+    if (nthreads == 1) worker(&jobs[t]); else pthread_create(&th[t], NULL, worker, &jobs[t]);
+  }
+  if (nthreads > 1) for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  free(th); free(jobs);
+}
+EXPORT void bjjref_mul_fixed_base_batch(const uint8_t *scalars, size_t n, uint8_t *out, int nthreads) {
+  run_batch(0, scalars, NULL, NULL, NULL, out, n, nthreads);
+}
+EXPORT void bjjref_mul_var_base_batch(const uint8_t *pts, const uint8_t *scalars, size_t n, uint8_t *out, int nthreads) {
+  run_batch(1, pts, scalars, NULL, NULL, out, n, nthreads);
+}
+EXPORT void bjjref_poseidon5_batch(const uint8_t *in, size_t n, uint8_t *out, int nthreads) {
+  run_batch(2, in, NULL, NULL, NULL, out, n, nthreads);
+}
+EXPORT void bjjref_verify_batch(const uint8_t *pk, const uint8_t *rb8, const uint8_t *s, const uint8_t *msg,
+                                size_t n, uint8_t *ok, int nthreads) {
+  run_batch(3, pk, rb8, s, msg, ok, n, nthreads);
+}
