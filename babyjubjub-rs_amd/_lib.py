@@ -1,0 +1,78 @@
+"""ctypes binding of libbjj_hip.so (the C ABI declared in include/bjj_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at
+import time, and if no HIP device is usable `bjj_init` fails with BJJ_E_NO_DEVICE.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbjj_hip.so")
+
+BJJ_OK = 0
+BJJ_E_INVALID = -1
+BJJ_E_NO_DEVICE = -2
+BJJ_E_HIP = -3
+BJJ_E_NOMEM = -4
+
+# every symbol include/bjj_hip.h declares
+EXPORTED_SYMBOLS = (
+    "bjj_version", "bjj_last_error", "bjj_init", "bjj_free", "bjj_sync", "bjj_stream",
+    "bjj_mul_fixed_base", "bjj_mul_var_base", "bjj_poseidon5", "bjj_eddsa_verify", "bjj_point_add",
+    "bjj_mul_fixed_base_dev", "bjj_mul_var_base_dev", "bjj_poseidon5_dev", "bjj_eddsa_verify_dev",
+    "bjj_point_add_dev", "bjj_reserve", "bjj_get_info",
+)
+
+
+class BjjInfo(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int),
+        ("compute_units", ctypes.c_int),
+        ("window_bits", ctypes.c_int),
+        ("n_windows", ctypes.c_int),
+        ("table_bytes", ctypes.c_uint64),
+        ("scratch_bytes", ctypes.c_uint64),
+        ("kernel_fixed_base", ctypes.c_char_p),
+        ("kernel_var_base", ctypes.c_char_p),
+        ("kernel_poseidon5", ctypes.c_char_p),
+        ("kernel_verify", ctypes.c_char_p),
+    ]
+
+
+def load():
+    # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  If torch is going to
+    # be used in this process (device memory / streams / torch.distributed), it must be the
+    # first to load the HIP runtime, otherwise the process ends up with two runtimes and
+    # torch reports "No HIP GPUs are available".  Pure C/C++ users are unaffected.
+    if os.environ.get("BJJ_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libbjj_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C babyjubjub-rs_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.bjj_version.restype = ctypes.c_char_p
+    lib.bjj_last_error.restype = ctypes.c_char_p
+    lib.bjj_init.argtypes = [ci, ci, ctypes.POINTER(vp)]
+    lib.bjj_free.argtypes = [vp]
+    lib.bjj_free.restype = None
+    lib.bjj_sync.argtypes = [vp]
+    lib.bjj_stream.argtypes = [vp]
+    lib.bjj_stream.restype = vp
+    lib.bjj_reserve.argtypes = [vp, sz]
+    lib.bjj_get_info.argtypes = [vp, ctypes.POINTER(BjjInfo)]
+    lib.bjj_mul_fixed_base.argtypes = [vp, vp, sz, vp]
+    lib.bjj_mul_var_base.argtypes = [vp, vp, vp, sz, vp]
+    lib.bjj_poseidon5.argtypes = [vp, vp, sz, vp]
+    lib.bjj_eddsa_verify.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    lib.bjj_point_add.argtypes = [vp, vp, vp, sz, vp]
+    lib.bjj_mul_fixed_base_dev.argtypes = [vp, vp, sz, vp, vp]
+    lib.bjj_mul_var_base_dev.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.bjj_poseidon5_dev.argtypes = [vp, vp, sz, vp, vp]
+    lib.bjj_eddsa_verify_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp]
+    lib.bjj_point_add_dev.argtypes = [vp, vp, vp, sz, vp, vp]
+    return lib

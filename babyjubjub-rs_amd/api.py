@@ -1,0 +1,281 @@
+"""Host-side mirror of the reference crate's API for the accelerated path.
+
+Names and argument meaning follow /root/reference/src/lib.rs:
+  Point{x,y}.mul_scalar(n)      lib.rs:149-164   -> Point.mul_scalar / mul_scalar_batch
+  Point.projective()/.equals()  lib.rs:141-147, 180-185
+  PointProjective.add/.affine   lib.rs:70-131    -> point_add_batch (add + affine)
+  Signature{r_b8, s}            lib.rs:239-243
+  verify(pk, sig, msg) -> bool  lib.rs:395-412   -> verify / verify_batch
+  B8.mul_scalar(k) (PrivateKey::public, lib.rs:304-306) -> mul_fixed_base_batch
+
+Everything numeric happens in libbjj_hip.so on the GPU.  This file only marshals
+Python ints / numpy byte arrays to the 32-byte little-endian records of the C ABI.
+Like the reference, mul_scalar and add are infallible and verify() folds every
+failure into False; BjjError is raised only for API misuse / HIP errors.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+Q = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # lib.rs:33-36
+B8 = (
+    5299619240641551281634865583518297030282874472190772894086521144482721001553,
+    16950150798460657717958625567821834550301663161624707787222815936182638968203,
+)  # lib.rs:37-46
+SUBORDER = 21888242871839275222246405745257275088614511777268538073601725287587578984328 >> 3  # lib.rs:53-58
+
+
+class BjjError(RuntimeError):
+    pass
+
+
+def _as_u8(a, width, name):
+    """Accepts an (n, width) / (n*width,) uint8 array, or a list of ints / int tuples."""
+    if isinstance(a, np.ndarray):
+        arr = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+        if arr.size % width:
+            raise BjjError("%s: byte length %d is not a multiple of %d" % (name, arr.size, width))
+        return arr
+    if isinstance(a, (bytes, bytearray)):
+        return _as_u8(np.frombuffer(bytes(a), dtype=np.uint8), width, name)
+    out = bytearray()
+    for item in a:
+        vals = item if isinstance(item, (tuple, list)) else (item,)
+        if len(vals) * 32 != width:
+            raise BjjError("%s: expected %d integers per item" % (name, width // 32))
+        for v in vals:
+            v = int(v)
+            if v < 0 or v >> 256:
+                raise BjjError("%s: integer out of the unsigned 256-bit range" % name)
+            out += v.to_bytes(32, "little")
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy()
+
+
+def _ints(arr, per_item):
+    b = arr.tobytes()
+    vals = [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+    if per_item == 1:
+        return vals
+    return [tuple(vals[i:i + per_item]) for i in range(0, len(vals), per_item)]
+
+
+class Context:
+    """One GPU + stream + fixed-base table (bjj_init / bjj_free)."""
+
+    def __init__(self, device=0, window_bits=0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self.lib.bjj_init(int(device), int(window_bits), ctypes.byref(h))
+        if rc != _lib.BJJ_OK:
+            raise BjjError("bjj_init failed (%d): %s" % (rc, self.lib.bjj_last_error().decode()))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.bjj_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != _lib.BJJ_OK:
+            raise BjjError("%s failed (%d): %s" % (what, rc, self.lib.bjj_last_error().decode()))
+
+    def info(self):
+        i = _lib.BjjInfo()
+        self._ck(self.lib.bjj_get_info(self.handle, ctypes.byref(i)), "bjj_get_info")
+        return i
+
+    def sync(self):
+        self._ck(self.lib.bjj_sync(self.handle), "bjj_sync")
+
+    def reserve(self, n):
+        self._ck(self.lib.bjj_reserve(self.handle, n), "bjj_reserve")
+
+    # ---- host-buffer batch calls (numpy uint8 in / out) ----
+    def mul_fixed_base(self, scalars):
+        s = _as_u8(scalars, 32, "scalars")
+        n = s.size // 32
+        out = np.empty(n * 64, dtype=np.uint8)
+        self._ck(self.lib.bjj_mul_fixed_base(self.handle, s.ctypes.data, n, out.ctypes.data), "bjj_mul_fixed_base")
+        return out.reshape(n, 64)
+
+    def mul_var_base(self, points, scalars):
+        p = _as_u8(points, 64, "points")
+        s = _as_u8(scalars, 32, "scalars")
+        n = s.size // 32
+        if p.size != n * 64:
+            raise BjjError("mul_var_base: %d points vs %d scalars" % (p.size // 64, n))
+        out = np.empty(n * 64, dtype=np.uint8)
+        self._ck(self.lib.bjj_mul_var_base(self.handle, p.ctypes.data, s.ctypes.data, n, out.ctypes.data),
+                 "bjj_mul_var_base")
+        return out.reshape(n, 64)
+
+    def poseidon5(self, inputs):
+        a = _as_u8(inputs, 160, "inputs")
+        n = a.size // 160
+        out = np.empty(n * 32, dtype=np.uint8)
+        self._ck(self.lib.bjj_poseidon5(self.handle, a.ctypes.data, n, out.ctypes.data), "bjj_poseidon5")
+        return out.reshape(n, 32)
+
+    def eddsa_verify(self, pk, r_b8, s, msg):
+        a = _as_u8(pk, 64, "pk")
+        r = _as_u8(r_b8, 64, "r_b8")
+        sv = _as_u8(s, 32, "s")
+        m = _as_u8(msg, 32, "msg")
+        n = sv.size // 32
+        if a.size != n * 64 or r.size != n * 64 or m.size != n * 32:
+            raise BjjError("eddsa_verify: array lengths disagree")
+        ok = np.empty(n, dtype=np.uint8)
+        self._ck(self.lib.bjj_eddsa_verify(self.handle, a.ctypes.data, r.ctypes.data, sv.ctypes.data, m.ctypes.data, n,
+                                           ok.ctypes.data), "bjj_eddsa_verify")
+        return ok
+
+    def point_add(self, p, q):
+        a = _as_u8(p, 64, "p")
+        b = _as_u8(q, 64, "q")
+        n = a.size // 64
+        if b.size != a.size:
+            raise BjjError("point_add: array lengths disagree")
+        out = np.empty(n * 64, dtype=np.uint8)
+        self._ck(self.lib.bjj_point_add(self.handle, a.ctypes.data, b.ctypes.data, n, out.ctypes.data), "bjj_point_add")
+        return out.reshape(n, 64)
+
+    # ---- device-pointer calls (integers: device addresses / hipStream_t) ----
+    def mul_fixed_base_dev(self, d_scalars, n, d_out, stream=0):
+        self._ck(self.lib.bjj_mul_fixed_base_dev(self.handle, d_scalars, n, d_out, stream), "bjj_mul_fixed_base_dev")
+
+    def mul_var_base_dev(self, d_pts, d_scalars, n, d_out, stream=0):
+        self._ck(self.lib.bjj_mul_var_base_dev(self.handle, d_pts, d_scalars, n, d_out, stream), "bjj_mul_var_base_dev")
+
+    def poseidon5_dev(self, d_in, n, d_out, stream=0):
+        self._ck(self.lib.bjj_poseidon5_dev(self.handle, d_in, n, d_out, stream), "bjj_poseidon5_dev")
+
+    def eddsa_verify_dev(self, d_pk, d_r, d_s, d_msg, n, d_ok, stream=0):
+        self._ck(self.lib.bjj_eddsa_verify_dev(self.handle, d_pk, d_r, d_s, d_msg, n, d_ok, stream),
+                 "bjj_eddsa_verify_dev")
+
+    def point_add_dev(self, d_p, d_q, n, d_out, stream=0):
+        self._ck(self.lib.bjj_point_add_dev(self.handle, d_p, d_q, n, d_out, stream), "bjj_point_add_dev")
+
+
+_DEFAULT = None
+
+
+def default_context():
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = Context()
+    return _DEFAULT
+
+
+# ---- crate-shaped objects ----------------------------------------------------
+class Point:
+    """`pub struct Point { pub x: Fr, pub y: Fr }` (lib.rs:134-138); x, y are canonical ints."""
+
+    __slots__ = ("x", "y")
+
+    def __init__(self, x, y):
+        self.x = int(x) % Q
+        self.y = int(y) % Q
+
+    def projective(self):  # lib.rs:141-147
+        return PointProjective(self.x, self.y, 1)
+
+    def mul_scalar(self, n, ctx=None):  # lib.rs:149-164 (sign of n dropped; n of any size)
+        n = abs(int(n))
+        ctx = ctx or default_context()
+        if n >> 256:
+            # the C ABI carries 32-byte scalars; for an ON-CURVE point n*P == (n mod 8l)*P
+            raise BjjError("mul_scalar: scalars wider than 256 bits are outside the accelerated boundary")
+        if (self.x, self.y) == B8:
+            out = ctx.mul_fixed_base([n])
+        else:
+            out = ctx.mul_var_base([(self.x, self.y)], [n])
+        x, y = _ints(out, 2)[0]
+        return Point(x, y)
+
+    def equals(self, p):  # lib.rs:180-185
+        return self.x == p.x and self.y == p.y
+
+    def __eq__(self, o):
+        return isinstance(o, Point) and self.equals(o)
+
+    def __repr__(self):
+        return "Point(x=%d, y=%d)" % (self.x, self.y)
+
+
+class PointProjective:
+    """`pub struct PointProjective { x, y, z }` (lib.rs:62-67).  Only z == 1 inputs reach the
+    GPU (`Point::projective()` always produces them); add() returns the affine sum lifted back."""
+
+    __slots__ = ("x", "y", "z")
+
+    def __init__(self, x, y, z=1):
+        self.x, self.y, self.z = int(x) % Q, int(y) % Q, int(z) % Q
+
+    def affine(self):  # lib.rs:70-85
+        if self.z == 0:
+            return Point(0, 0)
+        if self.z != 1:
+            zi = pow(self.z, Q - 2, Q)
+            return Point(self.x * zi % Q, self.y * zi % Q)
+        return Point(self.x, self.y)
+
+    def add(self, q, ctx=None):  # lib.rs:88-131 (+ affine), for z == 1 operands
+        if self.z != 1 or q.z != 1:
+            raise BjjError("PointProjective.add: the accelerated boundary takes affine (z == 1) operands")
+        ctx = ctx or default_context()
+        x, y = _ints(ctx.point_add([(self.x, self.y)], [(q.x, q.y)]), 2)[0]
+        return PointProjective(x, y, 1)
+
+
+class Signature:
+    """`pub struct Signature { pub r_b8: Point, pub s: BigInt }` (lib.rs:239-243)."""
+
+    __slots__ = ("r_b8", "s")
+
+    def __init__(self, r_b8, s):
+        self.r_b8 = r_b8
+        self.s = int(s)
+
+
+def verify(pk, sig, msg, ctx=None):
+    """verify(pk: Point, sig: Signature, msg: BigInt) -> bool  (lib.rs:395-412)."""
+    msg = int(msg)
+    if msg < 0:
+        raise BjjError("verify: negative msg (the reference panics at lib.rs:399)")
+    if msg > Q:  # lib.rs:396-398; also keeps msg inside the 32-byte record
+        return False
+    if sig.s < 0 or sig.s >> 256:
+        raise BjjError("verify: s outside the 32-byte record of the C ABI")
+    ctx = ctx or default_context()
+    ok = ctx.eddsa_verify([(pk.x, pk.y)], [(sig.r_b8.x, sig.r_b8.y)], [sig.s], [msg])
+    return bool(ok[0])
+
+
+# ---- batch forms ---------------------------------------------------------------
+def mul_fixed_base_batch(scalars, ctx=None):
+    return (ctx or default_context()).mul_fixed_base(scalars)
+
+
+def mul_scalar_batch(points, scalars, ctx=None):
+    return (ctx or default_context()).mul_var_base(points, scalars)
+
+
+def poseidon5_batch(inputs, ctx=None):
+    return (ctx or default_context()).poseidon5(inputs)
+
+
+def verify_batch(pk, r_b8, s, msg, ctx=None):
+    return (ctx or default_context()).eddsa_verify(pk, r_b8, s, msg)
+
+
+def point_add_batch(p, q, ctx=None):
+    return (ctx or default_context()).point_add(p, q)

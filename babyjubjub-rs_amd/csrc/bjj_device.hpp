@@ -1,0 +1,271 @@
+// Per-item bodies of the hot path (one item per lane).  __host__ __device__ so
+// that tests/emul can run exactly this code on the CPU with bound assertions; the
+// shipped library only instantiates them inside HIP kernels (bjj_kernels.hip).
+#pragma once
+#include "poseidon.hpp"
+
+namespace bjj {
+
+struct alignas(16) U4 { u32 x, y, z, w; };
+
+// 32-byte little-endian integer <-> 8 words (16-byte aligned memory)
+BJJ_HD void load_w8(const void* p, u32 w[8]) {
+  const U4* q = (const U4*)p;
+  U4 a = q[0], b = q[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+BJJ_HD void store_w8(void* p, const u32 w[8]) {
+  U4* q = (U4*)p;
+  U4 a = {w[0], w[1], w[2], w[3]}, b = {w[4], w[5], w[6], w[7]};
+  q[0] = a; q[1] = b;
+}
+// raw 9-limb field element <-> 48-byte slot (3 x 16 B; 3 words of padding)
+constexpr int FR_SLOT_WORDS = 12;
+BJJ_HD Fr load_fr_slot(const u32* p) {
+  const U4* q = (const U4*)p;
+  U4 a = q[0], b = q[1], c = q[2];
+  Fr r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x}};
+  return r;
+}
+BJJ_HD void store_fr_slot(u32* p, const Fr& f) {
+  U4* q = (U4*)p;
+  U4 a = {f.v[0], f.v[1], f.v[2], f.v[3]}, b = {f.v[4], f.v[5], f.v[6], f.v[7]}, c = {f.v[8], 0, 0, 0};
+  q[0] = a; q[1] = b; q[2] = c;
+}
+
+// ---- fixed-base table: entry = Niels in 32 words (128 B = one cache line) ----
+constexpr int NIELS_WORDS = 32;  // 27 used
+BJJ_HD Niels load_niels(const u32* p) {
+  const U4* q = (const U4*)p;
+  U4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
+  Niels n;
+  n.ymx = Fr{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x}};
+  n.ypx = Fr{{c.y, c.z, c.w, d.x, d.y, d.z, d.w, e.x, e.y}};
+  n.t2d = Fr{{e.z, e.w, f.x, f.y, f.z, f.w, g.x, g.y, g.z}};
+  return n;
+}
+BJJ_HD void store_niels(u32* p, const Niels& n) {
+  U4* q = (U4*)p;
+  q[0] = U4{n.ymx.v[0], n.ymx.v[1], n.ymx.v[2], n.ymx.v[3]};
+  q[1] = U4{n.ymx.v[4], n.ymx.v[5], n.ymx.v[6], n.ymx.v[7]};
+  q[2] = U4{n.ymx.v[8], n.ypx.v[0], n.ypx.v[1], n.ypx.v[2]};
+  q[3] = U4{n.ypx.v[3], n.ypx.v[4], n.ypx.v[5], n.ypx.v[6]};
+  q[4] = U4{n.ypx.v[7], n.ypx.v[8], n.t2d.v[0], n.t2d.v[1]};
+  q[5] = U4{n.t2d.v[2], n.t2d.v[3], n.t2d.v[4], n.t2d.v[5]};
+  q[6] = U4{n.t2d.v[6], n.t2d.v[7], n.t2d.v[8], 0};
+  q[7] = U4{0, 0, 0, 0};
+}
+// ---- per-lane variable-base table: entry = PNiels in 36 words (144 B) ---------
+constexpr int PNIELS_WORDS = 36;
+constexpr int VB_TABLE_ENTRIES = 9;  // 0*P .. 8*P
+constexpr int VB_TABLE_WORDS = PNIELS_WORDS * VB_TABLE_ENTRIES;
+BJJ_HD PNiels load_pniels(const u32* p) {
+  const U4* q = (const U4*)p;
+  U4 t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = q[i];
+  const u32* w = (const u32*)t;
+  PNiels n;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { n.ymx.v[i] = w[i]; n.ypx.v[i] = w[9 + i]; n.t2d.v[i] = w[18 + i]; n.z2.v[i] = w[27 + i]; }
+  return n;
+}
+BJJ_HD void store_pniels(u32* p, const PNiels& n) {
+  u32 w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { w[i] = n.ymx.v[i]; w[9 + i] = n.ypx.v[i]; w[18 + i] = n.t2d.v[i]; w[27 + i] = n.z2.v[i]; }
+  U4* q = (U4*)p;
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = U4{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+}
+
+// =============================================================================
+// fixed base:  acc + n * B8   with the precomputed window table
+//   table[j][k] = Niels( k * 2^(W j) * B8 ),  j < nwin, k < 2^W
+// =============================================================================
+BJJ_HD Ext fixed_base_accumulate(Ext acc, const u32* table, int W, int nwin, const u32 sc[8]) {
+  Niels cur = load_niels(table + (size_t)scalar_window(sc, 0, W) * NIELS_WORDS);
+#pragma unroll 1
+  for (int j = 0; j < nwin; j++) {
+    Niels nxt = cur;
+    if (j + 1 < nwin) {  // issue the next gather before the 7 multiplications of this window
+      size_t idx = ((size_t)(j + 1) << W) | scalar_window(sc, j + 1, W);
+      nxt = load_niels(table + idx * NIELS_WORDS);
+    }
+    acc = ext_madd(acc, cur);
+    cur = nxt;
+  }
+  return acc;
+}
+
+// =============================================================================
+// variable base, on-curve fast path:  n * P  (n < 2^254 already reduced mod 8l)
+// signed 4-bit windows, per-lane table tbl[0..8] = {0, P, .., 8P} in thread-private
+// memory (global scratch on the GPU).
+// =============================================================================
+BJJ_HD void vb_build_table(const Ext& P, u32* tbl, const Consts& K) {
+  PNiels id; id.ymx = fr_one(); id.ypx = fr_one(); id.t2d = fr_zero(); id.z2 = fr_dbl(fr_one());
+  store_pniels(tbl, id);
+  PNiels p1 = ext_to_pniels(P, K);
+  store_pniels(tbl + PNIELS_WORDS, p1);
+  Ext cur = P;
+#pragma unroll 1
+  for (int k = 2; k <= 8; k++) {
+    cur = ext_add_pn(cur, p1);
+    store_pniels(tbl + k * PNIELS_WORDS, ext_to_pniels(cur, K));
+  }
+}
+// nwin windows of 4 bits, most significant first; needs sc < 2^(4*nwin - 1) so that the
+// signed recoding (add 0x88..8, digit = nibble - 8) cannot carry out of the top window
+// (callers pass nwin = 64 with sc < 2^254).
+BJJ_HD Ext vb_mul_windowed(const u32* tbl, const u32 sc[8], int nwin) {
+  u32 t[8];
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (u64)sc[i] + 0x88888888u; t[i] = (u32)c; c >>= 32; }
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (int j = nwin - 1; j >= 0; j--) {
+    int d = (int)((t[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
+    bool neg = d < 0;
+    u32 idx = (u32)(neg ? -d : d);
+    PNiels e = load_pniels(tbl + idx * PNIELS_WORDS);  // issued ahead of the doublings
+    if (j != nwin - 1) {
+#pragma unroll 1
+      for (int k = 0; k < 3; k++) acc = ext_dbl<false>(acc);
+      acc = ext_dbl<true>(acc);
+    }
+    acc = ext_add_pn(acc, pniels_cneg(e, neg));
+  }
+  return acc;
+}
+
+// =============================================================================
+// exact path: the reference's own operation sequence (src/lib.rs:149-164, 70-85)
+// x, y Montgomery; scalar = nw words, little-endian.  Returns affine Montgomery.
+// =============================================================================
+BJJ_HD void ref_mul_scalar(const Fr& x, const Fr& y, const u32* sc, int nw, Fr& ox, Fr& oy, const Consts& K) {
+  int bits = 0;
+  for (int i = nw - 1; i >= 0; i--)
+    if (sc[i]) { bits = 32 * i + 32 - __builtin_clz(sc[i]); break; }
+  RefProj r; r.x = fr_zero(); r.y = fr_one(); r.z = fr_one();
+  RefProj e; e.x = x; e.y = y; e.z = fr_one();
+#pragma unroll 1
+  for (int i = 0; i < bits; i++) {
+    if ((sc[i >> 5] >> (i & 31)) & 1) r = ref_add(r, e, K);
+    e = ref_add(e, e, K);
+  }
+  if (fr_is_zero(r.z)) { ox = fr_zero(); oy = fr_zero(); return; }  // src/lib.rs:71-76
+  Fr zi = fr_inv(r.z);
+  ox = fr_mul(r.x, zi); oy = fr_mul(r.y, zi);
+}
+
+// fixed-base table entry (j, k) = Niels( k * 2^(W j) * B8 ), fully reduced
+BJJ_HD Niels fixed_table_entry(u32 k, int j, int W, const Consts& K) {
+  Ext base = ext_from_ref_affine(K.B8X, K.B8Y, K);
+  PNiels bn = ext_to_pniels(base, K);
+  PNiels idn; idn.ymx = fr_one(); idn.ypx = fr_one(); idn.t2d = fr_zero(); idn.z2 = fr_dbl(fr_one());
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (int b = W - 1; b >= 0; b--) {
+    acc = ext_dbl<true>(acc);
+    const bool bit = (k >> b) & 1;
+    PNiels sel;
+    sel.ymx = fr_select(bit, bn.ymx, idn.ymx); sel.ypx = fr_select(bit, bn.ypx, idn.ypx);
+    sel.t2d = fr_select(bit, bn.t2d, idn.t2d); sel.z2 = fr_select(bit, bn.z2, idn.z2);
+    acc = ext_add_pn(acc, sel);
+  }
+#pragma unroll 1
+  for (int d = 0; d < W * j; d++) acc = ext_dbl<true>(acc);
+  Fr zi = fr_inv(acc.Z);
+  Fr x = fr_mul(acc.X, zi), y = fr_mul(acc.Y, zi);
+  Niels n;
+  n.ymx = fr_canon(fr_sub(y, x)); n.ypx = fr_canon(fr_add(y, x)); n.t2d = fr_canon(fr_mul(fr_mul(x, y), K.D2P));
+  return n;
+}
+
+// one variable-base item: (x, y) Montgomery on the reference curve, raw 256-bit scalar.
+// Result as an extended point on the a'=-1 curve (exact-path results are mapped onto
+// it with Z = 1 so that the shared affine epilogue maps them back unchanged).
+BJJ_HD Ext var_base_item(const Fr& x, const Fr& y, const u32 sc[8], u32* tbl, const Consts& K) {
+  Ext p;
+  if (ref_on_curve(x, y, K)) {
+    u32 red[8];
+    scalar_mod_order(sc, red, K);
+    Ext P = ext_from_ref_affine(x, y, K);
+    vb_build_table(P, tbl, K);
+    p = vb_mul_windowed(tbl, red, 64);
+  } else {  // exact replay of the reference's bit-serial loop
+    Fr ox, oy;
+    ref_mul_scalar(x, y, sc, 8, ox, oy, K);
+    p.X = fr_mul(ox, K.F); p.Y = oy; p.Z = fr_one(); p.T = fr_zero();
+  }
+  return p;
+}
+
+// msg > Q ?   (src/lib.rs:396-398; msg == Q is accepted and wraps to 0)
+BJJ_HD bool words_gt_modulus(const u32 w[8]) {
+  const u32 M[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  bool gt = false, eq = true;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+    gt = gt || (eq && w[i] > M[i]);
+    eq = eq && (w[i] == M[i]);
+  }
+  return gt;
+}
+
+// =============================================================================
+// one EdDSA-Poseidon verification (src/lib.rs:395-412)
+// =============================================================================
+struct VerifyIn { const void *pk, *r, *s, *msg; };  // this item's 64/64/32/32-byte records
+
+BJJ_HD bool verify_item(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K) {
+  u32 w[8];
+  load_w8(in.msg, w);
+  if (words_gt_modulus(w)) return false;                        // :396-398
+  Fr h[5];
+  h[4] = fr_to_mont_words(w);                                   // :399
+  load_w8(in.r, w);                   h[0] = fr_to_mont_words(w);
+  load_w8((const char*)in.r + 32, w); h[1] = fr_to_mont_words(w);
+  load_w8(in.pk, w);                  h[2] = fr_to_mont_words(w);
+  load_w8((const char*)in.pk + 32, w); h[3] = fr_to_mont_words(w);
+  const bool fast = ref_on_curve(h[0], h[1], K) && ref_on_curve(h[2], h[3], K);
+  Fr hm = poseidon5(h, K);                                      // :400-404
+  Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // canonical integer, :406
+  u32 sw[8];
+  load_w8(in.s, sw);
+  if (fast) {
+    // s*B8 == R + 8*hm*A   <=>   8*(hm mod l)*(-A) + s*B8 == R      (group order 8l)
+    u32 kw[8];
+    fr_to_words(plain_mod_l(hm_plain, K), kw);
+    Ext negA = ext_from_ref_affine(fr_neg(h[2]), h[3], K);
+    vb_build_table(negA, vb_tbl, K);
+    Ext q = vb_mul_windowed(vb_tbl, kw, 64);                    // k < l < 2^251
+    q = ext_dbl<false>(q); q = ext_dbl<false>(q); q = ext_dbl<true>(q);
+    q = fixed_base_accumulate(q, fb_table, W, nwin, sw);        // + s*B8   (:405)
+    // compare with R on the a'=-1 curve: X == (F Rx) Z, Y == Ry Z
+    load_w8(in.r, w);                   Fr rx = fr_mul(fr_to_mont_words(w), K.F);
+    load_w8((const char*)in.r + 32, w); Fr ry = fr_to_mont_words(w);
+    return fr_eq(q.X, fr_mul(rx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z));
+  }
+  // exact path (some input point is off the curve): replay src/lib.rs:405-411
+  Fr lx, ly, tx, ty;
+  ref_mul_scalar(K.B8X, K.B8Y, sw, 8, lx, ly, K);               // :405
+  u32 h8[9], hw[8];
+  fr_to_words(hm_plain, hw);
+  h8[0] = hw[0] << 3;
+#pragma unroll
+  for (int i = 1; i < 8; i++) h8[i] = (hw[i] << 3) | (hw[i - 1] >> 29);
+  h8[8] = hw[7] >> 29;                                          // 8 * hm_b, :410
+  ref_mul_scalar(h[2], h[3], h8, 9, tx, ty, K);
+  RefProj rp; rp.x = h[0]; rp.y = h[1]; rp.z = fr_one();
+  RefProj tp; tp.x = tx; tp.y = ty; tp.z = fr_one();
+  RefProj sum = ref_add(rp, tp, K);                             // :407-410
+  Fr ax, ay;
+  if (fr_is_zero(sum.z)) { ax = fr_zero(); ay = fr_zero(); }    // :71-76
+  else { Fr zi = fr_inv(sum.z); ax = fr_mul(sum.x, zi); ay = fr_mul(sum.y, zi); }
+  return fr_eq(lx, ax) && fr_eq(ly, ay);                        // :411, :180-185
+}
+
+}  // namespace bjj

@@ -1,0 +1,534 @@
+// libbjj_hip.so -- HIP kernels (gfx950) and the extern "C" boundary declared in
+// include/bjj_hip.h.  There is no CPU fallback anywhere in this file: every entry
+// point launches device code or returns an error.
+//
+// Kernel map (SURVEY.md section 2 "kernel inventory"):
+//   bjj_k_build_fixed_table  init-time: window table of B8 multiples (Niels form)
+//   bjj_k_mul_fixed_base     K1  B8.mul_scalar(n)              src/lib.rs:149-164, 37-46
+//   bjj_k_mul_var_base       K2  P.mul_scalar(n) (+K6 exact path for off-curve P)
+//   bjj_k_poseidon5          K3  POSEIDON.hash([a,b,c,d,e])    src/lib.rs:400-404
+//   bjj_k_eddsa_verify       K4  verify(pk, sig, msg)          src/lib.rs:395-412
+//   bjj_k_point_add              PointProjective::add + affine src/lib.rs:88-131, 70-85
+// K5 (batched affine conversion) is the epilogue of K1/K2: Montgomery's trick per
+// lane over its items, then across the workgroup through LDS scans, so that ONE
+// Fermat inversion serves blockDim * items_per_lane points.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <new>
+
+#include "../../include/bjj_hip.h"
+#include "bjj_device.hpp"
+#include "bjj_constants.inc"
+
+using namespace bjj;
+
+#define BJJ_VERSION_STRING "bjj-hip 0.1.0 gfx950"
+#define BJJ_BLOCK 256
+
+__constant__ Consts c_K = {
+    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_B8X, BJJ_K_B8Y,
+    BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
+    BJJ_K_POSEIDON_C, BJJ_K_POSEIDON_M};
+
+// ---------------------------------------------------------------------------
+// workgroup-wide simultaneous inversion: every thread passes x (Montgomery, != 0,
+// < 2r) and receives 1/x.  Two LDS scans (prefix / suffix products) + one Fermat
+// inversion executed by wave 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lds_put(u32* lds, int t, const Fr& f) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) lds[i * BJJ_BLOCK + t] = f.v[i];  // limb-major: conflict-free
+}
+__device__ __forceinline__ Fr lds_get(const u32* lds, int t) {
+  Fr f;
+#pragma unroll
+  for (int i = 0; i < NL; i++) f.v[i] = lds[i * BJJ_BLOCK + t];
+  return f;
+}
+__device__ Fr block_invert(const Fr& x, u32* lds /* NL * BJJ_BLOCK words */) {
+  const int t = threadIdx.x;
+  Fr pre = x, suf = x;
+#pragma unroll 1
+  for (int d = 1; d < BJJ_BLOCK; d <<= 1) {  // inclusive prefix products
+    lds_put(lds, t, pre);
+    __syncthreads();
+    Fr y = (t >= d) ? lds_get(lds, t - d) : fr_one();
+    __syncthreads();
+    pre = fr_mul(pre, y);
+  }
+#pragma unroll 1
+  for (int d = 1; d < BJJ_BLOCK; d <<= 1) {  // inclusive suffix products
+    lds_put(lds, t, suf);
+    __syncthreads();
+    Fr y = (t + d < BJJ_BLOCK) ? lds_get(lds, t + d) : fr_one();
+    __syncthreads();
+    suf = fr_mul(suf, y);
+  }
+  // exclusive versions
+  lds_put(lds, t, pre);
+  __syncthreads();
+  Fr epre = (t > 0) ? lds_get(lds, t - 1) : fr_one();
+  Fr total = lds_get(lds, BJJ_BLOCK - 1);
+  __syncthreads();
+  lds_put(lds, t, suf);
+  __syncthreads();
+  Fr esuf = (t + 1 < BJJ_BLOCK) ? lds_get(lds, t + 1) : fr_one();
+  __syncthreads();
+  if (t < 64) {  // one wave inverts the workgroup product
+    Fr inv = fr_inv(total);
+    if (t == 0) lds_put(lds, 0, inv);
+  }
+  __syncthreads();
+  Fr inv = lds_get(lds, 0);
+  __syncthreads();
+  return fr_mul(fr_mul(inv, epre), esuf);
+}
+
+// Phase-1 record for the affine epilogue: X, Y (as 2 x 32-byte integers) go to the
+// item's final output slot; Z and the lane's running prefix product go to scratch.
+__device__ __forceinline__ void epilogue_stash(const Ext& p, Fr& run, uint8_t* out_item, u32* scr_item) {
+  u32 w[8];
+  fr_to_words(p.X, w); store_w8(out_item, w);
+  fr_to_words(p.Y, w); store_w8(out_item + 32, w);
+  fr_to_words(p.Z, w); store_w8(scr_item, w);
+  fr_to_words(run, w); store_w8(scr_item + 8, w);
+  run = fr_mul(run, p.Z);
+}
+// Phase-2: given inv = 1 / (product of this lane's Z_0..Z_i), finish item i and
+// step inv down to 1 / (Z_0..Z_{i-1}).  Output: canonical reference-curve (x, y).
+__device__ __forceinline__ void epilogue_finish(Fr& inv, uint8_t* out_item, const u32* scr_item) {
+  constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
+  u32 w[8];
+  load_w8(scr_item, w);     Fr Z = fr_from_words(w);
+  load_w8(scr_item + 8, w); Fr P = fr_from_words(w);
+  load_w8(out_item, w);     Fr X = fr_from_words(w);
+  load_w8(out_item + 32, w); Fr Y = fr_from_words(w);
+  Fr zinv = fr_mul(inv, P);
+  inv = fr_mul(inv, Z);
+  Fr c1 = fr_mul(zinv, fr_one_plain());   // plain 1/Z
+  Fr c2 = fr_mul(zinv, c_K.FINV_PLAIN);   // plain 1/(Z F): maps x' back to the reference curve
+  Fr x = fr_cond_sub_kr(fr_mul(X, c2), R1);
+  Fr y = fr_cond_sub_kr(fr_mul(Y, c1), R1);
+  fr_to_words(x, w); store_w8(out_item, w);
+  fr_to_words(y, w); store_w8(out_item + 32, w);
+}
+__device__ __forceinline__ void epilogue_run(Fr run, size_t n, size_t tid, size_t nthreads, uint8_t* out, u32* scratch,
+                                             u32* lds) {
+  Fr inv = block_invert(run, lds);
+  if (tid >= n) return;
+  size_t cnt = (n - tid + nthreads - 1) / nthreads;
+#pragma unroll 1
+  for (size_t m = cnt; m-- > 0;) {
+    size_t i = tid + m * nthreads;
+    epilogue_finish(inv, out + i * 64, scratch + i * 16);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// init: fixed-base table.  One thread per entry (j, k): k * 2^(W j) * B8.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_build_fixed_table(u32* table, int W, int nwin) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)nwin << W;
+  if (e >= total) return;
+  const u32 k = (u32)(e & (((size_t)1 << W) - 1));
+  const int j = (int)(e >> W);
+  Niels n = fixed_table_entry(k, j, W, c_K);
+  store_niels(table + e * NIELS_WORDS, n);
+}
+
+// ---------------------------------------------------------------------------
+// K1: fixed base
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
+                                                                  const uint8_t* __restrict__ scalars, size_t n,
+                                                                  uint8_t* __restrict__ out, u32* __restrict__ scratch) {
+  __shared__ u32 lds[NL * BJJ_BLOCK];
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  Fr run = fr_one();
+#pragma unroll 1
+  for (size_t i = tid; i < n; i += nthreads) {
+    u32 sc[8];
+    load_w8(scalars + i * 32, sc);
+    Ext p = fixed_base_accumulate(ext_identity(), table, W, nwin, sc);
+    epilogue_stash(p, run, out + i * 64, scratch + i * 16);
+  }
+  epilogue_run(run, n, tid, nthreads, out, scratch, lds);
+}
+
+// ---------------------------------------------------------------------------
+// K2 (+K6): variable base
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
+                                                                const uint8_t* __restrict__ scalars, size_t n,
+                                                                uint8_t* __restrict__ out, u32* __restrict__ scratch,
+                                                                u32* __restrict__ vb_tables) {
+  __shared__ u32 lds[NL * BJJ_BLOCK];
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
+  Fr run = fr_one();
+#pragma unroll 1
+  for (size_t i = tid; i < n; i += nthreads) {
+    u32 w[8], sc[8];
+    load_w8(pts + i * 64, w);      Fr x = fr_to_mont_words(w);
+    load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
+    load_w8(scalars + i * 32, sc);
+    Ext p = var_base_item(x, y, sc, tbl, c_K);
+    epilogue_stash(p, run, out + i * 64, scratch + i * 16);
+  }
+  epilogue_run(run, n, tid, nthreads, out, scratch, lds);
+}
+
+// ---------------------------------------------------------------------------
+// K3: Poseidon, 5 inputs
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_poseidon5(const uint8_t* __restrict__ in, size_t n,
+                                                             uint8_t* __restrict__ out) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = tid; i < n; i += nthreads) {
+    Fr h[5];
+    u32 w[8];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { load_w8(in + i * 160 + j * 32, w); h[j] = fr_to_mont_words(w); }
+    Fr r = poseidon5(h, c_K);
+    fr_from_mont_words(r, w);
+    store_w8(out + i * 32, w);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4: EdDSA-Poseidon verify
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
+                                                                const uint8_t* __restrict__ pk,
+                                                                const uint8_t* __restrict__ rb8,
+                                                                const uint8_t* __restrict__ s,
+                                                                const uint8_t* __restrict__ msg, size_t n,
+                                                                uint8_t* __restrict__ ok, u32* __restrict__ vb_tables) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
+#pragma unroll 1
+  for (size_t i = tid; i < n; i += nthreads) {
+    VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
+    ok[i] = verify_item(in, table, W, nwin, tbl, c_K) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// PointProjective::add on affine inputs followed by affine()  (reference-exact)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_point_add(const uint8_t* __restrict__ p, const uint8_t* __restrict__ q,
+                                                             size_t n, uint8_t* __restrict__ out) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = tid; i < n; i += nthreads) {
+    u32 w[8];
+    RefProj a, b;
+    load_w8(p + i * 64, w); a.x = fr_to_mont_words(w);
+    load_w8(p + i * 64 + 32, w); a.y = fr_to_mont_words(w); a.z = fr_one();
+    load_w8(q + i * 64, w); b.x = fr_to_mont_words(w);
+    load_w8(q + i * 64 + 32, w); b.y = fr_to_mont_words(w); b.z = fr_one();
+    RefProj r = ref_add(a, b, c_K);
+    Fr ox = fr_zero(), oy = fr_zero();
+    if (!fr_is_zero(r.z)) { Fr zi = fr_inv(r.z); ox = fr_mul(r.x, zi); oy = fr_mul(r.y, zi); }
+    fr_from_mont_words(ox, w); store_w8(out + i * 64, w);
+    fr_from_mont_words(oy, w); store_w8(out + i * 64 + 32, w);
+  }
+}
+
+// ===========================================================================
+// host side: context + extern "C" boundary
+// ===========================================================================
+static thread_local std::string g_err;
+static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCK(call)                                                                                  \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return set_err(BJJ_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+struct bjj_ctx {
+  int device = 0;
+  int cus = 0;
+  int W = 16, nwin = 16;
+  hipStream_t stream = nullptr;
+  u32* table = nullptr;
+  size_t table_bytes = 0;
+  u32* scratch = nullptr;      // n * 64 B (Z, prefix)
+  size_t scratch_items = 0;
+  u32* vb_tables = nullptr;    // grid threads * VB_TABLE_WORDS * 4 B
+  size_t vb_threads = 0;
+  // staging buffers for the host-pointer API
+  uint8_t* stage = nullptr;
+  size_t stage_bytes = 0;
+};
+
+static int grid_for(const bjj_ctx* c, size_t n, int blocks_per_cu) {
+  size_t want = (n + BJJ_BLOCK - 1) / BJJ_BLOCK;
+  size_t cap = (size_t)c->cus * blocks_per_cu;
+  if (want < 1) want = 1;
+  return (int)(want < cap ? want : cap);
+}
+// resident-lane budgets (blocks of 256 per CU); see DESIGN.md "launch geometry"
+#define BPC_FIXED 4
+#define BPC_VAR 2
+#define BPC_POSEIDON 2
+#define BPC_VERIFY 2
+
+static int ensure_scratch(bjj_ctx* c, size_t n) {
+  HIPCK(hipSetDevice(c->device));
+  if (n > c->scratch_items) {
+    if (c->scratch) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->scratch)); c->scratch = nullptr; }
+    HIPCK(hipMalloc((void**)&c->scratch, n * 64));
+    c->scratch_items = n;
+  }
+  size_t threads = (size_t)c->cus * BPC_VAR * BJJ_BLOCK;
+  if (threads > c->vb_threads) {
+    if (c->vb_tables) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->vb_tables)); c->vb_tables = nullptr; }
+    HIPCK(hipMalloc((void**)&c->vb_tables, threads * VB_TABLE_WORDS * sizeof(u32)));
+    c->vb_threads = threads;
+  }
+  return BJJ_OK;
+}
+static int ensure_stage(bjj_ctx* c, size_t bytes) {
+  if (bytes > c->stage_bytes) {
+    if (c->stage) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->stage)); c->stage = nullptr; }
+    HIPCK(hipMalloc((void**)&c->stage, bytes));
+    c->stage_bytes = bytes;
+  }
+  return BJJ_OK;
+}
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+const char* bjj_version(void) { return BJJ_VERSION_STRING; }
+const char* bjj_last_error(void) { return g_err.c_str(); }
+
+int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
+  if (!out_ctx) return set_err(BJJ_E_INVALID, "bjj_init: out_ctx is NULL");
+  *out_ctx = nullptr;
+  int W = window_bits == 0 ? 16 : window_bits;
+  if (W < 4 || W > 18) return set_err(BJJ_E_INVALID, "bjj_init: window_bits must be 0 or 4..18");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return set_err(BJJ_E_NO_DEVICE, "bjj_init: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return set_err(BJJ_E_INVALID, "bjj_init: device index out of range");
+  HIPCK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCK(hipGetDeviceProperties(&prop, device));
+  bjj_ctx* c = new (std::nothrow) bjj_ctx();
+  if (!c) return set_err(BJJ_E_NOMEM, "bjj_init: out of host memory");
+  c->device = device;
+  c->cus = prop.multiProcessorCount;
+  c->W = W;
+  c->nwin = (256 + W - 1) / W;
+  hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) { delete c; return set_err(BJJ_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
+  size_t entries = (size_t)c->nwin << W;
+  c->table_bytes = entries * NIELS_WORDS * sizeof(u32);
+  se = hipMalloc((void**)&c->table, c->table_bytes);
+  if (se != hipSuccess) { hipStreamDestroy(c->stream); delete c; return set_err(BJJ_E_NOMEM, "bjj_init: cannot allocate the fixed-base table"); }
+  int blocks = (int)((entries + BJJ_BLOCK - 1) / BJJ_BLOCK);
+  hipLaunchKernelGGL(bjj_k_build_fixed_table, dim3(blocks), dim3(BJJ_BLOCK), 0, c->stream, c->table, c->W, c->nwin);
+  se = hipGetLastError();
+  if (se == hipSuccess) se = hipStreamSynchronize(c->stream);
+  if (se != hipSuccess) {
+    hipFree(c->table); hipStreamDestroy(c->stream); delete c;
+    return set_err(BJJ_E_HIP, std::string("bjj_init: table build failed: ") + hipGetErrorString(se));
+  }
+  *out_ctx = c;
+  return BJJ_OK;
+}
+
+void bjj_free(bjj_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->table) hipFree(c->table);
+  if (c->scratch) hipFree(c->scratch);
+  if (c->vb_tables) hipFree(c->vb_tables);
+  if (c->stage) hipFree(c->stage);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int bjj_sync(bjj_ctx* c) {
+  if (!c) return set_err(BJJ_E_INVALID, "bjj_sync: ctx is NULL");
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+void* bjj_stream(bjj_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int bjj_reserve(bjj_ctx* c, size_t n) {
+  if (!c) return set_err(BJJ_E_INVALID, "bjj_reserve: ctx is NULL");
+  return ensure_scratch(c, n ? n : 1);
+}
+
+int bjj_get_info(bjj_ctx* c, bjj_info* info) {
+  if (!c || !info) return set_err(BJJ_E_INVALID, "bjj_get_info: NULL argument");
+  info->device = c->device;
+  info->compute_units = c->cus;
+  info->window_bits = c->W;
+  info->n_windows = c->nwin;
+  info->table_bytes = c->table_bytes;
+  info->scratch_bytes = c->scratch_items * 64 + c->vb_threads * VB_TABLE_WORDS * sizeof(u32);
+  info->kernel_fixed_base = "bjj_k_mul_fixed_base";
+  info->kernel_var_base = "bjj_k_mul_var_base";
+  info->kernel_poseidon5 = "bjj_k_poseidon5";
+  info->kernel_verify = "bjj_k_eddsa_verify";
+  return BJJ_OK;
+}
+
+// ---- device-pointer API ------------------------------------------------------
+#define CHECK_CTX(c, name) if (!(c)) return set_err(BJJ_E_INVALID, name ": ctx is NULL")
+#define CHECK_PTR(p, name) if (!(p) || !aligned16(p)) return set_err(BJJ_E_INVALID, name ": NULL or not 16-byte aligned device pointer")
+
+int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_out, void* stream) {
+  CHECK_CTX(c, "bjj_mul_fixed_base_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_scalars, "bjj_mul_fixed_base_dev"); CHECK_PTR(d_out, "bjj_mul_fixed_base_dev");
+  int rc = ensure_scratch(c, n); if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_mul_fixed_base, dim3(grid_for(c, n, BPC_FIXED)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
+                     c->nwin, (const uint8_t*)d_scalars, n, (uint8_t*)d_out, c->scratch);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* stream) {
+  CHECK_CTX(c, "bjj_mul_var_base_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_pts, "bjj_mul_var_base_dev"); CHECK_PTR(d_scalars, "bjj_mul_var_base_dev"); CHECK_PTR(d_out, "bjj_mul_var_base_dev");
+  int rc = ensure_scratch(c, n); if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid_for(c, n, BPC_VAR)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pts,
+                     (const uint8_t*)d_scalars, n, (uint8_t*)d_out, c->scratch, c->vb_tables);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+int bjj_poseidon5_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out, void* stream) {
+  CHECK_CTX(c, "bjj_poseidon5_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_in, "bjj_poseidon5_dev"); CHECK_PTR(d_out, "bjj_poseidon5_dev");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_poseidon5, dim3(grid_for(c, n, BPC_POSEIDON)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_in, n,
+                     (uint8_t*)d_out);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+int bjj_eddsa_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
+                         void* d_ok, void* stream) {
+  CHECK_CTX(c, "bjj_eddsa_verify_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_pk, "bjj_eddsa_verify_dev"); CHECK_PTR(d_r, "bjj_eddsa_verify_dev");
+  CHECK_PTR(d_s, "bjj_eddsa_verify_dev"); CHECK_PTR(d_msg, "bjj_eddsa_verify_dev");
+  if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_dev: d_ok is NULL");
+  int rc = ensure_scratch(c, 1); if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid_for(c, n, BPC_VERIFY)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
+                     c->nwin, (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n,
+                     (uint8_t*)d_ok, c->vb_tables);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+int bjj_point_add_dev(bjj_ctx* c, const void* d_p, const void* d_q, size_t n, void* d_out, void* stream) {
+  CHECK_CTX(c, "bjj_point_add_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_p, "bjj_point_add_dev"); CHECK_PTR(d_q, "bjj_point_add_dev"); CHECK_PTR(d_out, "bjj_point_add_dev");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_point_add, dim3(grid_for(c, n, 2)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_p,
+                     (const uint8_t*)d_q, n, (uint8_t*)d_out);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+
+// ---- host-pointer API: stage -> *_dev -> copy back ----------------------------
+static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+int bjj_mul_fixed_base(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* out) {
+  CHECK_CTX(c, "bjj_mul_fixed_base");
+  if (n == 0) return BJJ_OK;
+  if (!scalars || !out) return set_err(BJJ_E_INVALID, "bjj_mul_fixed_base: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_in = 0, o_out = up16(n * 32);
+  int rc = ensure_stage(c, o_out + n * 64); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage + o_in, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_mul_fixed_base_dev(c, c->stage + o_in, n, c->stage + o_out, nullptr); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+int bjj_mul_var_base(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out) {
+  CHECK_CTX(c, "bjj_mul_var_base");
+  if (n == 0) return BJJ_OK;
+  if (!pts || !scalars || !out) return set_err(BJJ_E_INVALID, "bjj_mul_var_base: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_p = 0, o_s = up16(n * 64), o_out = o_s + up16(n * 32);
+  int rc = ensure_stage(c, o_out + n * 64); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage + o_p, pts, n * 64, hipMemcpyHostToDevice, c->stream));
+  HIPCK(hipMemcpyAsync(c->stage + o_s, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_mul_var_base_dev(c, c->stage + o_p, c->stage + o_s, n, c->stage + o_out, nullptr); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+int bjj_poseidon5(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out) {
+  CHECK_CTX(c, "bjj_poseidon5");
+  if (n == 0) return BJJ_OK;
+  if (!in || !out) return set_err(BJJ_E_INVALID, "bjj_poseidon5: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_out = up16(n * 160);
+  int rc = ensure_stage(c, o_out + n * 32); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage, in, n * 160, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_poseidon5_dev(c, c->stage, n, c->stage + o_out, nullptr); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+int bjj_eddsa_verify(bjj_ctx* c, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n,
+                     uint8_t* ok) {
+  CHECK_CTX(c, "bjj_eddsa_verify");
+  if (n == 0) return BJJ_OK;
+  if (!pk || !r || !s || !msg || !ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_pk = 0, o_r = up16(n * 64), o_s = o_r + up16(n * 64), o_m = o_s + up16(n * 32), o_ok = o_m + up16(n * 32);
+  int rc = ensure_stage(c, o_ok + n); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage + o_pk, pk, n * 64, hipMemcpyHostToDevice, c->stream));
+  HIPCK(hipMemcpyAsync(c->stage + o_r, r, n * 64, hipMemcpyHostToDevice, c->stream));
+  HIPCK(hipMemcpyAsync(c->stage + o_s, s, n * 32, hipMemcpyHostToDevice, c->stream));
+  HIPCK(hipMemcpyAsync(c->stage + o_m, msg, n * 32, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_eddsa_verify_dev(c, c->stage + o_pk, c->stage + o_r, c->stage + o_s, c->stage + o_m, n, c->stage + o_ok, nullptr);
+  if (rc) return rc;
+  HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+int bjj_point_add(bjj_ctx* c, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out) {
+  CHECK_CTX(c, "bjj_point_add");
+  if (n == 0) return BJJ_OK;
+  if (!p || !q || !out) return set_err(BJJ_E_INVALID, "bjj_point_add: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_q = up16(n * 64), o_out = o_q + up16(n * 64);
+  int rc = ensure_stage(c, o_out + n * 64); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage, p, n * 64, hipMemcpyHostToDevice, c->stream));
+  HIPCK(hipMemcpyAsync(c->stage + o_q, q, n * 64, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_point_add_dev(c, c->stage, c->stage + o_q, n, c->stage + o_out, nullptr); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -1,0 +1,163 @@
+// BabyJubJub group law for the GPU path.
+//
+// Reference semantics being reproduced (file:line into /root/reference):
+//   PointProjective::add     src/lib.rs:88-131   (ref_add below: same op order)
+//   PointProjective::affine  src/lib.rs:70-85
+//   Point::mul_scalar        src/lib.rs:149-164
+//
+// Fast path.  The reference curve  A x^2 + y^2 = 1 + D x^2 y^2  (A = 168700 a
+// square, D = 168696 a non-square => complete addition law) is isomorphic, via
+// x' = F x with F = sqrt(-A), to  -x'^2 + y^2 = 1 + D' x'^2 y^2,  D' = -D/A (still a
+// non-square, and -1 is a square in F_r, so the law stays complete).  On that
+// curve extended coordinates (X:Y:Z:T), T = XY/Z, give 7M mixed additions
+// (madd-2008-hwcd-3), 8M additions and 4M+4S doublings, against the reference's
+// 12M+1S unified projective add.  Canonical affine coordinates of a group element
+// are unique, so for ON-CURVE inputs any correct evaluation of n*P is bit-identical
+// to the reference's LSB-first double-and-add.  Off-curve inputs (the reference
+// never validates points, src/lib.rs:134-138, 395-412) take the exact path:
+// ref_mul_scalar replays the reference's operation sequence.
+#pragma once
+#include "fr.hpp"
+
+namespace bjj {
+
+struct Consts {
+  Fr A, D;          // reference curve constants, Montgomery
+  Fr F;             // sqrt(-A), Montgomery
+  Fr FINV_PLAIN;    // 1/F, canonical (so that mont_mul(x_mont, FINV_PLAIN) is canonical x/F)
+  Fr DP, D2P;       // D', 2D' Montgomery
+  Fr B8X, B8Y;      // generator, Montgomery (reference curve)
+  Fr ORDER, ORDER2, ORDER4;  // plain integers 8l, 16l, 32l in 29-bit limbs
+  Fr L, L2, L4;              // plain integers l, 2l, 4l
+  Fr PC[408];       // Poseidon t=6 round constants, Montgomery
+  Fr PM[36];        // Poseidon t=6 MDS, row-major, Montgomery
+};
+
+struct Ext { Fr X, Y, Z, T; };            // a' = -1 curve, extended
+struct Niels { Fr ymx, ypx, t2d; };       // affine point (x',y): y-x', y+x', 2D'x'y
+struct PNiels { Fr ymx, ypx, t2d, z2; };  // projective: Y-X, Y+X, 2D'T, 2Z
+struct RefProj { Fr x, y, z; };           // reference PointProjective, src/lib.rs:62-67
+
+BJJ_HD Ext ext_identity() {
+  Ext e; e.X = fr_zero(); e.Y = fr_one(); e.Z = fr_one(); e.T = fr_zero(); return e;
+}
+BJJ_HD Niels niels_identity() { Niels n; n.ymx = fr_one(); n.ypx = fr_one(); n.t2d = fr_zero(); return n; }
+
+// P + Q, Q affine-precomputed.  Inputs: P coords < 2r; Q coords < 2r.  7M.
+BJJ_HD Ext ext_madd(const Ext& p, const Niels& q) {
+  Fr a = fr_mul(fr_sub(p.Y, p.X), q.ymx);
+  Fr b = fr_mul(fr_add(p.Y, p.X), q.ypx);
+  Fr c = fr_mul(p.T, q.t2d);
+  Fr d = fr_dbl(p.Z);
+  Fr e = fr_sub(b, a), f = fr_sub(d, c), g = fr_add(d, c), h = fr_add(b, a);
+  Ext r;
+  r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.T = fr_mul(e, h); r.Z = fr_mul(f, g);
+  return r;
+}
+// P + Q, Q projective-precomputed.  8M.
+BJJ_HD Ext ext_add_pn(const Ext& p, const PNiels& q) {
+  Fr a = fr_mul(fr_sub(p.Y, p.X), q.ymx);
+  Fr b = fr_mul(fr_add(p.Y, p.X), q.ypx);
+  Fr c = fr_mul(p.T, q.t2d);
+  Fr d = fr_mul(p.Z, q.z2);
+  Fr e = fr_sub(b, a), f = fr_sub(d, c), g = fr_add(d, c), h = fr_add(b, a);
+  Ext r;
+  r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.T = fr_mul(e, h); r.Z = fr_mul(f, g);
+  return r;
+}
+// 2P (dbl-2008-hwcd with a = -1; all four outputs negated, which is the same
+// projective point, so that only subtractions of small operands are needed).
+template <bool NEED_T>
+BJJ_HD Ext ext_dbl(const Ext& p) {
+  Fr a = fr_sqr(p.X), b = fr_sqr(p.Y);
+  Fr c = fr_dbl(fr_sqr(p.Z));              // < 4r
+  Fr h = fr_add(a, b);                     // H' = A + B          < 4r
+  Fr s = fr_sqr(fr_add(p.X, p.Y));
+  Fr e = fr_sub8(s, h);                    // E = (X+Y)^2 - A - B < 10r
+  Fr g = fr_sub(b, a);                     // G = B - A           < 6r
+  Fr f = fr_sub8(c, g);                    // F' = C - G          < 12r
+  Ext r;
+  r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.Z = fr_mul(f, g);
+  if (NEED_T) r.T = fr_mul(e, h); else r.T = fr_zero();
+  return r;
+}
+BJJ_HD PNiels ext_to_pniels(const Ext& p, const Consts& K) {
+  PNiels n;
+  n.ymx = fr_sub(p.Y, p.X); n.ypx = fr_add(p.Y, p.X);
+  n.t2d = fr_mul(p.T, K.D2P); n.z2 = fr_dbl(p.Z);
+  return n;
+}
+// conditional negation: -(x,y) = (-x,y)  => swap ymx/ypx, negate t2d
+BJJ_HD PNiels pniels_cneg(const PNiels& n, bool neg) {
+  PNiels r;
+  r.ymx = fr_select(neg, n.ypx, n.ymx);
+  r.ypx = fr_select(neg, n.ymx, n.ypx);
+  r.t2d = fr_select(neg, fr_neg(n.t2d), n.t2d);
+  r.z2 = n.z2;
+  return r;
+}
+BJJ_HD Niels niels_cneg(const Niels& n, bool neg) {
+  Niels r;
+  r.ymx = fr_select(neg, n.ypx, n.ymx);
+  r.ypx = fr_select(neg, n.ymx, n.ypx);
+  r.t2d = fr_select(neg, fr_neg(n.t2d), n.t2d);
+  return r;
+}
+// affine point of the REFERENCE curve (Montgomery x, y) -> extended point on the a'=-1 curve
+BJJ_HD Ext ext_from_ref_affine(const Fr& x, const Fr& y, const Consts& K) {
+  Ext e;
+  e.X = fr_mul(x, K.F); e.Y = y; e.Z = fr_one(); e.T = fr_mul(e.X, y);
+  return e;
+}
+// on-curve test on the reference curve: A x^2 + y^2 == 1 + D x^2 y^2  (x, y Montgomery, < 2r)
+BJJ_HD bool ref_on_curve(const Fr& x, const Fr& y, const Consts& K) {
+  Fr x2 = fr_sqr(x), y2 = fr_sqr(y);
+  Fr lhs = fr_add(fr_mul(K.A, x2), y2);                      // < 4r
+  Fr rhs = fr_add(fr_one(), fr_mul(K.D, fr_mul(x2, y2)));    // < 3r
+  return fr_eq(lhs, rhs);
+}
+
+// ---- reference-exact projective arithmetic (src/lib.rs:88-131) -------------
+BJJ_HD RefProj ref_add(const RefProj& p, const RefProj& q, const Consts& K) {
+  Fr a = fr_mul(p.z, q.z);
+  Fr b = fr_sqr(a);
+  Fr c = fr_mul(p.x, q.x);
+  Fr d = fr_mul(p.y, q.y);
+  Fr e = fr_mul(fr_mul(K.D, c), d);
+  Fr f = fr_sub(b, e);                       // < 6r
+  Fr g = fr_add(b, e);                       // < 4r
+  Fr aux = fr_mul(fr_add(p.x, p.y), fr_add(q.x, q.y));
+  aux = fr_sub(fr_sub(aux, c), d);           // < 10r
+  Fr x3 = fr_mul(fr_mul(a, f), aux);
+  Fr dac = fr_sub(d, fr_mul(K.A, c));        // < 6r
+  Fr y3 = fr_mul(fr_mul(a, g), dac);
+  RefProj r; r.x = x3; r.y = y3; r.z = fr_mul(f, g);
+  return r;
+}
+
+// ---- scalars ----------------------------------------------------------------
+// 256-bit scalar (8 words) mod 8l, returned as 8 words (< 2^254).  Exact for every
+// on-curve point because the group order is 8l.
+BJJ_HD void scalar_mod_order(const u32 w[8], u32 out[8], const Consts& K) {
+  Fr s = fr_from_words(w);
+  s = fr_cond_sub_kr(s, K.ORDER4.v);
+  s = fr_cond_sub_kr(s, K.ORDER2.v);
+  s = fr_cond_sub_kr(s, K.ORDER.v);
+  fr_to_words(s, out);
+}
+// canonical field element (plain N-form, < r < 8l) mod l
+BJJ_HD Fr plain_mod_l(const Fr& v, const Consts& K) {
+  Fr s = fr_cond_sub_kr(v, K.L4.v);
+  s = fr_cond_sub_kr(s, K.L2.v);
+  s = fr_cond_sub_kr(s, K.L.v);
+  return s;
+}
+// W-bit window j of a 256-bit little-endian integer (W <= 25); bits past 255 read as 0
+BJJ_HD u32 scalar_window(const u32 w[8], int j, int W) {
+  const int bit = j * W, wi = bit >> 5, sh = bit & 31;
+  if (wi >= 8) return 0;
+  u64 two = (u64)w[wi] | ((u64)(wi + 1 < 8 ? w[wi + 1] : 0u) << 32);
+  return (u32)(two >> sh) & ((1u << W) - 1u);
+}
+
+}  // namespace bjj

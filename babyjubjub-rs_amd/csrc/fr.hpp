@@ -1,0 +1,304 @@
+// Fr: the BN254 scalar field (reference `type Fr`, src/lib.rs:7; third-party
+// ff_ce derive) re-designed for the gfx950 VALU.
+//
+// Measured on MI355X (profiles/r01_ubench_valu_rates.txt): v_mad_u64_u32 costs
+// ~4.5 cycles per wave-instruction -- the same as v_addc_co_u32, v_lshl_add_u64
+// or v_mul_lo_u32 -- so a saturated 8x32-bit Montgomery multiplier spends more
+// issue slots on carries than on multiplies.  This field therefore uses an
+// UNSATURATED representation:
+//
+//     value = sum_{i<9} v[i] * 2^(29 i),   Montgomery radix R = 2^261
+//
+// Limb products are < 2^58, so a whole column (<= 9 a_i*b_j plus <= 9 m_i*n_j)
+// accumulates in one 64-bit register with a single v_mad_u64_u32 per product and
+// no carry instructions.  Because R / r ~ 2^7.4, values may float well above r
+// between multiplications ("lazy reduction"); the contract is:
+//
+//   N-form  : v[0..7] < 2^29, v[8] < 2^26      (all functions return N-form)
+//   fr_mul  : requires limbs < 2^30 and value(a)*value(b) < r*2^261
+//             (e.g. both < 13 r); returns a value < 2 r
+//   fr_add  : value adds; fr_sub(a,b): a + 4r - b (b < 4r); fr_sub8: a + 8r - b
+//
+// Everything is __host__ __device__ so the kernel bodies can also be executed on
+// the CPU by the debug harness (tests/emul); the shipped C-ABI only ever launches
+// the device code.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BJJ_HD __host__ __device__ __forceinline__
+#define BJJ_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define BJJ_HD inline
+#define BJJ_HD_NOINLINE
+#endif
+
+#if defined(BJJ_DEBUG_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+#include <assert.h>
+#define BJJ_ASSERT(x) assert(x)
+#else
+#define BJJ_ASSERT(x) ((void)0)
+#endif
+
+namespace bjj {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int NL = 9;
+constexpr u32 MASK29 = 0x1fffffffu;
+
+struct Fr { u32 v[NL]; };
+
+// r in 29-bit limbs
+#define BJJ_N0 0x10000001u
+#define BJJ_N1 0x1f0fac9fu
+#define BJJ_N2 0x0e5c2450u
+#define BJJ_N3 0x07d090f3u
+#define BJJ_N4 0x1585d283u
+#define BJJ_N5 0x02db40c0u
+#define BJJ_N6 0x00a6e141u
+#define BJJ_N7 0x0e5c2634u
+#define BJJ_N8 0x0030644eu
+#define BJJ_NINV29 0x0fffffffu  // -r^-1 mod 2^29
+
+BJJ_HD u32 fr_modlimb(int i) {
+  constexpr u32 N[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
+  return N[i];
+}
+
+// k*r written with "borrowed" limbs so that limbwise (C - b) never underflows
+// for an N-form b below (k r - 2^232):  c0 = d0 + 2^29, ci = di + 2^29 - 1, c8 = d8 - 1.
+BJJ_HD u32 fr_c4limb(int i) {
+  constexpr u32 C[NL] = {0x4u + 0x20000000u, 0x1c3eb27eu + 0x1fffffffu, 0x19709143u + 0x1fffffffu,
+                         0x1f4243cdu + 0x1fffffffu, 0x16174a0cu + 0x1fffffffu, 0x0b6d0302u + 0x1fffffffu,
+                         0x029b8504u + 0x1fffffffu, 0x197098d0u + 0x1fffffffu, 0x00c19139u - 1u};
+  return C[i];
+}
+BJJ_HD u32 fr_c8limb(int i) {
+  constexpr u32 C[NL] = {0x8u + 0x20000000u, 0x187d64fcu + 0x1fffffffu, 0x12e12287u + 0x1fffffffu,
+                         0x1e84879bu + 0x1fffffffu, 0x0c2e9419u + 0x1fffffffu, 0x16da0605u + 0x1fffffffu,
+                         0x05370a08u + 0x1fffffffu, 0x12e131a0u + 0x1fffffffu, 0x01832273u - 1u};
+  return C[i];
+}
+
+BJJ_HD Fr fr_zero() { Fr r; for (int i = 0; i < NL; i++) r.v[i] = 0; return r; }
+
+// carry propagation to N-form (limb 8 keeps whatever is left)
+BJJ_HD void fr_carry(Fr& a) {
+#pragma unroll
+  for (int i = 0; i < NL - 1; i++) {
+    a.v[i + 1] += a.v[i] >> 29;
+    a.v[i] &= MASK29;
+  }
+}
+
+BJJ_HD Fr fr_add(const Fr& a, const Fr& b) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + b.v[i];
+  fr_carry(r);
+  return r;
+}
+// a + 4r - b ; needs b < 4r - 2^232 (anything that is < 2r, or a sum of two canonical values)
+BJJ_HD Fr fr_sub(const Fr& a, const Fr& b) {
+  Fr r;
+  BJJ_ASSERT(b.v[8] <= fr_c4limb(8));
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + fr_c4limb(i) - b.v[i];
+  fr_carry(r);
+  return r;
+}
+// a + 8r - b ; needs b < 8r - 2^232
+BJJ_HD Fr fr_sub8(const Fr& a, const Fr& b) {
+  Fr r;
+  BJJ_ASSERT(b.v[8] <= fr_c8limb(8));
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + fr_c8limb(i) - b.v[i];
+  fr_carry(r);
+  return r;
+}
+BJJ_HD Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
+BJJ_HD Fr fr_dbl(const Fr& a) { return fr_add(a, a); }
+
+BJJ_HD Fr fr_select(bool c, const Fr& a, const Fr& b) {  // c ? a : b
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+
+#if defined(BJJ_DEBUG_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+inline void fr_check_mul_operands(const Fr& a, const Fr& b) {
+  for (int i = 0; i < NL; i++) { assert(a.v[i] < (1u << 30)); assert(b.v[i] < (1u << 30)); }
+  // value(a)*value(b) < r * 2^261, compared in units of 2^406 using the top two limbs (+1 for the tail)
+  unsigned __int128 ah = (((unsigned __int128)a.v[8] << 29) | a.v[7]) + 1;
+  unsigned __int128 bh = (((unsigned __int128)b.v[8] << 29) | b.v[7]) + 1;
+  // r * 2^261 / 2^406 = r / 2^145 = (r >> 144) >> 1
+  const unsigned __int128 lim = (((unsigned __int128)0x30644e72e131ULL << 64) | 0xa029b85045b68181ULL) >> 1;
+  assert(ah * bh <= lim);
+}
+#define BJJ_CHECK_MUL(a, b) fr_check_mul_operands(a, b)
+#else
+#define BJJ_CHECK_MUL(a, b) ((void)0)
+#endif
+
+// Montgomery product a*b*2^-261 mod r, product-scanning, one 64-bit accumulator.
+BJJ_HD Fr fr_mul(const Fr& a, const Fr& b) {
+  BJJ_CHECK_MUL(a, b);
+  u32 m[NL];
+  Fr r;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (u64)a.v[i] * b.v[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (u64)m[i] * fr_modlimb(k - i);
+    m[k] = ((u32)acc * BJJ_NINV29) & MASK29;
+    acc += (u64)m[k] * BJJ_N0;
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)a.v[i] * b.v[k - i];
+#pragma unroll
+    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)m[i] * fr_modlimb(k - i);
+    r.v[k - NL] = (u32)acc & MASK29;
+    acc >>= 29;
+  }
+  r.v[NL - 1] = (u32)acc;
+  return r;
+}
+
+// Montgomery square: cross terms once, against a pre-doubled copy.
+BJJ_HD Fr fr_sqr(const Fr& a) {
+  BJJ_CHECK_MUL(a, a);
+  u32 m[NL], a2[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;
+  Fr r;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; i++) acc += (u64)a2[i] * a.v[k - i];
+    if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (u64)m[i] * fr_modlimb(k - i);
+    m[k] = ((u32)acc * BJJ_NINV29) & MASK29;
+    acc += (u64)m[k] * BJJ_N0;
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = k - (NL - 1); 2 * i < k; i++) acc += (u64)a2[i] * a.v[k - i];
+    if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)m[i] * fr_modlimb(k - i);
+    r.v[k - NL] = (u32)acc & MASK29;
+    acc >>= 29;
+  }
+  r.v[NL - 1] = (u32)acc;
+  return r;
+}
+
+// ---- constants in Montgomery form (R = 2^261) ----------------------------
+BJJ_HD Fr fr_one() {  // 2^261 mod r
+  Fr r = {{0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u}};
+  return r;
+}
+BJJ_HD Fr fr_r2() {  // 2^522 mod r  (to-Montgomery multiplier)
+  Fr r = {{0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu, 0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au}};
+  return r;
+}
+BJJ_HD Fr fr_one_plain() { Fr r = fr_zero(); r.v[0] = 1; return r; }
+
+// ---- I/O: 32-byte little-endian canonical integers -----------------------
+// 8 x u32 words -> 9 x 29-bit limbs (plain value, any 256-bit integer)
+BJJ_HD Fr fr_from_words(const u32 w[8]) {
+  Fr r;
+  r.v[0] = w[0] & MASK29;
+#pragma unroll
+  for (int i = 1; i < 8; i++) {
+    // limb i holds bits [29i, 29i+29): spans words (29i)/32 and possibly the next
+    const int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+    u64 two = (u64)w[wi] | ((u64)(wi + 1 < 8 ? w[wi + 1] : 0u) << 32);
+    r.v[i] = (u32)(two >> sh) & MASK29;
+  }
+  r.v[8] = w[7] >> 8;  // bits 232..255
+  return r;
+}
+// N-form plain value < 2^256 -> 8 x u32 words
+BJJ_HD void fr_to_words(const Fr& a, u32 w[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int bit = 32 * j, li = bit / 29, sh = bit - 29 * li;  // word j starts inside limb li at offset sh
+    u64 acc = (u64)a.v[li] >> sh;
+    int have = 29 - sh;
+    acc |= (u64)a.v[li + 1] << have;
+    have += 29;
+    if (have < 32 && li + 2 < NL) acc |= (u64)a.v[li + 2] << have;
+    w[j] = (u32)acc;
+  }
+}
+
+// x - r if x >= r (x N-form with limbs < 2^29, top limb arbitrary)
+BJJ_HD Fr fr_cond_sub_kr(const Fr& x, const u32 kr[NL]) {
+  Fr d;
+  u32 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    u32 t = x.v[i] - kr[i] - borrow;
+    borrow = t >> 31;
+    d.v[i] = (i < NL - 1) ? (t & MASK29) : t;
+  }
+  return fr_select(borrow != 0, x, d);
+}
+// full reduction to [0, r) of an N-form value < 16 r
+BJJ_HD Fr fr_canon(const Fr& x) {
+  constexpr u32 R8[NL] = {0x8u, 0x187d64fcu, 0x12e12287u, 0x1e84879bu, 0x0c2e9419u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
+  constexpr u32 R4[NL] = {0x4u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
+  constexpr u32 R2[NL] = {0x2u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u, 0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
+  constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
+  Fr t = fr_cond_sub_kr(x, R8);
+  t = fr_cond_sub_kr(t, R4);
+  t = fr_cond_sub_kr(t, R2);
+  t = fr_cond_sub_kr(t, R1);
+  return t;
+}
+BJJ_HD bool fr_is_zero_canon(const Fr& a) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) o |= a.v[i];
+  return o == 0;
+}
+BJJ_HD bool fr_is_zero(const Fr& a) { return fr_is_zero_canon(fr_canon(a)); }  // a < 16 r
+BJJ_HD bool fr_eq(const Fr& a, const Fr& b) { return fr_is_zero(fr_sub(a, b)); }  // a < 12 r, b < 4r
+
+// bytes (as 8 words, any 256-bit integer) -> Montgomery form, value < 2r
+BJJ_HD Fr fr_to_mont_words(const u32 w[8]) { return fr_mul(fr_from_words(w), fr_r2()); }
+// Montgomery form -> canonical words
+BJJ_HD void fr_from_mont_words(const Fr& a, u32 w[8]) {
+  constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
+  Fr t = fr_mul(a, fr_one_plain());  // in [0, r]
+  t = fr_cond_sub_kr(t, R1);
+  fr_to_words(t, w);
+}
+
+// a^(r-2): Fermat inversion, plain left-to-right square-and-multiply (uniform
+// control flow: the exponent is a compile-time constant).  0 -> 0.
+BJJ_HD_NOINLINE Fr fr_inv(const Fr& a) {
+  // r - 2, 32-bit words, little-endian
+  const u32 E[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  Fr x = a;  // top bit (bit 253) is set
+  for (int bit = 252; bit >= 0; bit--) {
+    x = fr_sqr(x);
+    if ((E[bit >> 5] >> (bit & 31)) & 1) x = fr_mul(x, a);
+  }
+  return x;
+}
+
+}  // namespace bjj

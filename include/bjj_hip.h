@@ -1,0 +1,126 @@
+/*
+ * bjj_hip.h -- C ABI of libbjj_hip.so: batched BabyJubJub scalar multiplication,
+ * Poseidon(t=6) and EdDSA-Poseidon verification on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of the Rust crate
+ * arnaucube/babyjubjub-rs v0.0.11 (reference checkout: /root/reference).  The
+ * crate has no FFI of its own; its public Rust API is the interface, and each
+ * entry point below is the batch form of the function(s) it replaces:
+ *
+ *   bjj_mul_fixed_base   B8.mul_scalar(n)            src/lib.rs:149-164 with self = B8
+ *                        (src/lib.rs:37-46); the engine of PrivateKey::public(),
+ *                        src/lib.rs:304-306
+ *   bjj_mul_var_base     Point::mul_scalar(&self, n) src/lib.rs:149-164
+ *   bjj_poseidon5        POSEIDON.hash(vec![a,b,c,d,e]) as called at
+ *                        src/lib.rs:400-404 (poseidon-rs 0.0.8, Cargo.toml:20)
+ *   bjj_eddsa_verify     verify(pk, sig, msg)        src/lib.rs:395-412
+ *   bjj_point_add        PointProjective::add(..).affine()
+ *                        src/lib.rs:88-131 + 70-85 on affine inputs (z = 1)
+ *
+ * Data formats (all little-endian, caller-owned, tightly packed arrays):
+ *   field element  32 bytes, the canonical integer < r  (== Fr::into_repr().0
+ *                  as [u64;4]); values >= r on input are reduced mod r
+ *   point          64 bytes: x then y  (the crate's `Point { x, y }`,
+ *                  src/lib.rs:134-138).  Points are NOT required to be on the
+ *                  curve: like the reference, off-curve inputs are processed with
+ *                  the reference's exact formula sequence
+ *   scalar / s / msg  32 bytes, unsigned integer (BigInt::to_bytes_le zero-padded
+ *                  to 32 bytes, as src/lib.rs:249-252 does for `s`)
+ *   ok             1 byte per item: 1 = verify() returned true, 0 = false
+ *
+ * Error model: the reference's functions on this path are infallible
+ * (mul_scalar, add) or fold every failure into `false` (verify, src/lib.rs:396-404).
+ * Accordingly per-item outcomes are DATA (ok[i]); the int status is only for
+ * API misuse / HIP runtime errors.  0 = success; negative = BJJ_E_*; see
+ * bjj_last_error().
+ *
+ * Threading: a context is bound to one device and one internal stream; calls on
+ * the same context are serialised by the caller; different contexts are
+ * independent.  The library keeps no pointer past return.
+ *
+ * Host entry points take host pointers and do H2D / kernel / D2H synchronously.
+ * *_dev entry points take DEVICE pointers (16-byte aligned) plus a hipStream_t
+ * (passed as void*; NULL = the context's stream), enqueue the work and return
+ * without synchronising -- they are what bench.py times.
+ */
+#ifndef BJJ_HIP_H
+#define BJJ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bjj_ctx bjj_ctx;
+
+enum {
+  BJJ_OK = 0,
+  BJJ_E_INVALID = -1,   /* bad argument (NULL pointer, misaligned device pointer, ...) */
+  BJJ_E_NO_DEVICE = -2, /* no usable HIP device: there is NO CPU fallback */
+  BJJ_E_HIP = -3,       /* HIP runtime error, text in bjj_last_error() */
+  BJJ_E_NOMEM = -4
+};
+
+/* Library / build identification: "bjj-hip <version> gfx950". */
+const char* bjj_version(void);
+/* Text of the last error on this thread ("" if none). */
+const char* bjj_last_error(void);
+
+/* Creates a context on HIP device `device`: stream, scratch, and the fixed-base
+ * window table of B8 multiples (built on the GPU).  `window_bits` selects the
+ * fixed-base window width W (table = ceil(256/W) * 2^W entries of 128 bytes, kept
+ * in HBM); 0 picks the default (16). Valid: 4..18. */
+int bjj_init(int device, int window_bits, bjj_ctx** out_ctx);
+void bjj_free(bjj_ctx* ctx);
+/* Blocks until everything enqueued on the context's stream has finished. */
+int bjj_sync(bjj_ctx* ctx);
+/* The context's own stream (hipStream_t as void*). */
+void* bjj_stream(bjj_ctx* ctx);
+
+/* ---- host-pointer batch API ------------------------------------------------ */
+int bjj_mul_fixed_base(bjj_ctx* ctx, const uint8_t* scalars /* n*32 */, size_t n,
+                       uint8_t* out_xy /* n*64 */);
+int bjj_mul_var_base(bjj_ctx* ctx, const uint8_t* pts_xy /* n*64 */,
+                     const uint8_t* scalars /* n*32 */, size_t n, uint8_t* out_xy /* n*64 */);
+int bjj_poseidon5(bjj_ctx* ctx, const uint8_t* in /* n*160 */, size_t n, uint8_t* out /* n*32 */);
+int bjj_eddsa_verify(bjj_ctx* ctx, const uint8_t* pk_xy /* n*64 */, const uint8_t* r_xy /* n*64 */,
+                     const uint8_t* s /* n*32 */, const uint8_t* msg /* n*32 */, size_t n,
+                     uint8_t* ok /* n */);
+int bjj_point_add(bjj_ctx* ctx, const uint8_t* p_xy /* n*64 */, const uint8_t* q_xy /* n*64 */,
+                  size_t n, uint8_t* out_xy /* n*64 */);
+
+/* ---- device-pointer batch API (asynchronous on `stream`) -------------------- */
+int bjj_mul_fixed_base_dev(bjj_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* stream);
+int bjj_mul_var_base_dev(bjj_ctx* ctx, const void* d_pts_xy, const void* d_scalars, size_t n,
+                         void* d_out_xy, void* stream);
+int bjj_poseidon5_dev(bjj_ctx* ctx, const void* d_in, size_t n, void* d_out, void* stream);
+int bjj_eddsa_verify_dev(bjj_ctx* ctx, const void* d_pk_xy, const void* d_r_xy, const void* d_s,
+                         const void* d_msg, size_t n, void* d_ok, void* stream);
+int bjj_point_add_dev(bjj_ctx* ctx, const void* d_p_xy, const void* d_q_xy, size_t n, void* d_out_xy,
+                      void* stream);
+
+/* Makes sure the context's scratch can serve batches of up to n items, so that
+ * later *_dev calls do not allocate (call once before timing). */
+int bjj_reserve(bjj_ctx* ctx, size_t n);
+
+/* Introspection for benchmarks / profiling reports. */
+typedef struct {
+  int device;
+  int compute_units;
+  int window_bits;          /* fixed-base W */
+  int n_windows;            /* ceil(256 / W) */
+  uint64_t table_bytes;     /* fixed-base table size in HBM */
+  uint64_t scratch_bytes;   /* current scratch allocation */
+  const char* kernel_fixed_base; /* kernel symbol names, for matching rocprofv3 rows */
+  const char* kernel_var_base;
+  const char* kernel_poseidon5;
+  const char* kernel_verify;
+} bjj_info;
+int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BJJ_HIP_H */

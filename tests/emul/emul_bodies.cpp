@@ -1,0 +1,59 @@
+// DEBUG HARNESS (tests only): executes the product's per-item kernel bodies
+// (bjj_device.hpp) on the CPU with limb/value-bound assertions.  It exists to
+// catch arithmetic-contract violations here, where there is no GPU; it is not a
+// fallback and is not linked into libbjj_hip.so.
+#define BJJ_DEBUG_BOUNDS 1
+#include <string.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../babyjubjub-rs_amd/csrc/bjj_device.hpp"
+#include "../../babyjubjub-rs_amd/csrc/bjj_constants.inc"
+using namespace bjj;
+static const Consts K = {
+    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_B8X, BJJ_K_B8Y,
+    BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
+    BJJ_K_POSEIDON_C, BJJ_K_POSEIDON_M};
+static std::vector<u32> g_table; static int g_W = 0, g_nwin = 0;
+static void ensure_table(int W) {
+  if (g_W == W) return;
+  g_W = W; g_nwin = (256 + W - 1) / W;
+  size_t entries = (size_t)g_nwin << W;
+  g_table.assign(entries * NIELS_WORDS + 4, 0);
+  u32* t = (u32*)(((uintptr_t)g_table.data() + 15) & ~(uintptr_t)15);
+  for (size_t e = 0; e < entries; e++) store_niels(t + e * NIELS_WORDS, fixed_table_entry((u32)(e & ((1u << W) - 1)), (int)(e >> W), W, K));
+}
+static const u32* table_ptr() { return (const u32*)(((uintptr_t)g_table.data() + 15) & ~(uintptr_t)15); }
+static void ext_out(const Ext& p, uint8_t* out) {  // single-item affine epilogue
+  alignas(16) u32 w[8];
+  Fr zi = fr_inv(p.Z);
+  Fr c1 = fr_mul(zi, fr_one_plain()), c2 = fr_mul(zi, K.FINV_PLAIN);
+  constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
+  fr_to_words(fr_cond_sub_kr(fr_mul(p.X, c2), R1), w); memcpy(out, w, 32);
+  fr_to_words(fr_cond_sub_kr(fr_mul(p.Y, c1), R1), w); memcpy(out + 32, w, 32);
+}
+extern "C" {
+void emul_fixed_base(const uint8_t* scalar, int W, uint8_t* out) {
+  ensure_table(W);
+  alignas(16) u32 sc[8]; memcpy(sc, scalar, 32);
+  ext_out(fixed_base_accumulate(ext_identity(), table_ptr(), g_W, g_nwin, sc), out);
+}
+void emul_var_base(const uint8_t* pt, const uint8_t* scalar, uint8_t* out) {
+  alignas(16) u32 w[8], sc[8]; alignas(16) static u32 tbl[VB_TABLE_WORDS];
+  memcpy(w, pt, 32); Fr x = fr_to_mont_words(w);
+  memcpy(w, pt + 32, 32); Fr y = fr_to_mont_words(w);
+  memcpy(sc, scalar, 32);
+  ext_out(var_base_item(x, y, sc, tbl, K), out);
+}
+void emul_poseidon5(const uint8_t* in, uint8_t* out) {
+  Fr h[5]; alignas(16) u32 w[8];
+  for (int j = 0; j < 5; j++) { memcpy(w, in + 32 * j, 32); h[j] = fr_to_mont_words(w); }
+  fr_from_mont_words(poseidon5(h, K), w); memcpy(out, w, 32);
+}
+int emul_verify(const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, int W) {
+  ensure_table(W);
+  alignas(16) uint8_t b[192]; alignas(16) static u32 tbl[VB_TABLE_WORDS];
+  memcpy(b, pk, 64); memcpy(b + 64, r, 64); memcpy(b + 128, s, 32); memcpy(b + 160, msg, 32);
+  VerifyIn in = {b, b + 64, b + 128, b + 160};
+  return verify_item(in, table_ptr(), g_W, g_nwin, tbl, K) ? 1 : 0;
+}
+}
