@@ -1,0 +1,162 @@
+// babyjubjub.hpp -- header-only C++ mirror of the reference crate's API for the accelerated
+// path, on top of the C ABI (include/bjj_hip.h).  The reference is Rust and no Rust toolchain
+// exists in this image, so this is the compiled-language host side; names, argument meaning
+// and error behaviour follow /root/reference/src/lib.rs:
+//
+//   Fr::from_str (decimal)                      used all over lib.rs:28-60 and the tests
+//   Point { x, y }, projective(), mul_scalar(), equals()      lib.rs:134-164, 180-185
+//   PointProjective { x, y, z }, add(), affine()              lib.rs:62-131
+//   Signature { r_b8, s }                                     lib.rs:239-243
+//   verify(pk, sig, msg) -> bool                              lib.rs:395-412
+//   + *_batch forms (what the GPU is for)
+//
+// Every arithmetic operation runs in libbjj_hip.so on the GPU; this header only marshals
+// integers to the ABI's 32-byte little-endian records.  mul_scalar/add are infallible and
+// verify folds every failure into `false`, as in the reference; std::runtime_error is thrown
+// only for API misuse or HIP runtime errors.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bjj_hip.h"
+
+namespace babyjubjub_rs {
+
+// Unsigned 256-bit integer, little-endian bytes: stands in for both `Fr` values at the
+// boundary (canonical, < r) and `BigInt` scalars (`n`, `s`, `msg`).
+struct U256 {
+  std::array<uint8_t, 32> le{};
+  U256() = default;
+  explicit U256(uint64_t v) { for (int i = 0; i < 8; i++) le[i] = (uint8_t)(v >> (8 * i)); }
+  // decimal string, like Fr::from_str / BigInt::parse_bytes(.., 10); throws on overflow / bad digit
+  static U256 from_str(const std::string& dec) {
+    if (dec.empty()) throw std::runtime_error("U256::from_str: empty string");
+    U256 r;
+    for (char ch : dec) {
+      if (ch < '0' || ch > '9') throw std::runtime_error("U256::from_str: not a decimal digit");
+      unsigned carry = (unsigned)(ch - '0');
+      for (int i = 0; i < 32; i++) { unsigned v = r.le[i] * 10u + carry; r.le[i] = (uint8_t)v; carry = v >> 8; }
+      if (carry) throw std::runtime_error("U256::from_str: value does not fit 256 bits");
+    }
+    return r;
+  }
+  static U256 from_hex(const std::string& hex) {  // big-endian hex, optional 0x
+    size_t p = (hex.size() > 1 && hex[0] == '0' && (hex[1] == 'x' || hex[1] == 'X')) ? 2 : 0;
+    U256 r; size_t nd = hex.size() - p;
+    if (nd == 0 || nd > 64) throw std::runtime_error("U256::from_hex: bad length");
+    for (size_t k = 0; k < nd; k++) {
+      char c = hex[hex.size() - 1 - k]; unsigned v;
+      if (c >= '0' && c <= '9') v = c - '0'; else if (c >= 'a' && c <= 'f') v = c - 'a' + 10;
+      else if (c >= 'A' && c <= 'F') v = c - 'A' + 10; else throw std::runtime_error("U256::from_hex: bad digit");
+      r.le[k / 2] |= (uint8_t)(v << (4 * (k & 1)));
+    }
+    return r;
+  }
+  std::string to_hex() const {  // 64 hex chars, big-endian, like ff's to_hex (lib.rs:169, 336, 406)
+    static const char* d = "0123456789abcdef"; std::string s(64, '0');
+    for (int i = 0; i < 32; i++) { s[63 - 2 * i] = d[le[i] & 15]; s[62 - 2 * i] = d[le[i] >> 4]; }
+    return s;
+  }
+  bool operator==(const U256& o) const { return le == o.le; }
+  bool operator!=(const U256& o) const { return !(le == o.le); }
+};
+using Fr = U256;
+
+class Context {  // RAII over bjj_ctx (one GPU + stream + fixed-base table)
+ public:
+  explicit Context(int device = 0, int window_bits = 0) {
+    int rc = bjj_init(device, window_bits, &h_);
+    if (rc != BJJ_OK) throw std::runtime_error(std::string("bjj_init: ") + bjj_last_error());
+  }
+  ~Context() { bjj_free(h_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  bjj_ctx* handle() const { return h_; }
+  static Context& global() { static Context c; return c; }
+ private:
+  bjj_ctx* h_ = nullptr;
+};
+inline void check(int rc, const char* what) {
+  if (rc != BJJ_OK) throw std::runtime_error(std::string(what) + ": " + bjj_last_error());
+}
+
+struct Point;
+struct PointProjective {  // lib.rs:62-67
+  Fr x, y, z;
+  Point affine() const;                                   // lib.rs:70-85 (z must be 0 or 1 at this boundary)
+  PointProjective add(const PointProjective& q) const;    // lib.rs:88-131 (operands with z == 1)
+};
+struct Point {  // lib.rs:134-138
+  Fr x, y;
+  PointProjective projective() const { return PointProjective{x, y, Fr(1)}; }  // lib.rs:141-147
+  Point mul_scalar(const U256& n) const;                                       // lib.rs:149-164
+  bool equals(const Point& p) const { return x == p.x && y == p.y; }           // lib.rs:180-185
+};
+struct Signature {  // lib.rs:239-243
+  Point r_b8;
+  U256 s;
+};
+
+inline const Point& B8() {  // lib.rs:37-46
+  static const Point p{Fr::from_str("5299619240641551281634865583518297030282874472190772894086521144482721001553"),
+                       Fr::from_str("16950150798460657717958625567821834550301663161624707787222815936182638968203")};
+  return p;
+}
+
+// ---- batch forms --------------------------------------------------------------------
+inline std::vector<Point> mul_fixed_base_batch(const std::vector<U256>& n, Context& c = Context::global()) {
+  std::vector<Point> out(n.size());
+  static_assert(sizeof(U256) == 32 && sizeof(Point) == 64, "records must be tightly packed");
+  check(bjj_mul_fixed_base(c.handle(), (const uint8_t*)n.data(), n.size(), (uint8_t*)out.data()), "bjj_mul_fixed_base");
+  return out;
+}
+inline std::vector<Point> mul_scalar_batch(const std::vector<Point>& p, const std::vector<U256>& n,
+                                           Context& c = Context::global()) {
+  if (p.size() != n.size()) throw std::runtime_error("mul_scalar_batch: length mismatch");
+  std::vector<Point> out(n.size());
+  check(bjj_mul_var_base(c.handle(), (const uint8_t*)p.data(), (const uint8_t*)n.data(), n.size(), (uint8_t*)out.data()),
+        "bjj_mul_var_base");
+  return out;
+}
+inline std::vector<Fr> poseidon5_batch(const std::vector<std::array<Fr, 5>>& in, Context& c = Context::global()) {
+  std::vector<Fr> out(in.size());
+  check(bjj_poseidon5(c.handle(), (const uint8_t*)in.data(), in.size(), (uint8_t*)out.data()), "bjj_poseidon5");
+  return out;
+}
+inline std::vector<uint8_t> verify_batch(const std::vector<Point>& pk, const std::vector<Signature>& sig,
+                                         const std::vector<U256>& msg, Context& c = Context::global()) {
+  size_t n = pk.size();
+  if (sig.size() != n || msg.size() != n) throw std::runtime_error("verify_batch: length mismatch");
+  std::vector<Point> r(n); std::vector<U256> s(n);
+  for (size_t i = 0; i < n; i++) { r[i] = sig[i].r_b8; s[i] = sig[i].s; }
+  std::vector<uint8_t> ok(n);
+  check(bjj_eddsa_verify(c.handle(), (const uint8_t*)pk.data(), (const uint8_t*)r.data(), (const uint8_t*)s.data(),
+                         (const uint8_t*)msg.data(), n, ok.data()), "bjj_eddsa_verify");
+  return ok;
+}
+
+// ---- scalar (single-item) forms, same signatures as the crate ------------------------------
+inline Point Point::mul_scalar(const U256& n) const {
+  if (equals(B8())) return mul_fixed_base_batch({n})[0];
+  return mul_scalar_batch({*this}, {n})[0];
+}
+inline PointProjective PointProjective::add(const PointProjective& q) const {
+  if (z != Fr(1) || q.z != Fr(1)) throw std::runtime_error("PointProjective::add: boundary takes z == 1 operands");
+  Point a{x, y}, b{q.x, q.y}, o;
+  check(bjj_point_add(Context::global().handle(), (const uint8_t*)&a, (const uint8_t*)&b, 1, (uint8_t*)&o), "bjj_point_add");
+  return PointProjective{o.x, o.y, Fr(1)};
+}
+inline Point PointProjective::affine() const {
+  if (z == Fr(0)) return Point{Fr(0), Fr(0)};  // lib.rs:71-76
+  if (z != Fr(1)) throw std::runtime_error("PointProjective::affine: boundary holds z in {0, 1}");
+  return Point{x, y};
+}
+inline bool verify(const Point& pk, const Signature& sig, const U256& msg) {  // lib.rs:395-412
+  return verify_batch({pk}, {sig}, {msg})[0] != 0;
+}
+
+}  // namespace babyjubjub_rs

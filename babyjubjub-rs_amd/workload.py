@@ -1,0 +1,59 @@
+"""Synthetic workload + sharding helpers shared by bench.py and the tests.
+
+Inputs follow SURVEY.md 8(d): one SplitMix64 generator, 4 x u64 little-endian per
+32-byte value, fixed seeds per stream.  Generation is vectorised with numpy (u64
+wrap-around arithmetic), so 1M-item batches take milliseconds on the host.
+"""
+import numpy as np
+
+SEED_SCALARS = 0x424A4A5F5343414C
+SEED_POINTS = 0x424A4A5F504F494E
+SEED_MSGS = 0x424A4A5F4D534753
+SEED_KEYS = 0x424A4A5F4B455953
+SEED_NONCES = 0x424A4A5F4E4F4E43
+SEED_BAD = 0x424A4A5F42414421
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+
+def splitmix64(seed, count, offset=0):
+    """`count` outputs of SplitMix64(seed), starting at output index `offset`."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(offset + 1, offset + count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def random_u256(seed, n, offset=0, top_bits_cleared=0):
+    """n values of 32 bytes (uint8 array of shape (n, 32)); item i uses outputs 4i..4i+3."""
+    w = splitmix64(seed, 4 * n, 4 * offset).reshape(n, 4)
+    if top_bits_cleared:
+        w[:, 3] &= np.uint64((1 << (64 - top_bits_cleared)) - 1)
+    return w.astype("<u8").view(np.uint8).reshape(n, 32)
+
+
+def scalars_254(n, offset=0):
+    """cfg 1-3 scalars: uniform in [0, 2^254)."""
+    return random_u256(SEED_SCALARS, n, offset, top_bits_cleared=2)
+
+
+def shard_bounds(n, world_size, rank):
+    """Contiguous block partition of n items: [lo, hi) for `rank`."""
+    per = (n + world_size - 1) // world_size
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+# ---- arithmetic mod l on arrays of little-endian 256-bit integers (host-side signer math) ----
+L_ORDER = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+
+
+def to_ints(a):
+    b = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+    return [int.from_bytes(r.tobytes(), "little") for r in b]
+
+
+def from_ints(vals):
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), np.uint8).reshape(-1, 32).copy()

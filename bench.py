@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the BabyJubJub hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fixed_base|var_base|verify|poseidon5]
+                  [--batch B] [--scatter] [--no-cpu-baseline]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM (SplitMix64 streams of SURVEY.md 8d).  Default workload = BASELINE.json
+configs[1]: 2^20 fixed-base scalar multiplications per GPU.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU, RCCL) every rank owns its own 2^20-item block of the
+global batch -- the path shards with no data-path collective (weak scaling) -- and `value` is
+the whole-job rate: N * batch * K / max-over-ranks time.  `--scatter` instead times BASELINE
+cfg 5's shape (rank 0 holds everything; RCCL scatter -> kernel -> gather).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     : algorithmic bytes per launch / average kernel duration (HIP events on the
+                 launch stream) against the 8 TB/s HBM peak
+  cpu_baseline : the oracle's C restatement of the reference algorithm ("port": the Rust
+                 reference cannot be built in this image) timed on this box's host cores on
+                 a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+ALGO_BYTES = {"fixed_base": 96, "var_base": 160, "verify": 193, "poseidon5": 192}
+UNITS = {"fixed_base": "scalar mults/s", "var_base": "scalar mults/s", "verify": "verifies/s", "poseidon5": "hashes/s"}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fixed_base", choices=sorted(ALGO_BYTES))
+    ap.add_argument("--batch", type=int, default=1 << 20, help="items per GPU per step")
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--scatter", action="store_true", help="cfg 5 shape: rank-0 resident, RCCL scatter/gather timed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workload lines")
+    return ap.parse_args()
+
+
+class Workload:
+    """Device-resident synthetic inputs for one rank, and the launch closure."""
+
+    def __init__(self, ctx, kind, n, offset, dev, stream):
+        from babyjubjub_rs_amd import workload as w
+        self.kind, self.n, self.ctx, self.stream = kind, n, ctx, stream
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)  # noqa: E731
+        self.host = {}
+        if kind == "fixed_base":
+            self.host["scalars"] = w.scalars_254(n, offset)
+            self.d_sc = up(self.host["scalars"])
+            self.d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        elif kind == "var_base":
+            # cfg 3 points: random multiples of B8 made by the (parity-tested) fixed-base kernel
+            self.host["scalars"] = w.scalars_254(n, offset)
+            self.host["points"] = ctx.mul_fixed_base(w.random_u256(w.SEED_POINTS, n, offset))
+            self.d_sc, self.d_pts = up(self.host["scalars"]), up(self.host["points"])
+            self.d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        elif kind == "poseidon5":
+            self.host["in"] = w.random_u256(w.SEED_MSGS, 5 * n, 5 * offset, top_bits_cleared=3).reshape(n, 160)
+            self.d_in = up(self.host["in"])
+            self.d_out = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+        else:  # verify: cfg 4 signatures, 1/64 corrupted
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from test_gpu_parity import make_signatures, corrupt
+            A, R, S, msg = make_signatures(ctx.mul_fixed_base, ctx.poseidon5, n, offset)
+            self.bad = corrupt(A, R, S, msg, n, offset)
+            self.host.update(pk=A, r=R, s=S, msg=msg)
+            self.d_pk, self.d_r, self.d_s, self.d_msg = up(A), up(R), up(S), up(msg)
+            self.d_out = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def launch(self):
+        c, n, s = self.ctx, self.n, self.stream.cuda_stream
+        if self.kind == "fixed_base":
+            c.mul_fixed_base_dev(self.d_sc.data_ptr(), n, self.d_out.data_ptr(), s)
+        elif self.kind == "var_base":
+            c.mul_var_base_dev(self.d_pts.data_ptr(), self.d_sc.data_ptr(), n, self.d_out.data_ptr(), s)
+        elif self.kind == "poseidon5":
+            c.poseidon5_dev(self.d_in.data_ptr(), n, self.d_out.data_ptr(), s)
+        else:
+            c.eddsa_verify_dev(self.d_pk.data_ptr(), self.d_r.data_ptr(), self.d_s.data_ptr(), self.d_msg.data_ptr(), n,
+                               self.d_out.data_ptr(), s)
+
+    def check_sample(self, orc, count=512):
+        """byte-compare a strided sample of the last step's output with the oracle"""
+        n = self.n
+        idx = np.unique(np.linspace(0, n - 1, min(count, n)).astype(np.int64))
+        h = self.host
+        if self.kind == "fixed_base":
+            got = self.d_out.view(n, 64)[torch.from_numpy(idx).to(self.d_out.device)].cpu().numpy()
+            return bool((got == orc.mul_fixed_base(h["scalars"][idx])).all())
+        if self.kind == "var_base":
+            got = self.d_out.view(n, 64)[torch.from_numpy(idx).to(self.d_out.device)].cpu().numpy()
+            return bool((got == orc.mul_var_base(h["points"][idx], h["scalars"][idx])).all())
+        if self.kind == "poseidon5":
+            got = self.d_out.view(n, 32)[torch.from_numpy(idx).to(self.d_out.device)].cpu().numpy()
+            return bool((got == orc.poseidon5(h["in"][idx])).all())
+        got = self.d_out.cpu().numpy()
+        ok_mask = bool((got == (~self.bad).astype(np.uint8)).all())
+        return ok_mask and bool((got[idx] == orc.verify(h["pk"][idx], h["r"][idx], h["s"][idx], h["msg"][idx])).all())
+
+
+def timed_steps(wl, steps, warmup, world):
+    """W untimed + K timed launches; returns (wall seconds for K steps, mean kernel ms from HIP events)."""
+    st = wl.stream
+    for _ in range(warmup):
+        wl.launch()
+    st.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs[0].record(st)
+    for k in range(steps):
+        wl.launch()
+        evs[k + 1].record(st)
+    st.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
+    return dt, float(np.mean(kernel_ms))
+
+
+def cpu_baseline(kind, wl, budget_cpu_s=25.0):
+    """oracle (C restatement of the reference algorithm, "port") on the host cores, bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import Oracle
+    orc = Oracle()
+    cores = os.cpu_count() or 1
+    orc.threads = min(cores, 256)
+    per_core_rate = {"fixed_base": 3500.0, "var_base": 3500.0, "verify": 1300.0, "poseidon5": 9000.0}[kind]
+    sample = int(min(wl.n, max(orc.threads * 8, per_core_rate * budget_cpu_s)))
+    h = wl.host
+    t0 = time.perf_counter()
+    if kind == "fixed_base":
+        orc.mul_fixed_base(h["scalars"][:sample])
+    elif kind == "var_base":
+        orc.mul_var_base(h["points"][:sample], h["scalars"][:sample])
+    elif kind == "poseidon5":
+        orc.poseidon5(h["in"][:sample])
+    else:
+        orc.verify(h["pk"][:sample], h["r"][:sample], h["s"][:sample], h["msg"][:sample])
+    dt = time.perf_counter() - t0
+    # single-thread rate on a small slice
+    orc1 = Oracle()
+    orc1.threads = 1
+    m = max(16, min(sample, int(per_core_rate * 1.0)))
+    t1 = time.perf_counter()
+    if kind == "fixed_base":
+        orc1.mul_fixed_base(h["scalars"][:m])
+    elif kind == "var_base":
+        orc1.mul_var_base(h["points"][:m], h["scalars"][:m])
+    elif kind == "poseidon5":
+        orc1.poseidon5(h["in"][:m])
+    else:
+        orc1.verify(h["pk"][:m], h["r"][:m], h["s"][:m], h["msg"][:m])
+    dt1 = time.perf_counter() - t1
+    return {"value": sample / dt, "unit": UNITS[kind], "cores": orc.threads, "kind": "port",
+            "sample": "first %d items of the same %s batch, oracle/bjj_ref.c (reference algorithm: bit-serial "
+                      "double-and-add, unified adds, one inversion per mult), %d pthreads" % (sample, kind, orc.threads),
+            "single_thread_value": m / dt1}, orc
+
+
+def load_traffic(kind):
+    """per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json), or None"""
+    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(kind, {}).get("bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import babyjubjub_rs_amd as bjj
+    ctx = bjj.Context(local_rank, args.window_bits)
+    n = args.batch
+    ctx.reserve(n)
+    stream = torch.cuda.Stream(device=dev)
+    kind = args.workload
+    wl = Workload(ctx, kind, n, rank * n, dev, stream)
+
+    extra = {}
+    if args.scatter and world > 1:
+        # cfg 5 shape: time scatter + kernel + gather of rank-0 resident data
+        from babyjubjub_rs_amd import shard
+        rows = {"fixed_base": [32], "var_base": [64, 32], "verify": [64, 64, 32, 32], "poseidon5": [160]}[kind]
+        outb = {"fixed_base": 64, "var_base": 64, "verify": 1, "poseidon5": 32}[kind]
+        total = n * world
+        full = None
+        if rank == 0:
+            full = [torch.zeros(total * rb, dtype=torch.uint8, device=dev) for rb in rows]
+        tensors = {"fixed_base": ["d_sc"], "var_base": ["d_pts", "d_sc"], "verify": ["d_pk", "d_r", "d_s", "d_msg"],
+                   "poseidon5": ["d_in"]}[kind]
+        # assemble the global batch on rank 0 from every rank's block (untimed setup)
+        for ti, (name, rb) in enumerate(zip(tensors, rows)):
+            g = shard.gather_rows(getattr(wl, name), total, rb, dev) if True else None
+            if rank == 0:
+                full[ti] = g
+
+        def step():
+            shards = [shard.scatter_rows(full[i] if rank == 0 else None, total, rb, dev) for i, rb in enumerate(rows)]
+            for name, s in zip(tensors, shards):
+                getattr(wl, name).copy_(s)
+            torch.cuda.current_stream().synchronize()
+            wl.launch()
+            wl.stream.synchronize()
+            return shard.gather_rows(wl.d_out, total, outb, dev)
+
+        for _ in range(args.warmup):
+            step()
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        dist.barrier(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kernel_ms = None
+        extra["mode"] = "rank0-resident scatter/kernel/gather (BASELINE cfg 5 shape)"
+    else:
+        dt, kernel_ms = timed_steps(wl, args.steps, args.warmup, world)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        info = ctx.info()
+        value = world * n * args.steps / dt_max
+        result = {
+            "metric": "BabyJubJub %s, %d-item batch per GPU" % (
+                {"fixed_base": "fixed-base scalar mults/sec", "var_base": "variable-base scalar mults/sec",
+                 "verify": "EdDSA-Poseidon verifies/sec", "poseidon5": "Poseidon(t=6) hashes/sec"}[kind], n),
+            "value": value, "unit": UNITS[kind], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": {"fixed_base": "1M fixed-base scalar mults (generator B8), BASELINE configs[1]",
+                                    "var_base": "1M variable-base scalar mults, BASELINE configs[2]",
+                                    "verify": "1M EdDSA-Poseidon verifies, 1/64 corrupted, BASELINE configs[3]",
+                                    "poseidon5": "Poseidon t=6 hashes (component of configs[3])"}[kind],
+                       "batch_per_gpu": n, "global_batch": n * world, "window_bits": info.window_bits,
+                       "fixed_base_table_mb": info.table_bytes / 1e6,
+                       "limbs": "9 x 29-bit, 64-bit column accumulators (v_mad_u64_u32)",
+                       "parallelism": "independent shards, one process per GPU, no data-path collective"},
+        }
+        result.update(extra)
+        if kernel_ms is not None:
+            algo = ALGO_BYTES[kind] * n
+            ach = algo / (kernel_ms * 1e-3) / 1e9
+            result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": ach / HBM_PEAK_GBPS, "traffic": load_traffic(kind),
+                                  "kernel": {"fixed_base": info.kernel_fixed_base, "var_base": info.kernel_var_base,
+                                             "verify": info.kernel_verify, "poseidon5": info.kernel_poseidon5}[kind].decode(),
+                                  "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": algo,
+                                  "note": "integer-ALU bound path (see DESIGN.md): HBM fraction is reported as measured"}
+        orc = None
+        if not args.no_cpu_baseline and world == 1:
+            cb, orc = cpu_baseline(kind, wl)
+            result["cpu_baseline"] = cb
+        if orc is None:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from conftest import Oracle
+            orc = Oracle()
+        result["parity_sample_ok"] = wl.check_sample(orc)
+        if not args.no_also and not args.scatter:
+            also = {}
+            for k2, n2, s2 in (("verify", n, 5), ("var_base", n, 5)):
+                if k2 == kind:
+                    continue
+                w2 = Workload(ctx, k2, n2, rank * n2, dev, stream)
+                d2, km2 = timed_steps(w2, s2, 1, 1)
+                also[k2] = {"value_one_gpu": n2 * s2 / d2, "unit": UNITS[k2], "kernel_ms_avg": km2, "batch": n2,
+                            "parity_sample_ok": w2.check_sample(orc, 128)}
+                del w2
+            result["also"] = also
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,7 +139,7 @@ def pack(vals):
 
 
 def unpack(arr, per_item=1):
-    b = np.ascontiguousarray(arr, np.uint8).tobytes()
+    b = bytes(arr) if isinstance(arr, (bytes, bytearray)) else np.ascontiguousarray(arr, np.uint8).tobytes()
     vals = [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
     if per_item == 1:
         return vals

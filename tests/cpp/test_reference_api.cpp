@@ -1,0 +1,69 @@
+// The reference's own unit tests for the accelerated path (src/lib.rs:421-552, 689-738)
+// re-stated in C++ against babyjubjub.hpp -> libbjj_hip.so.  Run on a GPU box by
+// tests/test_gpu_cpp_api.py.  Exit code 0 = all assertions held.
+#include <cstdio>
+#include "../../babyjubjub-rs_amd/csrc/babyjubjub.hpp"
+using namespace babyjubjub_rs;
+static int failures = 0;
+#define ASSERT_EQ(a, b) do { if (!((a) == (b))) { printf("FAIL %s:%d  %s != %s\n", __FILE__, __LINE__, #a, #b); failures++; } } while (0)
+#define ASSERT_TRUE(a) do { if (!(a)) { printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #a); failures++; } } while (0)
+
+static Point P() {
+  return Point{Fr::from_str("17777552123799933955779906779655732241715742912184938656739573121738514868268"),
+               Fr::from_str("2626589144620713026669568689430873010625803728049924121243784502389097019475")};
+}
+static void test_add_same_point() {  // lib.rs:421-459
+  PointProjective p = P().projective(), q = P().projective();
+  Point res = p.add(q).affine();
+  ASSERT_EQ(res.x, Fr::from_str("6890855772600357754907169075114257697580319025794532037257385534741338397365"));
+  ASSERT_EQ(res.y, Fr::from_str("4338620300185947561074059802482547481416142213883829469920100239455078257889"));
+}
+static void test_add_different_points() {  // lib.rs:461-499
+  PointProjective p = P().projective();
+  PointProjective q{Fr::from_str("16540640123574156134436876038791482806971768689494387082833631921987005038935"),
+                    Fr::from_str("20819045374670962167435360035096875258406992893633759881276124905556507972311"), Fr(1)};
+  Point res = p.add(q).affine();
+  ASSERT_EQ(res.x, Fr::from_str("7916061937171219682591368294088513039687205273691143098332585753343424131937"));
+  ASSERT_EQ(res.y, Fr::from_str("14035240266687799601661095864649209771790948434046947201833777492504781204499"));
+}
+static void test_mul_scalar() {  // lib.rs:502-552
+  Point p = P();
+  Point res_m = p.mul_scalar(U256(3));
+  Point res_a = p.projective().add(p.projective()).add(p.projective()).affine();
+  ASSERT_EQ(res_m.x, res_a.x);
+  ASSERT_EQ(res_m.x, Fr::from_str("19372461775513343691590086534037741906533799473648040012278229434133483800898"));
+  ASSERT_EQ(res_m.y, Fr::from_str("9458658722007214007257525444427903161243386465067105737478306991484593958249"));
+  U256 n = U256::from_str("14035240266687799601661095864649209771790948434046947201833777492504781204499");
+  Point res2 = p.mul_scalar(n);
+  ASSERT_EQ(res2.x, Fr::from_str("17070357974431721403481313912716834497662307308519659060910483826664480189605"));
+  ASSERT_EQ(res2.y, Fr::from_str("4014745322800118607127020275658861516666525056516280575712425373174125159339"));
+}
+static void test_circomlib_testvector() {  // lib.rs:689-738 (everything downstream of Blake-512)
+  U256 scalar_key = U256::from_str("6466070937662820620902051049739362987537906109895538826186780010858059362905");
+  Point pk = B8().mul_scalar(scalar_key);  // PrivateKey::public, lib.rs:304-306
+  ASSERT_EQ(pk.x.to_hex(), std::string("1d5ac1f31407018b7d413a4f52c8f74463b30e6ac2238220ad8b254de4eaa3a2"));
+  ASSERT_EQ(pk.y.to_hex(), std::string("1e1de8a908826c3f9ac2e0ceee929ecd0caf3b99b3ef24523aaab796a6f733c4"));
+  U256 msg; for (int i = 0; i < 10; i++) msg.le[i] = (uint8_t)i;  // BigInt::from_bytes_le("00010203040506070809")
+  Signature sig{Point{Fr::from_hex("192b4e51adf302c8139d356d0e08e2404b5ace440ef41fc78f5c4f2428df0765"),
+                      Fr::from_hex("2202bebcf57b820863e0acc88970b6ca7d987a0d513c2ddeb42e3f5d31b4eddf")},
+                U256::from_str("1672775540645840396591609181675628451599263765380031905495115170613215233181")};
+  ASSERT_TRUE(verify(pk, sig, msg));
+  Signature bad = sig; bad.s.le[0] ^= 1;
+  ASSERT_TRUE(!verify(pk, bad, msg));
+  U256 big = U256::from_str("21888242871839275222246405745257275088548364400416034343698204186575808495618");  // Q + 1
+  ASSERT_TRUE(!verify(pk, sig, big));  // lib.rs:396-398
+}
+static void test_batch() {
+  std::vector<U256> n; for (uint64_t i = 0; i < 1000; i++) n.push_back(U256(i * 0x9E3779B97F4A7C15ULL + 1));
+  std::vector<Point> a = mul_fixed_base_batch(n);
+  std::vector<Point> b = mul_scalar_batch(std::vector<Point>(n.size(), B8()), n);
+  for (size_t i = 0; i < n.size(); i++) ASSERT_TRUE(a[i].equals(b[i]));
+  ASSERT_TRUE(a[0].equals(B8()));  // n = 1
+}
+int main() {
+  try {
+    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_batch();
+  } catch (const std::exception& e) { printf("EXCEPTION %s\n", e.what()); return 2; }
+  printf(failures ? "FAILED %d\n" : "ok (reference tests re-stated in C++)\n", failures);
+  return failures ? 1 : 0;
+}

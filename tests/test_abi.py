@@ -1,0 +1,87 @@
+"""The C-ABI library: loads here (no GPU), exports every symbol include/bjj_hip.h declares,
+refuses to run without a device (no CPU fallback), and the host-side mirror marshals
+correctly.  CPU only -- no compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "bjj_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(bjj_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    from babyjubjub_rs_amd import _lib
+    assert sorted(_lib.EXPORTED_SYMBOLS) == header_functions()
+
+
+def test_library_exports_every_declared_symbol():
+    from babyjubjub_rs_amd import _lib
+    lib = _lib.load()
+    for name in header_functions():
+        assert hasattr(lib, name), "libbjj_hip.so does not export %s" % name
+    assert lib.bjj_version().decode().startswith("bjj-hip")
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from babyjubjub_rs_amd import _lib
+    import babyjubjub_rs_amd as bjj
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    rc = lib.bjj_init(0, 0, ctypes.byref(h))
+    assert rc == _lib.BJJ_E_NO_DEVICE and not h.value
+    assert b"no CPU fallback" in lib.bjj_last_error()
+    with pytest.raises(bjj.BjjError):
+        bjj.Context(0)
+    # NULL context is rejected, not dereferenced
+    assert lib.bjj_mul_fixed_base(None, None, 4, None) == _lib.BJJ_E_INVALID
+    assert lib.bjj_eddsa_verify_dev(None, None, None, None, None, 4, None, None) == _lib.BJJ_E_INVALID
+
+
+def test_init_argument_checks():
+    from babyjubjub_rs_amd import _lib
+    lib = _lib.load()
+    assert lib.bjj_init(0, 0, None) == _lib.BJJ_E_INVALID
+    h = ctypes.c_void_p()
+    assert lib.bjj_init(0, 3, ctypes.byref(h)) == _lib.BJJ_E_INVALID  # window_bits out of range
+    assert lib.bjj_init(0, 19, ctypes.byref(h)) == _lib.BJJ_E_INVALID
+
+
+def test_marshalling_helpers():
+    from babyjubjub_rs_amd import api
+    a = api._as_u8([(1, 2), (3, 4)], 64, "pts")
+    assert a.dtype == np.uint8 and a.size == 128 and a[0] == 1 and a[32] == 2 and a[64] == 3
+    assert api._ints(a, 2) == [(1, 2), (3, 4)]
+    with pytest.raises(api.BjjError):
+        api._as_u8([1 << 256], 32, "s")
+    with pytest.raises(api.BjjError):
+        api._as_u8([-1], 32, "s")
+    with pytest.raises(api.BjjError):
+        api._as_u8(np.zeros(33, np.uint8), 32, "s")
+    # reference-shaped objects
+    p = api.Point(api.Q + 5, 7)
+    assert p.x == 5 and p.projective().z == 1 and p.equals(api.Point(5, 7))
+    assert api.PointProjective(1, 2, 0).affine().equals(api.Point(0, 0))  # lib.rs:71-76
+    # verify(): msg > Q is false before anything touches the device (lib.rs:396-398)
+    sig = api.Signature(api.Point(0, 1), 0)
+    assert api.verify(api.Point(0, 1), sig, api.Q + 1, ctx=object()) is False
+
+
+def test_workload_generator_matches_oracle_splitmix(pyoracle):
+    from babyjubjub_rs_amd import workload as w
+    g = pyoracle.SplitMix64(pyoracle.SEED_SCALARS)
+    want = [g.u256() & ((1 << 254) - 1) for _ in range(10)]
+    assert w.to_ints(w.scalars_254(10)) == want
+    assert w.to_ints(w.scalars_254(4, offset=6)) == want[6:]
+    assert [w.shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert w.shard_bounds(2, 4, 3) == (2, 2)

@@ -1,0 +1,241 @@
+"""Parity of the HIP path (through the C ABI of libbjj_hip.so) with the oracle: bit-exact on
+every output byte.  Needs a real MI355X: run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from conftest import pack, unpack
+
+pytestmark = pytest.mark.gpu
+
+Q = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+L = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+ORDER = 8 * L
+
+
+def hexint(x):
+    return int(x, 16) if isinstance(x, str) else int(x)
+
+
+def rows(cases, key):
+    return pack([tuple(c[key]) if isinstance(c[key], (list, tuple)) else c[key] for c in cases])
+
+
+# ---------------------------------------------------------------- golden fixtures
+def test_golden_fixed_base(gpu_ctx, golden):
+    fb = golden["oracle_vectors"]["fixed_base"]
+    got = gpu_ctx.mul_fixed_base(rows(fb, "n"))
+    assert (got.reshape(-1) == rows(fb, "out")).all()
+
+
+def test_golden_var_base_incl_off_curve(gpu_ctx, golden):
+    vb = golden["oracle_vectors"]["var_base"]
+    assert any(not c["on_curve"] for c in vb) and any(c["on_curve"] for c in vb)
+    got = gpu_ctx.mul_var_base(rows(vb, "p"), rows(vb, "n"))
+    want = rows(vb, "out").reshape(-1, 64)
+    bad = [i for i in range(len(vb)) if (got[i] != want[i]).any()]
+    assert not bad, [vb[i] for i in bad[:3]]
+
+
+def test_golden_poseidon(gpu_ctx, golden):
+    ps = golden["oracle_vectors"]["poseidon5"] + [
+        {"in": c["in"], "out": c["out"]} for c in golden["reference_kats"]["poseidon_public"]["cases"]]
+    got = gpu_ctx.poseidon5(rows(ps, "in"))
+    assert (got.reshape(-1) == rows(ps, "out")).all()
+
+
+def test_golden_point_add(gpu_ctx, golden):
+    ad = golden["oracle_vectors"]["point_add"]
+    got = gpu_ctx.point_add(rows(ad, "p"), rows(ad, "q"))
+    assert (got.reshape(-1) == rows(ad, "out")).all()
+
+
+def test_golden_verify_edge_semantics(gpu_ctx, golden):
+    ve = golden["oracle_vectors"]["verify"]
+    got = gpu_ctx.eddsa_verify(rows(ve, "pk"), rows(ve, "r_b8"), rows(ve, "s"), rows(ve, "msg"))
+    for c, g in zip(ve, got):
+        assert bool(g) == c["ok"], c["note"]
+
+
+# ---------------------------------------------------------------- seeded random vs oracle
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 4096])
+def test_fixed_base_random_and_ragged(gpu_ctx, oracle, n):
+    from babyjubjub_rs_amd import workload
+    sc = workload.random_u256(workload.SEED_SCALARS, n)  # full 256-bit scalars (unreduced)
+    got = gpu_ctx.mul_fixed_base(sc)
+    assert (got == oracle.mul_fixed_base(sc)).all()
+
+
+def test_empty_batches(gpu_ctx):
+    e = np.zeros(0, np.uint8)
+    assert gpu_ctx.mul_fixed_base(e).shape == (0, 64)
+    assert gpu_ctx.mul_var_base(e, e).shape == (0, 64)
+    assert gpu_ctx.poseidon5(e).shape == (0, 32)
+    assert gpu_ctx.eddsa_verify(e, e, e, e).shape == (0,)
+
+
+def _points(oracle, n, seed):
+    """cfg-3 points: k*B8 + c*T8 (whole group incl. torsion), via the oracle."""
+    from babyjubjub_rs_amd import workload
+    import bjj_oracle as o
+    ks = workload.random_u256(seed, n)
+    base = oracle.mul_fixed_base(ks)
+    tors = [o.mul_scalar(o.T8, c) for c in range(8)]
+    cs = workload.splitmix64(seed ^ 0x55, n) & np.uint64(7)
+    tp = pack([tors[int(c)] for c in cs]).reshape(n, 64)
+    return oracle.point_add(base, tp)
+
+
+def test_var_base_random_full_group(gpu_ctx, oracle):
+    from babyjubjub_rs_amd import workload
+    n = 1536
+    pts = _points(oracle, n, workload.SEED_POINTS)
+    sc = workload.random_u256(workload.SEED_SCALARS, n, offset=100)
+    # edge rows: identity, order-2 point, off-curve garbage, zero scalar, huge scalars
+    pts[0] = pack([(0, 1)]); pts[1] = pack([(0, Q - 1)]); pts[2] = 7; pts[3] = 0
+    sc[4] = 0; sc[5] = 255; sc[6] = pack([ORDER]); sc[7] = pack([L])
+    got = gpu_ctx.mul_var_base(pts, sc)
+    want = oracle.mul_var_base(pts, sc)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+
+
+def test_poseidon_random(gpu_ctx, oracle):
+    from babyjubjub_rs_amd import workload
+    n = 4096
+    a = workload.random_u256(workload.SEED_MSGS, 5 * n).reshape(n, 160)  # values >= r are reduced on both sides
+    assert (gpu_ctx.poseidon5(a) == oracle.poseidon5(a)).all()
+
+
+def make_signatures(fixed_base, poseidon5, n, offset=0):
+    """cfg-4 workload: A = k*B8, R = rho*B8, S = rho + 8*hm*k mod l.
+    `fixed_base` / `poseidon5` are callables (GPU library or oracle)."""
+    from babyjubjub_rs_amd import workload as w
+    k = [v % L for v in w.to_ints(w.random_u256(w.SEED_KEYS, n, offset))]
+    rho = [v % L for v in w.to_ints(w.random_u256(w.SEED_NONCES, n, offset))]
+    msg = w.random_u256(w.SEED_MSGS, n, offset, top_bits_cleared=3)  # < 2^253 < Q
+    A = fixed_base(w.from_ints(k))
+    R = fixed_base(w.from_ints(rho))
+    hm = w.to_ints(poseidon5(np.concatenate([R, A, msg], axis=1)))
+    S = w.from_ints([(rho[i] + 8 * hm[i] * k[i]) % L for i in range(n)])
+    return A, R, S, msg
+
+
+def corrupt(A, R, S, msg, n, offset=0):
+    """1 item in 64 gets one seeded bit flipped in S, msg, R.y or A.x; returns the bad mask."""
+    from babyjubjub_rs_amd import workload as w
+    r = w.splitmix64(w.SEED_BAD, n, offset)
+    bad = (r & np.uint64(63)) == 0
+    which = (r >> np.uint64(6)) & np.uint64(3)
+    bit = ((r >> np.uint64(8)) % np.uint64(250)).astype(np.int64)
+    for i in np.nonzero(bad)[0]:
+        tgt = (S[i], msg[i], R[i, 32:], A[i, :32])[int(which[i])]
+        tgt[bit[i] // 8] ^= np.uint8(1 << (bit[i] % 8))
+    return bad
+
+
+def test_verify_random_with_corruption(gpu_ctx, oracle):
+    n = 2048
+    A, R, S, msg = make_signatures(oracle.mul_fixed_base, oracle.poseidon5, n)
+    bad = corrupt(A, R, S, msg, n)
+    assert bad.sum() > 8
+    got = gpu_ctx.eddsa_verify(A, R, S, msg)
+    want = oracle.verify(A, R, S, msg)
+    assert (got == want).all()
+    assert (got[~bad] == 1).all() and (got[bad] == 0).all()
+
+
+def test_verify_msg_range_rule(gpu_ctx, oracle):
+    """msg > Q -> false; msg == Q accepted and hashed as 0 (src/lib.rs:396-399)."""
+    import bjj_oracle as o
+    A, R, S = o.sign_with_scalars(12345, 67890, 0)
+    msgs = [0, Q, Q + 1, (1 << 256) - 1, Q - 1]
+    n = len(msgs)
+    got = gpu_ctx.eddsa_verify(pack([A] * n), pack([R] * n), pack([S] * n), pack(msgs))
+    assert list(got) == [1, 1, 0, 0, 0]
+    assert list(oracle.verify(pack([A] * n), pack([R] * n), pack([S] * n), pack(msgs))) == [1, 1, 0, 0, 0]
+
+
+@pytest.mark.parametrize("window_bits", [4, 8, 13])
+def test_fixed_base_other_window_widths(oracle, window_bits):
+    """the table geometry is a tuning knob; results must not depend on it (13 does not divide 256)."""
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload
+    ctx = bjj.Context(0, window_bits)
+    try:
+        info = ctx.info()
+        assert info.window_bits == window_bits and info.n_windows == -(-256 // window_bits)
+        sc = workload.random_u256(workload.SEED_SCALARS, 777, offset=5)
+        sc[0] = 255
+        assert (ctx.mul_fixed_base(sc) == oracle.mul_fixed_base(sc)).all()
+        A, R, S, msg = make_signatures(oracle.mul_fixed_base, oracle.poseidon5, 130)
+        S[3, 0] ^= 1
+        assert (ctx.eddsa_verify(A, R, S, msg) == oracle.verify(A, R, S, msg)).all()
+    finally:
+        ctx.close()
+
+
+# ---------------------------------------------------------------- device-pointer API
+def test_device_pointer_api_and_streams(gpu_ctx, oracle):
+    import torch
+    from babyjubjub_rs_amd import workload, BjjError
+    dev = torch.device("cuda:0")
+    n = 5000
+    sc = workload.scalars_254(n)
+    d_sc = torch.from_numpy(sc.reshape(-1)).to(dev)
+    d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream()
+    gpu_ctx.reserve(n)
+    torch.cuda.synchronize()
+    gpu_ctx.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    want = oracle.mul_fixed_base(sc)
+    assert (d_out.cpu().numpy().reshape(n, 64) == want).all()
+    # variable base on the results, default (context) stream
+    d_out2 = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    gpu_ctx.mul_var_base_dev(d_out.data_ptr(), d_sc.data_ptr(), n, d_out2.data_ptr(), 0)
+    gpu_ctx.sync()
+    assert (d_out2.cpu().numpy().reshape(n, 64) == oracle.mul_var_base(want, sc)).all()
+    # misaligned / NULL device pointers are rejected
+    with pytest.raises(BjjError):
+        gpu_ctx.mul_fixed_base_dev(d_sc.data_ptr() + 4, n - 1, d_out.data_ptr(), 0)
+    with pytest.raises(BjjError):
+        gpu_ctx.mul_fixed_base_dev(0, n, d_out.data_ptr(), 0)
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE sizes)
+def test_full_size_fixed_base_1m(gpu_ctx, oracle):
+    """cfg 2 at 2^20: (i) strided sample byte-compared with the oracle, (ii) linearity over the whole
+    batch: a*B8 + b*B8 == ((a + b) mod 8l)*B8, (iii) the variable-base kernel on P = B8 agrees."""
+    from babyjubjub_rs_amd import workload as w
+    n = 1 << 20
+    a = w.scalars_254(n)
+    ga = gpu_ctx.mul_fixed_base(a)
+    idx = np.arange(0, n, 997)
+    assert (ga[idx] == oracle.mul_fixed_base(a[idx])).all()
+    b = np.roll(a, 1, axis=0)
+    gb = np.roll(ga, 1, axis=0)
+    a64 = a.view("<u8").reshape(n, 4).astype(object)
+    b64 = b.view("<u8").reshape(n, 4).astype(object)
+    summed = [(int(x[0]) | int(x[1]) << 64 | int(x[2]) << 128 | int(x[3]) << 192) +
+              (int(y[0]) | int(y[1]) << 64 | int(y[2]) << 128 | int(y[3]) << 192) for x, y in zip(a64, b64)]
+    gs = gpu_ctx.mul_fixed_base(w.from_ints([s % ORDER for s in summed]))
+    assert (gpu_ctx.point_add(ga, gb) == gs).all()
+    m = 1 << 17
+    b8 = np.tile(pack([(5299619240641551281634865583518297030282874472190772894086521144482721001553,
+                        16950150798460657717958625567821834550301663161624707787222815936182638968203)]), (m, 1))
+    assert (gpu_ctx.mul_var_base(b8, a[:m]) == ga[:m]).all()
+
+
+def test_full_size_verify_1m(gpu_ctx, oracle):
+    """cfg 4 at 2^20: signatures synthesised with the GPU kernels themselves (a strided sample of
+    every intermediate is checked against the oracle), 1/64 corrupted; the verdict vector must equal
+    the known corruption mask, and a strided sample must equal the oracle's verdicts."""
+    n = 1 << 20
+    A, R, S, msg = make_signatures(gpu_ctx.mul_fixed_base, gpu_ctx.poseidon5, n)
+    idx = np.arange(0, n, 4099)
+    Ao, Ro, So, mo = make_signatures(oracle.mul_fixed_base, oracle.poseidon5, idx.size)  # offset 0 prefix
+    assert (A[:idx.size] == Ao).all() and (R[:idx.size] == Ro).all() and (S[:idx.size] == So).all()
+    bad = corrupt(A, R, S, msg, n)
+    got = gpu_ctx.eddsa_verify(A, R, S, msg)
+    assert (got == (~bad).astype(np.uint8)).all()
+    assert (got[idx] == oracle.verify(A[idx], R[idx], S[idx], msg[idx])).all()
