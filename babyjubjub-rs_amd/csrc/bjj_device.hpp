@@ -185,22 +185,28 @@ BJJ_HD Niels fixed_table_entry(u32 k, int j, int W, const Consts& K) {
 }
 
 // one variable-base item: (x, y) Montgomery on the reference curve, raw 256-bit scalar.
-// Result as an extended point on the a'=-1 curve (exact-path results are mapped onto
-// it with Z = 1 so that the shared affine epilogue maps them back unchanged).
-BJJ_HD Ext var_base_item(const Fr& x, const Fr& y, const u32 sc[8], u32* tbl, const Consts& K) {
+// Fast path (on-curve): extended point on the a'=-1 curve.  Off-curve points need the
+// reference's exact formula sequence; the kernels defer them to a compacted second launch
+// (a wave that contains one such lane would otherwise execute both paths for all 64 lanes).
+BJJ_HD Ext var_base_fast(const Fr& x, const Fr& y, const u32 sc[8], u32* tbl, const Consts& K) {
+  u32 red[8];
+  scalar_mod_order(sc, red, K);
+  Ext P = ext_from_ref_affine(x, y, K);
+  vb_build_table(P, tbl, K);
+  return vb_mul_windowed(tbl, red, 64);
+}
+// exact replay of the reference's bit-serial loop; result mapped onto the a'=-1 curve with
+// Z = 1 so that the shared affine epilogue maps it back unchanged.
+BJJ_HD Ext var_base_exact(const Fr& x, const Fr& y, const u32 sc[8], const Consts& K) {
+  Fr ox, oy;
+  ref_mul_scalar(x, y, sc, 8, ox, oy, K);
   Ext p;
-  if (ref_on_curve(x, y, K)) {
-    u32 red[8];
-    scalar_mod_order(sc, red, K);
-    Ext P = ext_from_ref_affine(x, y, K);
-    vb_build_table(P, tbl, K);
-    p = vb_mul_windowed(tbl, red, 64);
-  } else {  // exact replay of the reference's bit-serial loop
-    Fr ox, oy;
-    ref_mul_scalar(x, y, sc, 8, ox, oy, K);
-    p.X = fr_mul(ox, K.F); p.Y = oy; p.Z = fr_one(); p.T = fr_zero();
-  }
+  p.X = fr_mul(ox, K.F); p.Y = oy; p.Z = fr_one(); p.T = fr_zero();
   return p;
+}
+BJJ_HD Ext var_base_item(const Fr& x, const Fr& y, const u32 sc[8], u32* tbl, const Consts& K) {
+  if (ref_on_curve(x, y, K)) return var_base_fast(x, y, sc, tbl, K);
+  return var_base_exact(x, y, sc, K);
 }
 
 // msg > Q ?   (src/lib.rs:396-398; msg == Q is accepted and wraps to 0)
@@ -220,7 +226,38 @@ BJJ_HD bool words_gt_modulus(const u32 w[8]) {
 // =============================================================================
 struct VerifyIn { const void *pk, *r, *s, *msg; };  // this item's 64/64/32/32-byte records
 
-BJJ_HD bool verify_item(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K) {
+// Fast path.  Sets need_exact (and returns false) when pk or R is off the curve.
+BJJ_HD bool verify_fast(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K,
+                        bool& need_exact) {
+  u32 w[8];
+  need_exact = false;
+  load_w8(in.msg, w);
+  if (words_gt_modulus(w)) return false;                        // :396-398
+  Fr h[5];
+  h[4] = fr_to_mont_words(w);                                   // :399
+  load_w8(in.r, w);                   h[0] = fr_to_mont_words(w);
+  load_w8((const char*)in.r + 32, w); h[1] = fr_to_mont_words(w);
+  load_w8(in.pk, w);                  h[2] = fr_to_mont_words(w);
+  load_w8((const char*)in.pk + 32, w); h[3] = fr_to_mont_words(w);
+  if (!(ref_on_curve(h[0], h[1], K) && ref_on_curve(h[2], h[3], K))) { need_exact = true; return false; }
+  Fr hm = poseidon5(h, K);                                      // :400-404
+  Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // canonical integer, :406
+  // s*B8 == R + 8*hm*A   <=>   8*(hm mod l)*(-A) + s*B8 == R      (group order 8l)
+  u32 kw[8], sw[8];
+  fr_to_words(plain_mod_l(hm_plain, K), kw);
+  Ext negA = ext_from_ref_affine(fr_neg(h[2]), h[3], K);
+  vb_build_table(negA, vb_tbl, K);
+  Ext q = vb_mul_windowed(vb_tbl, kw, 64);                      // k < l < 2^251
+  q = ext_dbl<false>(q); q = ext_dbl<false>(q); q = ext_dbl<true>(q);
+  load_w8(in.s, sw);
+  q = fixed_base_accumulate(q, fb_table, W, nwin, sw);          // + s*B8   (:405)
+  // compare with R on the a'=-1 curve: X == (F Rx) Z, Y == Ry Z
+  load_w8(in.r, w);                   Fr rx = fr_mul(fr_to_mont_words(w), K.F);
+  load_w8((const char*)in.r + 32, w); Fr ry = fr_to_mont_words(w);
+  return fr_eq(q.X, fr_mul(rx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z));
+}
+// Exact path: replays src/lib.rs:395-412 operation by operation (any input).
+BJJ_HD bool verify_exact(const VerifyIn& in, const Consts& K) {
   u32 w[8];
   load_w8(in.msg, w);
   if (words_gt_modulus(w)) return false;                        // :396-398
@@ -230,26 +267,10 @@ BJJ_HD bool verify_item(const VerifyIn& in, const u32* fb_table, int W, int nwin
   load_w8((const char*)in.r + 32, w); h[1] = fr_to_mont_words(w);
   load_w8(in.pk, w);                  h[2] = fr_to_mont_words(w);
   load_w8((const char*)in.pk + 32, w); h[3] = fr_to_mont_words(w);
-  const bool fast = ref_on_curve(h[0], h[1], K) && ref_on_curve(h[2], h[3], K);
   Fr hm = poseidon5(h, K);                                      // :400-404
-  Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // canonical integer, :406
+  Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // :406
   u32 sw[8];
   load_w8(in.s, sw);
-  if (fast) {
-    // s*B8 == R + 8*hm*A   <=>   8*(hm mod l)*(-A) + s*B8 == R      (group order 8l)
-    u32 kw[8];
-    fr_to_words(plain_mod_l(hm_plain, K), kw);
-    Ext negA = ext_from_ref_affine(fr_neg(h[2]), h[3], K);
-    vb_build_table(negA, vb_tbl, K);
-    Ext q = vb_mul_windowed(vb_tbl, kw, 64);                    // k < l < 2^251
-    q = ext_dbl<false>(q); q = ext_dbl<false>(q); q = ext_dbl<true>(q);
-    q = fixed_base_accumulate(q, fb_table, W, nwin, sw);        // + s*B8   (:405)
-    // compare with R on the a'=-1 curve: X == (F Rx) Z, Y == Ry Z
-    load_w8(in.r, w);                   Fr rx = fr_mul(fr_to_mont_words(w), K.F);
-    load_w8((const char*)in.r + 32, w); Fr ry = fr_to_mont_words(w);
-    return fr_eq(q.X, fr_mul(rx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z));
-  }
-  // exact path (some input point is off the curve): replay src/lib.rs:405-411
   Fr lx, ly, tx, ty;
   ref_mul_scalar(K.B8X, K.B8Y, sw, 8, lx, ly, K);               // :405
   u32 h8[9], hw[8];
@@ -266,6 +287,11 @@ BJJ_HD bool verify_item(const VerifyIn& in, const u32* fb_table, int W, int nwin
   if (fr_is_zero(sum.z)) { ax = fr_zero(); ay = fr_zero(); }    // :71-76
   else { Fr zi = fr_inv(sum.z); ax = fr_mul(sum.x, zi); ay = fr_mul(sum.y, zi); }
   return fr_eq(lx, ax) && fr_eq(ly, ay);                        // :411, :180-185
+}
+BJJ_HD bool verify_item(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K) {
+  bool need_exact;
+  bool ok = verify_fast(in, fb_table, W, nwin, vb_tbl, K, need_exact);
+  return need_exact ? verify_exact(in, K) : ok;
 }
 
 }  // namespace bjj

@@ -31,7 +31,7 @@ using namespace bjj;
 __constant__ Consts c_K = {
     BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_B8X, BJJ_K_B8Y,
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
-    BJJ_K_POSEIDON_C, BJJ_K_POSEIDON_M};
+    BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M};
 
 // ---------------------------------------------------------------------------
 // workgroup-wide simultaneous inversion: every thread passes x (Montgomery, != 0,
@@ -161,12 +161,13 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_fixed_base(const u32* __r
 }
 
 // ---------------------------------------------------------------------------
-// K2 (+K6): variable base
+// K2: variable base.  Off-curve points are appended to `slow` (slow[0] = count, then item
+// indices) and finished by K6 (bjj_k_mul_var_base_exact) right after this kernel.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
                                                                 const uint8_t* __restrict__ scalars, size_t n,
                                                                 uint8_t* __restrict__ out, u32* __restrict__ scratch,
-                                                                u32* __restrict__ vb_tables) {
+                                                                u32* __restrict__ vb_tables, u32* __restrict__ slow) {
   __shared__ u32 lds[NL * BJJ_BLOCK];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
@@ -178,16 +179,35 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_var_base(const uint8_t* _
     load_w8(pts + i * 64, w);      Fr x = fr_to_mont_words(w);
     load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
     load_w8(scalars + i * 32, sc);
-    Ext p = var_base_item(x, y, sc, tbl, c_K);
+    Ext p = ext_identity();
+    if (ref_on_curve(x, y, c_K)) p = var_base_fast(x, y, sc, tbl, c_K);
+    else slow[1 + atomicAdd(&slow[0], 1u)] = (u32)i;  // placeholder result; K6 overwrites the output
     epilogue_stash(p, run, out + i * 64, scratch + i * 16);
   }
   epilogue_run(run, n, tid, nthreads, out, scratch, lds);
+}
+// K6: exact replay of the reference's loop for the (rare) off-curve inputs, one per lane.
+__global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __restrict__ pts,
+                                                               const uint8_t* __restrict__ scalars,
+                                                               uint8_t* __restrict__ out, const u32* __restrict__ slow) {
+  const u32 cnt = slow[0];
+  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
+    const size_t i = slow[1 + j];
+    u32 w[8], sc[8];
+    load_w8(pts + i * 64, w);      Fr x = fr_to_mont_words(w);
+    load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
+    load_w8(scalars + i * 32, sc);
+    Fr ox, oy;
+    ref_mul_scalar(x, y, sc, 8, ox, oy, c_K);
+    fr_from_mont_words(ox, w); store_w8(out + i * 64, w);
+    fr_from_mont_words(oy, w); store_w8(out + i * 64 + 32, w);
+  }
 }
 
 // ---------------------------------------------------------------------------
 // K3: Poseidon, 5 inputs
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_poseidon5(const uint8_t* __restrict__ in, size_t n,
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_poseidon5(const uint8_t* __restrict__ in, size_t n,
                                                              uint8_t* __restrict__ out) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
@@ -204,21 +224,38 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_poseidon5(const uint8_t* __re
 }
 
 // ---------------------------------------------------------------------------
-// K4: EdDSA-Poseidon verify
+// K4: EdDSA-Poseidon verify.  Items whose pk or R is off the curve go to `slow` and are
+// finished by bjj_k_eddsa_verify_exact.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
                                                                 const uint8_t* __restrict__ pk,
                                                                 const uint8_t* __restrict__ rb8,
                                                                 const uint8_t* __restrict__ s,
                                                                 const uint8_t* __restrict__ msg, size_t n,
-                                                                uint8_t* __restrict__ ok, u32* __restrict__ vb_tables) {
+                                                                uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
+                                                                u32* __restrict__ slow) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
 #pragma unroll 1
   for (size_t i = tid; i < n; i += nthreads) {
     VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
-    ok[i] = verify_item(in, table, W, nwin, tbl, c_K) ? 1 : 0;
+    bool need_exact;
+    bool v = verify_fast(in, table, W, nwin, tbl, c_K, need_exact);
+    if (need_exact) slow[1 + atomicAdd(&slow[0], 1u)] = (u32)i;
+    else ok[i] = v ? 1 : 0;
+  }
+}
+__global__ void __launch_bounds__(64) bjj_k_eddsa_verify_exact(const uint8_t* __restrict__ pk,
+                                                               const uint8_t* __restrict__ rb8,
+                                                               const uint8_t* __restrict__ s,
+                                                               const uint8_t* __restrict__ msg,
+                                                               uint8_t* __restrict__ ok, const u32* __restrict__ slow) {
+  const u32 cnt = slow[0];
+  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
+    const size_t i = slow[1 + j];
+    VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
+    ok[i] = verify_exact(in, c_K) ? 1 : 0;
   }
 }
 
@@ -268,6 +305,8 @@ struct bjj_ctx {
   size_t scratch_items = 0;
   u32* vb_tables = nullptr;    // grid threads * VB_TABLE_WORDS * 4 B
   size_t vb_threads = 0;
+  u32* slow = nullptr;         // [0] = count, [1..] item indices deferred to the exact-path kernels
+  size_t slow_items = 0;
   // staging buffers for the host-pointer API
   uint8_t* stage = nullptr;
   size_t stage_bytes = 0;
@@ -291,6 +330,11 @@ static int ensure_scratch(bjj_ctx* c, size_t n) {
     if (c->scratch) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->scratch)); c->scratch = nullptr; }
     HIPCK(hipMalloc((void**)&c->scratch, n * 64));
     c->scratch_items = n;
+  }
+  if (n > c->slow_items) {
+    if (c->slow) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->slow)); c->slow = nullptr; }
+    HIPCK(hipMalloc((void**)&c->slow, (n + 4) * sizeof(u32)));
+    c->slow_items = n;
   }
   size_t threads = (size_t)c->cus * BPC_VAR * BJJ_BLOCK;
   if (threads > c->vb_threads) {
@@ -360,6 +404,7 @@ void bjj_free(bjj_ctx* c) {
   if (c->table) hipFree(c->table);
   if (c->scratch) hipFree(c->scratch);
   if (c->vb_tables) hipFree(c->vb_tables);
+  if (c->slow) hipFree(c->slow);
   if (c->stage) hipFree(c->stage);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -384,7 +429,7 @@ int bjj_get_info(bjj_ctx* c, bjj_info* info) {
   info->window_bits = c->W;
   info->n_windows = c->nwin;
   info->table_bytes = c->table_bytes;
-  info->scratch_bytes = c->scratch_items * 64 + c->vb_threads * VB_TABLE_WORDS * sizeof(u32);
+  info->scratch_bytes = c->scratch_items * 64 + c->vb_threads * VB_TABLE_WORDS * sizeof(u32) + c->slow_items * 4;
   info->kernel_fixed_base = "bjj_k_mul_fixed_base";
   info->kernel_var_base = "bjj_k_mul_var_base";
   info->kernel_poseidon5 = "bjj_k_poseidon5";
@@ -413,8 +458,12 @@ int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, s
   CHECK_PTR(d_pts, "bjj_mul_var_base_dev"); CHECK_PTR(d_scalars, "bjj_mul_var_base_dev"); CHECK_PTR(d_out, "bjj_mul_var_base_dev");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIPCK(hipMemsetAsync(c->slow, 0, sizeof(u32), st));
   hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid_for(c, n, BPC_VAR)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pts,
-                     (const uint8_t*)d_scalars, n, (uint8_t*)d_out, c->scratch, c->vb_tables);
+                     (const uint8_t*)d_scalars, n, (uint8_t*)d_out, c->scratch, c->vb_tables, c->slow);
+  HIPCK(hipGetLastError());
+  hipLaunchKernelGGL(bjj_k_mul_var_base_exact, dim3(c->cus * 4), dim3(64), 0, st, (const uint8_t*)d_pts,
+                     (const uint8_t*)d_scalars, (uint8_t*)d_out, c->slow);
   HIPCK(hipGetLastError());
   return BJJ_OK;
 }
@@ -435,11 +484,15 @@ int bjj_eddsa_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const vo
   CHECK_PTR(d_pk, "bjj_eddsa_verify_dev"); CHECK_PTR(d_r, "bjj_eddsa_verify_dev");
   CHECK_PTR(d_s, "bjj_eddsa_verify_dev"); CHECK_PTR(d_msg, "bjj_eddsa_verify_dev");
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_dev: d_ok is NULL");
-  int rc = ensure_scratch(c, 1); if (rc) return rc;
+  int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIPCK(hipMemsetAsync(c->slow, 0, sizeof(u32), st));
   hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid_for(c, n, BPC_VERIFY)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
                      c->nwin, (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n,
-                     (uint8_t*)d_ok, c->vb_tables);
+                     (uint8_t*)d_ok, c->vb_tables, c->slow);
+  HIPCK(hipGetLastError());
+  hipLaunchKernelGGL(bjj_k_eddsa_verify_exact, dim3(c->cus * 4), dim3(64), 0, st, (const uint8_t*)d_pk,
+                     (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, (uint8_t*)d_ok, c->slow);
   HIPCK(hipGetLastError());
   return BJJ_OK;
 }

@@ -29,8 +29,12 @@ struct Consts {
   Fr B8X, B8Y;      // generator, Montgomery (reference curve)
   Fr ORDER, ORDER2, ORDER4;  // plain integers 8l, 16l, 32l in 29-bit limbs
   Fr L, L2, L4;              // plain integers l, 2l, 4l
-  Fr PC[408];       // Poseidon t=6 round constants, Montgomery
-  Fr PM[36];        // Poseidon t=6 MDS, row-major, Montgomery
+  // Poseidon t=6 in its sparse-partial-round form (gen_tables.py: poseidon_sparse_constants)
+  Fr PCF[48];       // full-round constants: rounds 0-3 then 64-67 (round 64 adjusted), Montgomery
+  Fr PKP[60];       // scalar constant of each partial round
+  Fr PSP[660];      // per partial round: m00, v[5], what[5]
+  Fr PAL[25];       // 5x5 block applied after the last partial round
+  Fr PM[36];        // MDS, row-major
 };
 
 struct Ext { Fr X, Y, Z, T; };            // a' = -1 curve, extended

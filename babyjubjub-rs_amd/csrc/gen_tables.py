@@ -120,6 +120,86 @@ def poseidon_plain(C, M, inputs):
     return st[0]
 
 
+# ---------------------------------------------------------------- sparse partial rounds
+def mat_vec(M, v):
+    return [sum(M[i][j] * v[j] for j in range(len(v))) % Q for i in range(len(M))]
+
+
+def mat_mul(A, B):
+    n, m, k = len(A), len(B[0]), len(B)
+    return [[sum(A[i][x] * B[x][j] for x in range(k)) % Q for j in range(m)] for i in range(n)]
+
+
+def mat_inv(A):
+    n = len(A)
+    a = [list(r) + [1 if i == j else 0 for j in range(n)] for i, r in enumerate(A)]
+    for c in range(n):
+        piv = next(r for r in range(c, n) if a[r][c] % Q)
+        a[c], a[piv] = a[piv], a[c]
+        iv = inv(a[c][c])
+        a[c] = [x * iv % Q for x in a[c]]
+        for r in range(n):
+            if r != c and a[r][c]:
+                f = a[r][c]
+                a[r] = [(x - f * y) % Q for x, y in zip(a[r], a[c])]
+    return [r[n:] for r in a]
+
+
+def poseidon_sparse_constants(C, M):
+    """Equivalent form of the 60 partial rounds (same outputs, fewer multiplications).
+
+    state' = M . sbox0(state + c)  with sbox0 touching element 0 only.
+    (1) the constants of elements 1..5 commute with sbox0, so they are pushed through M into
+        the next round; every partial round keeps only a scalar constant k_p for element 0,
+        the last tail lands in the constants of full round 64.
+    (2) M^(p) = A_p . B_p with A_p = diag(1, Mh) (commutes with the next sbox0) and the sparse
+        B_p = [[m00, v], [Mh^-1 w, I]];  M^(p+1) = M . A_p.  A_59 is applied once at the end.
+    Returns (CF[48], K[60], S[60][11] = m00, v[5], what[5], AL[25])."""
+    full_c = [list(C[r * T:(r + 1) * T]) for r in range(RF + RP)]
+    kp = [list(full_c[RF // 2 + p]) for p in range(RP)]
+    for p in range(RP):
+        tail = [0] + kp[p][1:]
+        pushed = mat_vec(M, tail)
+        if p + 1 < RP:
+            kp[p + 1] = [(a + b) % Q for a, b in zip(kp[p + 1], pushed)]
+        else:
+            full_c[RF // 2 + RP] = [(a + b) % Q for a, b in zip(full_c[RF // 2 + RP], pushed)]
+    K = [kp[p][0] for p in range(RP)]
+    S = []
+    Mp = [list(r) for r in M]
+    A_last = None
+    for p in range(RP):
+        m00 = Mp[0][0]
+        v = Mp[0][1:]
+        w = [[Mp[i][0]] for i in range(1, T)]
+        Mh = [Mp[i][1:] for i in range(1, T)]
+        what = [x[0] for x in mat_mul(mat_inv(Mh), w)]
+        S.append([m00] + v + what)
+        A = [[1] + [0] * (T - 1)] + [[0] + Mh[i] for i in range(T - 1)]
+        A_last = Mh
+        Mp = mat_mul(M, A)
+    CF = [c for r in range(RF // 2) for c in full_c[r]] + [c for r in range(RF // 2 + RP, RF + RP) for c in full_c[r]]
+    AL = [A_last[i][j] for i in range(T - 1) for j in range(T - 1)]
+    return CF, K, S, AL
+
+
+def poseidon_sparse(CF, K, S, AL, M, inputs):
+    st = [0] + list(inputs)
+    for r in range(RF // 2):
+        st = [pow((st[j] + CF[r * T + j]) % Q, 5, Q) for j in range(T)]
+        st = mat_vec(M, st)
+    for p in range(RP):
+        x0 = pow((st[0] + K[p]) % Q, 5, Q)
+        s = S[p]
+        u0 = (s[0] * x0 + sum(s[1 + j] * st[1 + j] for j in range(T - 1))) % Q
+        st = [u0] + [(s[T + j] * x0 + st[1 + j]) % Q for j in range(T - 1)]
+    st = [st[0]] + [sum(AL[i * (T - 1) + j] * st[1 + j] for j in range(T - 1)) % Q for i in range(T - 1)]
+    for r in range(RF // 2):
+        st = [pow((st[j] + CF[(RF // 2 + r) * T + j]) % Q, 5, Q) for j in range(T)]
+        st = mat_vec(M, st)
+    return st[0]
+
+
 # ---------------------------------------------------------------- emit helpers
 def limbs32(v):
     """9 x 29-bit limbs (fr.hpp N-form); the top limb takes whatever is left (< 2^26)."""
@@ -160,8 +240,31 @@ def main():
     o.append("#define BJJ_K_L        %s  // PLAIN l" % limbs32(SUBORDER))
     o.append("#define BJJ_K_L2       %s  // PLAIN 2*l" % limbs32(2 * SUBORDER))
     o.append("#define BJJ_K_L4       %s  // PLAIN 4*l" % limbs32(4 * SUBORDER))
-    o.append("#define BJJ_K_POSEIDON_C { \\")
+    CF, KP, SP, AL = poseidon_sparse_constants(C, M)
+    import random
+    rnd = random.Random(2024)
+    for _ in range(6):
+        ins = [rnd.randrange(Q) for _ in range(5)]
+        assert poseidon_sparse(CF, KP, SP, AL, M, ins) == poseidon_plain(C, M, ins), "sparse Poseidon is not equivalent"
+    o.append("#define BJJ_K_POSEIDON_C { /* plain form, 68 x 6: kept for tests / documentation */ \\")
     for v in C:
+        o.append("  %s, \\" % limbs32(mont(v)))
+    o.append("}")
+    o.append("#define BJJ_K_POSEIDON_CF { /* full-round constants: rounds 0-3, then 64-67 (64 adjusted) */ \\")
+    for v in CF:
+        o.append("  %s, \\" % limbs32(mont(v)))
+    o.append("}")
+    o.append("#define BJJ_K_POSEIDON_KP { /* scalar constant of each partial round */ \\")
+    for v in KP:
+        o.append("  %s, \\" % limbs32(mont(v)))
+    o.append("}")
+    o.append("#define BJJ_K_POSEIDON_SP { /* per partial round: m00, v[5], what[5] */ \\")
+    for row in SP:
+        for v in row:
+            o.append("  %s, \\" % limbs32(mont(v)))
+    o.append("}")
+    o.append("#define BJJ_K_POSEIDON_AL { /* 5x5 block applied after the last partial round, row-major */ \\")
+    for v in AL:
         o.append("  %s, \\" % limbs32(mont(v)))
     o.append("}")
     o.append("#define BJJ_K_POSEIDON_M { /* row-major M[i][j] */ \\")
