@@ -226,6 +226,18 @@ BJJ_HD bool words_gt_modulus(const u32 w[8]) {
 // =============================================================================
 struct VerifyIn { const void *pk, *r, *s, *msg; };  // this item's 64/64/32/32-byte records
 
+// true when verify() must take the exact path: msg in range and pk or R off the curve
+BJJ_HD bool verify_needs_exact(const VerifyIn& in, const Consts& K) {
+  u32 w[8];
+  load_w8(in.msg, w);
+  if (words_gt_modulus(w)) return false;  // verdict is `false` either way (:396-398)
+  load_w8(in.r, w);                    Fr rx = fr_to_mont_words(w);
+  load_w8((const char*)in.r + 32, w);  Fr ry = fr_to_mont_words(w);
+  if (!ref_on_curve(rx, ry, K)) return true;
+  load_w8(in.pk, w);                   Fr ax = fr_to_mont_words(w);
+  load_w8((const char*)in.pk + 32, w); Fr ay = fr_to_mont_words(w);
+  return !ref_on_curve(ax, ay, K);
+}
 // Fast path.  Sets need_exact (and returns false) when pk or R is off the curve.
 BJJ_HD bool verify_fast(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K,
                         bool& need_exact) {

@@ -161,8 +161,8 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_fixed_base(const u32* __r
 }
 
 // ---------------------------------------------------------------------------
-// K2: variable base.  Off-curve points are appended to `slow` (slow[0] = count, then item
-// indices) and finished by K6 (bjj_k_mul_var_base_exact) right after this kernel.
+// K2: variable base.  Off-curve points are appended to `slow` (slow[0] = count, item indices from
+// slow[8]) and finished by K6 (bjj_k_mul_var_base_exact) right after this kernel.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
                                                                 const uint8_t* __restrict__ scalars, size_t n,
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_var_base(const uint8_t* _
     load_w8(scalars + i * 32, sc);
     Ext p = ext_identity();
     if (ref_on_curve(x, y, c_K)) p = var_base_fast(x, y, sc, tbl, c_K);
-    else slow[1 + atomicAdd(&slow[0], 1u)] = (u32)i;  // placeholder result; K6 overwrites the output
+    else slow[8 + atomicAdd(&slow[0], 1u)] = (u32)i;  // placeholder result; K6 overwrites the output
     epilogue_stash(p, run, out + i * 64, scratch + i * 16);
   }
   epilogue_run(run, n, tid, nthreads, out, scratch, lds);
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __
                                                                uint8_t* __restrict__ out, const u32* __restrict__ slow) {
   const u32 cnt = slow[0];
   for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
-    const size_t i = slow[1 + j];
+    const size_t i = slow[8 + j];
     u32 w[8], sc[8];
     load_w8(pts + i * 64, w);      Fr x = fr_to_mont_words(w);
     load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
@@ -224,38 +224,65 @@ __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_poseidon5(const uint8_t* _
 }
 
 // ---------------------------------------------------------------------------
-// K4: EdDSA-Poseidon verify.  Items whose pk or R is off the curve go to `slow` and are
-// finished by bjj_k_eddsa_verify_exact.
+// K4: EdDSA-Poseidon verify, two launches:
+//  (1) bjj_k_eddsa_verify_scan: on-curve tests only (14 multiplications per item); items whose
+//      pk or R is off the curve -- they need the reference's exact, ~3x longer, strictly serial
+//      formula sequence -- are appended to the work list `wl`.
+//  (2) bjj_k_eddsa_verify: waves pull work through atomic cursors: first 64-item groups of the
+//      exact list (so the long items start at t = 0 and overlap everything else), then 64-item
+//      chunks of the whole batch on the fast path.  No wave ever runs both paths for one group.
+// wl layout (u32 words): [0] exact count, [2..3] exact cursor (u64), [4..5] batch cursor (u64),
+// [8..] exact item indices.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
-                                                                const uint8_t* __restrict__ pk,
-                                                                const uint8_t* __restrict__ rb8,
-                                                                const uint8_t* __restrict__ s,
-                                                                const uint8_t* __restrict__ msg, size_t n,
-                                                                uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
-                                                                u32* __restrict__ slow) {
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#define WL_HDR 8
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_eddsa_verify_scan(const uint8_t* __restrict__ pk,
+                                                                     const uint8_t* __restrict__ rb8,
+                                                                     const uint8_t* __restrict__ msg, size_t n,
+                                                                     u32* __restrict__ wl) {
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
-  u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
 #pragma unroll 1
-  for (size_t i = tid; i < n; i += nthreads) {
-    VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
-    bool need_exact;
-    bool v = verify_fast(in, table, W, nwin, tbl, c_K, need_exact);
-    if (need_exact) slow[1 + atomicAdd(&slow[0], 1u)] = (u32)i;
-    else ok[i] = v ? 1 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    VerifyIn in = {pk + i * 64, rb8 + i * 64, nullptr, msg + i * 32};
+    if (verify_needs_exact(in, c_K)) wl[WL_HDR + atomicAdd(&wl[0], 1u)] = (u32)i;
   }
 }
-__global__ void __launch_bounds__(64) bjj_k_eddsa_verify_exact(const uint8_t* __restrict__ pk,
-                                                               const uint8_t* __restrict__ rb8,
-                                                               const uint8_t* __restrict__ s,
-                                                               const uint8_t* __restrict__ msg,
-                                                               uint8_t* __restrict__ ok, const u32* __restrict__ slow) {
-  const u32 cnt = slow[0];
-  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
-    const size_t i = slow[1 + j];
-    VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
-    ok[i] = verify_exact(in, c_K) ? 1 : 0;
+__device__ __forceinline__ unsigned long long wave_grab(u32* cursor_words, int lane) {
+  unsigned long long c = 0;
+  if (lane == 0) c = atomicAdd((unsigned long long*)cursor_words, 64ULL);
+  return __shfl(c, 0, 64);
+}
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
+                                                                   const uint8_t* __restrict__ pk,
+                                                                   const uint8_t* __restrict__ rb8,
+                                                                   const uint8_t* __restrict__ s,
+                                                                   const uint8_t* __restrict__ msg, size_t n,
+                                                                   uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
+                                                                   u32* __restrict__ wl) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
+  const unsigned long long nexact = wl[0];
+#pragma unroll 1
+  for (;;) {  // exact-path groups first
+    const unsigned long long c = wave_grab(wl + 2, lane);
+    if (c >= nexact) break;
+    if (c + lane < nexact) {
+      const size_t i = wl[WL_HDR + c + lane];
+      VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
+      ok[i] = verify_exact(in, c_K) ? 1 : 0;
+    }
+  }
+#pragma unroll 1
+  for (;;) {  // then the bulk
+    const unsigned long long c = wave_grab(wl + 4, lane);
+    if (c >= n) break;
+    const size_t i = c + lane;
+    if (i < n) {
+      VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
+      bool need_exact;
+      bool v = verify_fast(in, table, W, nwin, tbl, c_K, need_exact);
+      if (!need_exact) ok[i] = v ? 1 : 0;  // exact items were written by the first loop
+    }
   }
 }
 
@@ -333,7 +360,7 @@ static int ensure_scratch(bjj_ctx* c, size_t n) {
   }
   if (n > c->slow_items) {
     if (c->slow) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->slow)); c->slow = nullptr; }
-    HIPCK(hipMalloc((void**)&c->slow, (n + 4) * sizeof(u32)));
+    HIPCK(hipMalloc((void**)&c->slow, (n + 16) * sizeof(u32)));
     c->slow_items = n;
   }
   size_t threads = (size_t)c->cus * BPC_VAR * BJJ_BLOCK;
@@ -458,7 +485,7 @@ int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, s
   CHECK_PTR(d_pts, "bjj_mul_var_base_dev"); CHECK_PTR(d_scalars, "bjj_mul_var_base_dev"); CHECK_PTR(d_out, "bjj_mul_var_base_dev");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIPCK(hipMemsetAsync(c->slow, 0, sizeof(u32), st));
+  HIPCK(hipMemsetAsync(c->slow, 0, 8 * sizeof(u32), st));
   hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid_for(c, n, BPC_VAR)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pts,
                      (const uint8_t*)d_scalars, n, (uint8_t*)d_out, c->scratch, c->vb_tables, c->slow);
   HIPCK(hipGetLastError());
@@ -486,13 +513,14 @@ int bjj_eddsa_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const vo
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_dev: d_ok is NULL");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIPCK(hipMemsetAsync(c->slow, 0, sizeof(u32), st));
+  if (n >> 32) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_dev: batches are limited to 2^32 - 1 items");
+  HIPCK(hipMemsetAsync(c->slow, 0, WL_HDR * sizeof(u32), st));
+  hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_for(c, n, 8)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pk,
+                     (const uint8_t*)d_r, (const uint8_t*)d_msg, n, c->slow);
+  HIPCK(hipGetLastError());
   hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid_for(c, n, BPC_VERIFY)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
                      c->nwin, (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n,
                      (uint8_t*)d_ok, c->vb_tables, c->slow);
-  HIPCK(hipGetLastError());
-  hipLaunchKernelGGL(bjj_k_eddsa_verify_exact, dim3(c->cus * 4), dim3(64), 0, st, (const uint8_t*)d_pk,
-                     (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, (uint8_t*)d_ok, c->slow);
   HIPCK(hipGetLastError());
   return BJJ_OK;
 }

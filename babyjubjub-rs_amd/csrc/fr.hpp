@@ -143,6 +143,13 @@ inline void fr_check_mul_operands(const Fr& a, const Fr& b) {
 #define BJJ_CHECK_MUL(a, b) ((void)0)
 #endif
 
+// One multiply-accumulate step of a limb column: acc += x * y (64-bit, never overflows by
+// the column bound above); hipcc selects v_mad_u64_u32.  (Pinning the chain with one inline
+// asm per multiply-add was measured and rejected: hipcc pads every asm statement with an
+// s_nop -- tools/ubench/fr_bench.hip, profiles/r01_fr_bench_*.txt.)
+#define BJJ_MAD(acc, x, y) acc += (u64)(x) * (y)
+#define BJJ_MAD_K(acc, x, k) acc += (u64)(x) * (k)
+
 // Montgomery product a*b*2^-261 mod r, product-scanning, one 64-bit accumulator.
 BJJ_HD Fr fr_mul(const Fr& a, const Fr& b) {
   BJJ_CHECK_MUL(a, b);
@@ -152,19 +159,19 @@ BJJ_HD Fr fr_mul(const Fr& a, const Fr& b) {
 #pragma unroll
   for (int k = 0; k < NL; k++) {
 #pragma unroll
-    for (int i = 0; i <= k; i++) acc += (u64)a.v[i] * b.v[k - i];
+    for (int i = 0; i <= k; i++) BJJ_MAD(acc, a.v[i], b.v[k - i]);
 #pragma unroll
-    for (int i = 0; i < k; i++) acc += (u64)m[i] * fr_modlimb(k - i);
+    for (int i = 0; i < k; i++) BJJ_MAD_K(acc, m[i], fr_modlimb(k - i));
     m[k] = ((u32)acc * BJJ_NINV29) & MASK29;
-    acc += (u64)m[k] * BJJ_N0;
+    BJJ_MAD_K(acc, m[k], BJJ_N0);
     acc >>= 29;
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; k++) {
 #pragma unroll
-    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)a.v[i] * b.v[k - i];
+    for (int i = k - (NL - 1); i < NL; i++) BJJ_MAD(acc, a.v[i], b.v[k - i]);
 #pragma unroll
-    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)m[i] * fr_modlimb(k - i);
+    for (int i = k - (NL - 1); i < NL; i++) BJJ_MAD_K(acc, m[i], fr_modlimb(k - i));
     r.v[k - NL] = (u32)acc & MASK29;
     acc >>= 29;
   }
@@ -183,27 +190,43 @@ BJJ_HD Fr fr_sqr(const Fr& a) {
 #pragma unroll
   for (int k = 0; k < NL; k++) {
 #pragma unroll
-    for (int i = 0; 2 * i < k; i++) acc += (u64)a2[i] * a.v[k - i];
-    if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
+    for (int i = 0; 2 * i < k; i++) BJJ_MAD(acc, a2[i], a.v[k - i]);
+    if ((k & 1) == 0) BJJ_MAD(acc, a.v[k / 2], a.v[k / 2]);
 #pragma unroll
-    for (int i = 0; i < k; i++) acc += (u64)m[i] * fr_modlimb(k - i);
+    for (int i = 0; i < k; i++) BJJ_MAD_K(acc, m[i], fr_modlimb(k - i));
     m[k] = ((u32)acc * BJJ_NINV29) & MASK29;
-    acc += (u64)m[k] * BJJ_N0;
+    BJJ_MAD_K(acc, m[k], BJJ_N0);
     acc >>= 29;
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; k++) {
 #pragma unroll
-    for (int i = k - (NL - 1); 2 * i < k; i++) acc += (u64)a2[i] * a.v[k - i];
-    if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
+    for (int i = k - (NL - 1); 2 * i < k; i++) BJJ_MAD(acc, a2[i], a.v[k - i]);
+    if ((k & 1) == 0) BJJ_MAD(acc, a.v[k / 2], a.v[k / 2]);
 #pragma unroll
-    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)m[i] * fr_modlimb(k - i);
+    for (int i = k - (NL - 1); i < NL; i++) BJJ_MAD_K(acc, m[i], fr_modlimb(k - i));
     r.v[k - NL] = (u32)acc & MASK29;
     acc >>= 29;
   }
   r.v[NL - 1] = (u32)acc;
   return r;
 }
+
+// value-preserving (mod r) weak reduction of an N-form value: result < r + 2^233.
+// q = floor(top limb / (floor(r / 2^232) + 1)) never exceeds floor(x / r).
+BJJ_HD Fr fr_reduce_weak(const Fr& x) {
+  const u32 q = x.v[8] / 3171407u;  // floor(r / 2^232) = 0x30644e = 3171406
+  Fr r;
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    c += (int64_t)x.v[i] - (int64_t)((u64)q * fr_modlimb(i));
+    r.v[i] = (i < NL - 1) ? ((u32)c & MASK29) : (u32)c;
+    c >>= 29;
+  }
+  return r;
+}
+BJJ_HD Fr fr_reduce4(const Fr& x) { return fr_reduce_weak(x); }
 
 // ---- constants in Montgomery form (R = 2^261) ----------------------------
 BJJ_HD Fr fr_one() {  // 2^261 mod r

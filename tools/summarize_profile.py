@@ -15,7 +15,7 @@ stats = os.path.join(src, "trace_%s" % wl, "trace_kernel_stats.csv")
 out += ["## kernel stats (`--kernel-trace --stats`)", "", "```"] + open(stats).read().strip().splitlines() + ["```", ""]
 avg_ns = None
 for r in csv.DictReader(open(stats)):
-    if r["Name"].startswith(KERNEL):
+    if r["Name"].startswith(KERNEL + "("):
         avg_ns = float(r["AverageNs"])
 counters = {}
 meta = {}
@@ -25,7 +25,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
-        if r["Kernel_Name"].startswith(KERNEL):
+        if r["Kernel_Name"].startswith(KERNEL + "("):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
                                       "Accum_VGPR_Count", "SGPR_Count")}
