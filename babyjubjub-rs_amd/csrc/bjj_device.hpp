@@ -98,6 +98,30 @@ BJJ_HD Ext fixed_base_accumulate(Ext acc, const u32* table, int W, int nwin, con
   return acc;
 }
 
+// n * B8 from scratch: window 0's entry is lifted directly to extended coordinates
+// (X:Y:Z:T) = (2x' : 2y : 2 : 2x'y), T recovered from the stored 2D'x'y with one
+// multiplication by 1/D', instead of a 7M addition to the identity.
+BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 sc[8], const Consts& K) {
+  Niels n0 = load_niels(table + (size_t)scalar_window(sc, 0, W) * NIELS_WORDS);
+  Niels cur = n0;
+  if (nwin > 1) cur = load_niels(table + ((((size_t)1) << W) | scalar_window(sc, 1, W)) * NIELS_WORDS);
+  Ext acc;
+  acc.X = fr_reduce_weak(fr_sub(n0.ypx, n0.ymx));  // ext_madd wants coordinates < 2r
+  acc.Y = fr_add(n0.ypx, n0.ymx);
+  acc.Z = fr_add(fr_one(), fr_one()); acc.T = fr_mul(n0.t2d, K.DPINV);
+#pragma unroll 1
+  for (int j = 1; j < nwin; j++) {
+    Niels nxt = cur;
+    if (j + 1 < nwin) {
+      size_t idx = ((size_t)(j + 1) << W) | scalar_window(sc, j + 1, W);
+      nxt = load_niels(table + idx * NIELS_WORDS);
+    }
+    acc = ext_madd(acc, cur);
+    cur = nxt;
+  }
+  return acc;
+}
+
 // =============================================================================
 // variable base, on-curve fast path:  n * P  (n < 2^254 already reduced mod 8l)
 // signed 4-bit windows, per-lane table tbl[0..8] = {0, P, .., 8P} in thread-private

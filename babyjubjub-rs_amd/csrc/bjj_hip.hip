@@ -27,9 +27,12 @@ using namespace bjj;
 
 #define BJJ_VERSION_STRING "bjj-hip 0.1.0 gfx950"
 #define BJJ_BLOCK 256
+// Workgroup size of the kernels that end in the shared-inversion epilogue: one Fermat
+// inversion (381 multiplications on one wave) is amortised over the whole workgroup.
+#define BJJ_EPI_BLOCK 512
 
 __constant__ Consts c_K = {
-    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_B8X, BJJ_K_B8Y,
+    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y,
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
     BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M};
 
@@ -40,19 +43,19 @@ __constant__ Consts c_K = {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void lds_put(u32* lds, int t, const Fr& f) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) lds[i * BJJ_BLOCK + t] = f.v[i];  // limb-major: conflict-free
+  for (int i = 0; i < NL; i++) lds[i * BJJ_EPI_BLOCK + t] = f.v[i];  // limb-major: conflict-free
 }
 __device__ __forceinline__ Fr lds_get(const u32* lds, int t) {
   Fr f;
 #pragma unroll
-  for (int i = 0; i < NL; i++) f.v[i] = lds[i * BJJ_BLOCK + t];
+  for (int i = 0; i < NL; i++) f.v[i] = lds[i * BJJ_EPI_BLOCK + t];
   return f;
 }
-__device__ Fr block_invert(const Fr& x, u32* lds /* NL * BJJ_BLOCK words */) {
+__device__ Fr block_invert(const Fr& x, u32* lds /* NL * BJJ_EPI_BLOCK words */) {
   const int t = threadIdx.x;
   Fr pre = x, suf = x;
 #pragma unroll 1
-  for (int d = 1; d < BJJ_BLOCK; d <<= 1) {  // inclusive prefix products
+  for (int d = 1; d < BJJ_EPI_BLOCK; d <<= 1) {  // inclusive prefix products
     lds_put(lds, t, pre);
     __syncthreads();
     Fr y = (t >= d) ? lds_get(lds, t - d) : fr_one();
@@ -60,10 +63,10 @@ __device__ Fr block_invert(const Fr& x, u32* lds /* NL * BJJ_BLOCK words */) {
     pre = fr_mul(pre, y);
   }
 #pragma unroll 1
-  for (int d = 1; d < BJJ_BLOCK; d <<= 1) {  // inclusive suffix products
+  for (int d = 1; d < BJJ_EPI_BLOCK; d <<= 1) {  // inclusive suffix products
     lds_put(lds, t, suf);
     __syncthreads();
-    Fr y = (t + d < BJJ_BLOCK) ? lds_get(lds, t + d) : fr_one();
+    Fr y = (t + d < BJJ_EPI_BLOCK) ? lds_get(lds, t + d) : fr_one();
     __syncthreads();
     suf = fr_mul(suf, y);
   }
@@ -71,14 +74,18 @@ __device__ Fr block_invert(const Fr& x, u32* lds /* NL * BJJ_BLOCK words */) {
   lds_put(lds, t, pre);
   __syncthreads();
   Fr epre = (t > 0) ? lds_get(lds, t - 1) : fr_one();
-  Fr total = lds_get(lds, BJJ_BLOCK - 1);
+  Fr total = lds_get(lds, BJJ_EPI_BLOCK - 1);
   __syncthreads();
   lds_put(lds, t, suf);
   __syncthreads();
-  Fr esuf = (t + 1 < BJJ_BLOCK) ? lds_get(lds, t + 1) : fr_one();
+  Fr esuf = (t + 1 < BJJ_EPI_BLOCK) ? lds_get(lds, t + 1) : fr_one();
   __syncthreads();
   if (t < 64) {  // one wave inverts the workgroup product
+#ifdef BJJ_EXPERIMENT_NO_INV
+    Fr inv = total;  // timing experiment only: wrong results
+#else
     Fr inv = fr_inv(total);
+#endif
     if (t == 0) lds_put(lds, 0, inv);
   }
   __syncthreads();
@@ -143,10 +150,10 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_build_fixed_table(u32* table,
 // ---------------------------------------------------------------------------
 // K1: fixed base
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
+__global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
                                                                   const uint8_t* __restrict__ scalars, size_t n,
                                                                   uint8_t* __restrict__ out, u32* __restrict__ scratch) {
-  __shared__ u32 lds[NL * BJJ_BLOCK];
+  __shared__ u32 lds[NL * BJJ_EPI_BLOCK];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   Fr run = fr_one();
@@ -154,7 +161,7 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_fixed_base(const u32* __r
   for (size_t i = tid; i < n; i += nthreads) {
     u32 sc[8];
     load_w8(scalars + i * 32, sc);
-    Ext p = fixed_base_accumulate(ext_identity(), table, W, nwin, sc);
+    Ext p = fixed_base_mul(table, W, nwin, sc, c_K);
     epilogue_stash(p, run, out + i * 64, scratch + i * 16);
   }
   epilogue_run(run, n, tid, nthreads, out, scratch, lds);
@@ -164,11 +171,11 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_fixed_base(const u32* __r
 // K2: variable base.  Off-curve points are appended to `slow` (slow[0] = count, item indices from
 // slow[8]) and finished by K6 (bjj_k_mul_var_base_exact) right after this kernel.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
+__global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
                                                                 const uint8_t* __restrict__ scalars, size_t n,
                                                                 uint8_t* __restrict__ out, u32* __restrict__ scratch,
                                                                 u32* __restrict__ vb_tables, u32* __restrict__ slow) {
-  __shared__ u32 lds[NL * BJJ_BLOCK];
+  __shared__ u32 lds[NL * BJJ_EPI_BLOCK];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
@@ -325,6 +332,9 @@ struct bjj_ctx {
   int device = 0;
   int cus = 0;
   int W = 16, nwin = 16;
+  // resident workgroups per CU of each kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor):
+  // grids are sized to exactly one resident wave of workgroups, items are grid-strided
+  int occ_fixed = 1, occ_var = 1, occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
   hipStream_t stream = nullptr;
   u32* table = nullptr;
   size_t table_bytes = 0;
@@ -339,17 +349,18 @@ struct bjj_ctx {
   size_t stage_bytes = 0;
 };
 
-static int grid_for(const bjj_ctx* c, size_t n, int blocks_per_cu) {
-  size_t want = (n + BJJ_BLOCK - 1) / BJJ_BLOCK;
+static int grid_for(const bjj_ctx* c, size_t n, int blocks_per_cu, int block = BJJ_BLOCK) {
+  size_t want = (n + block - 1) / block;
   size_t cap = (size_t)c->cus * blocks_per_cu;
   if (want < 1) want = 1;
   return (int)(want < cap ? want : cap);
 }
-// resident-lane budgets (blocks of 256 per CU); see DESIGN.md "launch geometry"
-#define BPC_FIXED 4
-#define BPC_VAR 2
-#define BPC_POSEIDON 2
-#define BPC_VERIFY 2
+template <typename K>
+static int occupancy_of(K kernel, int block) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) nb = 1;
+  return nb;
+}
 
 static int ensure_scratch(bjj_ctx* c, size_t n) {
   HIPCK(hipSetDevice(c->device));
@@ -363,7 +374,8 @@ static int ensure_scratch(bjj_ctx* c, size_t n) {
     HIPCK(hipMalloc((void**)&c->slow, (n + 16) * sizeof(u32)));
     c->slow_items = n;
   }
-  size_t threads = (size_t)c->cus * BPC_VAR * BJJ_BLOCK;
+  size_t tv = (size_t)c->occ_var * BJJ_EPI_BLOCK, te = (size_t)c->occ_verify * BJJ_BLOCK;
+  size_t threads = (size_t)c->cus * (tv > te ? tv : te);
   if (threads > c->vb_threads) {
     if (c->vb_tables) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->vb_tables)); c->vb_tables = nullptr; }
     HIPCK(hipMalloc((void**)&c->vb_tables, threads * VB_TABLE_WORDS * sizeof(u32)));
@@ -406,6 +418,12 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->cus = prop.multiProcessorCount;
   c->W = W;
   c->nwin = (256 + W - 1) / W;
+  c->occ_fixed = occupancy_of(bjj_k_mul_fixed_base, BJJ_EPI_BLOCK);
+  c->occ_var = occupancy_of(bjj_k_mul_var_base, BJJ_EPI_BLOCK);
+  c->occ_poseidon = occupancy_of(bjj_k_poseidon5, BJJ_BLOCK);
+  c->occ_verify = occupancy_of(bjj_k_eddsa_verify, BJJ_BLOCK);
+  c->occ_scan = occupancy_of(bjj_k_eddsa_verify_scan, BJJ_BLOCK);
+  c->occ_add = occupancy_of(bjj_k_point_add, BJJ_BLOCK);
   hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (se != hipSuccess) { delete c; return set_err(BJJ_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
   size_t entries = (size_t)c->nwin << W;
@@ -474,7 +492,7 @@ int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_
   CHECK_PTR(d_scalars, "bjj_mul_fixed_base_dev"); CHECK_PTR(d_out, "bjj_mul_fixed_base_dev");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  hipLaunchKernelGGL(bjj_k_mul_fixed_base, dim3(grid_for(c, n, BPC_FIXED)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
+  hipLaunchKernelGGL(bjj_k_mul_fixed_base, dim3(grid_for(c, n, c->occ_fixed, BJJ_EPI_BLOCK)), dim3(BJJ_EPI_BLOCK), 0, st, c->table, c->W,
                      c->nwin, (const uint8_t*)d_scalars, n, (uint8_t*)d_out, c->scratch);
   HIPCK(hipGetLastError());
   return BJJ_OK;
@@ -486,7 +504,7 @@ int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, s
   int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   HIPCK(hipMemsetAsync(c->slow, 0, 8 * sizeof(u32), st));
-  hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid_for(c, n, BPC_VAR)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pts,
+  hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid_for(c, n, c->occ_var, BJJ_EPI_BLOCK)), dim3(BJJ_EPI_BLOCK), 0, st, (const uint8_t*)d_pts,
                      (const uint8_t*)d_scalars, n, (uint8_t*)d_out, c->scratch, c->vb_tables, c->slow);
   HIPCK(hipGetLastError());
   hipLaunchKernelGGL(bjj_k_mul_var_base_exact, dim3(c->cus * 4), dim3(64), 0, st, (const uint8_t*)d_pts,
@@ -499,7 +517,7 @@ int bjj_poseidon5_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out, void*
   if (n == 0) return BJJ_OK;
   CHECK_PTR(d_in, "bjj_poseidon5_dev"); CHECK_PTR(d_out, "bjj_poseidon5_dev");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  hipLaunchKernelGGL(bjj_k_poseidon5, dim3(grid_for(c, n, BPC_POSEIDON)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_in, n,
+  hipLaunchKernelGGL(bjj_k_poseidon5, dim3(grid_for(c, n, c->occ_poseidon)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_in, n,
                      (uint8_t*)d_out);
   HIPCK(hipGetLastError());
   return BJJ_OK;
@@ -515,10 +533,10 @@ int bjj_eddsa_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const vo
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (n >> 32) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_dev: batches are limited to 2^32 - 1 items");
   HIPCK(hipMemsetAsync(c->slow, 0, WL_HDR * sizeof(u32), st));
-  hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_for(c, n, 8)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pk,
+  hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_for(c, n, c->occ_scan)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pk,
                      (const uint8_t*)d_r, (const uint8_t*)d_msg, n, c->slow);
   HIPCK(hipGetLastError());
-  hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid_for(c, n, BPC_VERIFY)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
+  hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid_for(c, n, c->occ_verify)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
                      c->nwin, (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n,
                      (uint8_t*)d_ok, c->vb_tables, c->slow);
   HIPCK(hipGetLastError());
@@ -529,7 +547,7 @@ int bjj_point_add_dev(bjj_ctx* c, const void* d_p, const void* d_q, size_t n, vo
   if (n == 0) return BJJ_OK;
   CHECK_PTR(d_p, "bjj_point_add_dev"); CHECK_PTR(d_q, "bjj_point_add_dev"); CHECK_PTR(d_out, "bjj_point_add_dev");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  hipLaunchKernelGGL(bjj_k_point_add, dim3(grid_for(c, n, 2)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_p,
+  hipLaunchKernelGGL(bjj_k_point_add, dim3(grid_for(c, n, c->occ_add)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_p,
                      (const uint8_t*)d_q, n, (uint8_t*)d_out);
   HIPCK(hipGetLastError());
   return BJJ_OK;

@@ -25,7 +25,7 @@ struct Consts {
   Fr A, D;          // reference curve constants, Montgomery
   Fr F;             // sqrt(-A), Montgomery
   Fr FINV_PLAIN;    // 1/F, canonical (so that mont_mul(x_mont, FINV_PLAIN) is canonical x/F)
-  Fr DP, D2P;       // D', 2D' Montgomery
+  Fr DP, D2P, DPINV;  // D', 2D', 1/D' Montgomery
   Fr B8X, B8Y;      // generator, Montgomery (reference curve)
   Fr ORDER, ORDER2, ORDER4;  // plain integers 8l, 16l, 32l in 29-bit limbs
   Fr L, L2, L4;              // plain integers l, 2l, 4l
@@ -47,24 +47,35 @@ BJJ_HD Ext ext_identity() {
 }
 BJJ_HD Niels niels_identity() { Niels n; n.ymx = fr_one(); n.ypx = fr_one(); n.t2d = fr_zero(); return n; }
 
-// P + Q, Q affine-precomputed.  Inputs: P coords < 2r; Q coords < 2r.  7M.
+// Limb discipline inside the formulas below: products of fr_mul/fr_sqr are N-form
+// (limbs < 2^29); sums/differences that feed exactly one multiplication stay carry-less
+// ("lazy", limbs < 2^30 for a sum, < 1.5*2^30 for a difference) and only the one operand per
+// formula that would break the 64-bit column bound is carried.  Value bounds in comments.
+
+// P + Q, Q affine-precomputed (entries N-form, < 2r).  P coords N-form < 2r.  7M.
 BJJ_HD Ext ext_madd(const Ext& p, const Niels& q) {
-  Fr a = fr_mul(fr_sub(p.Y, p.X), q.ymx);
-  Fr b = fr_mul(fr_add(p.Y, p.X), q.ypx);
+  Fr a = fr_mul(fr_sub_lazy(p.Y, p.X), q.ymx);   // (Y-X) < 6r
+  Fr b = fr_mul(fr_add_lazy(p.Y, p.X), q.ypx);   // (Y+X) < 4r
   Fr c = fr_mul(p.T, q.t2d);
-  Fr d = fr_dbl(p.Z);
-  Fr e = fr_sub(b, a), f = fr_sub(d, c), g = fr_add(d, c), h = fr_add(b, a);
+  Fr d = fr_add_lazy(p.Z, p.Z);                  // 2Z < 4r, limbs < 2^30
+  Fr e = fr_sub_lazy(b, a);                      // < 6r,  limbs < 1.5*2^30
+  Fr f = fr_sub(d, c);                           // < 8r,  carried
+  Fr g = fr_add_lazy(d, c);                      // < 6r,  limbs < 1.5*2^30
+  Fr h = fr_add_lazy(b, a);                      // < 4r,  limbs < 2^30
   Ext r;
   r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.T = fr_mul(e, h); r.Z = fr_mul(f, g);
   return r;
 }
-// P + Q, Q projective-precomputed.  8M.
+// P + Q, Q projective-precomputed (entries carried).  8M.
 BJJ_HD Ext ext_add_pn(const Ext& p, const PNiels& q) {
-  Fr a = fr_mul(fr_sub(p.Y, p.X), q.ymx);
-  Fr b = fr_mul(fr_add(p.Y, p.X), q.ypx);
+  Fr a = fr_mul(fr_sub_lazy(p.Y, p.X), q.ymx);
+  Fr b = fr_mul(fr_add_lazy(p.Y, p.X), q.ypx);
   Fr c = fr_mul(p.T, q.t2d);
   Fr d = fr_mul(p.Z, q.z2);
-  Fr e = fr_sub(b, a), f = fr_sub(d, c), g = fr_add(d, c), h = fr_add(b, a);
+  Fr e = fr_sub_lazy(b, a);                      // limbs < 1.5*2^30
+  Fr f = fr_sub(d, c);                           // carried
+  Fr g = fr_add_lazy(d, c);                      // limbs < 2^30
+  Fr h = fr_add_lazy(b, a);                      // limbs < 2^30
   Ext r;
   r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.T = fr_mul(e, h); r.Z = fr_mul(f, g);
   return r;
@@ -73,13 +84,12 @@ BJJ_HD Ext ext_add_pn(const Ext& p, const PNiels& q) {
 // projective point, so that only subtractions of small operands are needed).
 template <bool NEED_T>
 BJJ_HD Ext ext_dbl(const Ext& p) {
-  Fr a = fr_sqr(p.X), b = fr_sqr(p.Y);
-  Fr c = fr_dbl(fr_sqr(p.Z));              // < 4r
-  Fr h = fr_add(a, b);                     // H' = A + B          < 4r
-  Fr s = fr_sqr(fr_add(p.X, p.Y));
-  Fr e = fr_sub8(s, h);                    // E = (X+Y)^2 - A - B < 10r
-  Fr g = fr_sub(b, a);                     // G = B - A           < 6r
-  Fr f = fr_sub8(c, g);                    // F' = C - G          < 12r
+  Fr a = fr_sqr(p.X), b = fr_sqr(p.Y), zz = fr_sqr(p.Z);
+  Fr h = fr_add_lazy(a, b);                      // H' = A + B           < 4r, limbs < 2^30
+  Fr s = fr_sqr(fr_add_lazy(p.X, p.Y));
+  Fr e = fr_sub8_of_lazy(s, h);                  // E = (X+Y)^2 - A - B  < 10r, carried
+  Fr g = fr_sub_lazy(b, a);                      // G = B - A            < 6r, limbs < 1.5*2^30
+  Fr f = fr_sub(fr_add_lazy(fr_add_lazy(zz, zz), a), b);  // F' = 2Z^2 - G = 2Z^2 + A - B  < 10r, carried
   Ext r;
   r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.Z = fr_mul(f, g);
   if (NEED_T) r.T = fr_mul(e, h); else r.T = fr_zero();

@@ -118,6 +118,37 @@ BJJ_HD Fr fr_sub8(const Fr& a, const Fr& b) {
   fr_carry(r);
   return r;
 }
+// ---- carry-less ("lazy") forms: limbs may exceed 29 bits; only legal where the consumer's
+// column bound holds (fr_mul: sum_k a_i*b_{k-i} + 9*2^58 + 2^36 < 2^64; checked in the debug
+// harness).  Typical use: one operand of a multiplication.
+BJJ_HD Fr fr_add_lazy(const Fr& a, const Fr& b) {  // limbs: a_i + b_i
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+BJJ_HD Fr fr_sub_lazy(const Fr& a, const Fr& b) {  // a + 4r - b, b N-form < 4r; limbs < a_i + 2^30
+  Fr r;
+  BJJ_ASSERT(b.v[8] <= fr_c4limb(8));
+#pragma unroll
+  for (int i = 0; i < NL; i++) { BJJ_ASSERT(b.v[i] <= fr_c4limb(i)); r.v[i] = a.v[i] + fr_c4limb(i) - b.v[i]; }
+  return r;
+}
+// 8r with limbs >= 2^30 - 2 (i < 8), so that a lazy (limbs < 2^30) subtrahend never underflows
+BJJ_HD u32 fr_k8limb(int i) {
+  constexpr u32 C[NL] = {0x8u + 0x40000000u, 0x187d64fcu + 0x3ffffffeu, 0x12e12287u + 0x3ffffffeu,
+                         0x1e84879bu + 0x3ffffffeu, 0x0c2e9419u + 0x3ffffffeu, 0x16da0605u + 0x3ffffffeu,
+                         0x05370a08u + 0x3ffffffeu, 0x12e131a0u + 0x3ffffffeu, 0x01832273u - 2u};
+  return C[i];
+}
+// a + 8r - b with b lazy (limbs <= 2^30 - 2, value < 8r - 2^233); result N-form
+BJJ_HD Fr fr_sub8_of_lazy(const Fr& a, const Fr& b) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) { BJJ_ASSERT(b.v[i] <= fr_k8limb(i)); r.v[i] = a.v[i] + fr_k8limb(i) - b.v[i]; }
+  fr_carry(r);
+  return r;
+}
 BJJ_HD Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
 BJJ_HD Fr fr_dbl(const Fr& a) { return fr_add(a, a); }
 
@@ -130,10 +161,16 @@ BJJ_HD Fr fr_select(bool c, const Fr& a, const Fr& b) {  // c ? a : b
 
 #if defined(BJJ_DEBUG_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
 inline void fr_check_mul_operands(const Fr& a, const Fr& b) {
-  for (int i = 0; i < NL; i++) { assert(a.v[i] < (1u << 30)); assert(b.v[i] < (1u << 30)); }
+  // every 64-bit column accumulator must hold: sum_i a_i*b_{k-i} + 9 reduction products + carry-in
+  for (int k = 0; k < 2 * NL - 1; k++) {
+    unsigned __int128 col = 0;
+    for (int i = 0; i < NL; i++) { int j = k - i; if (j >= 0 && j < NL) col += (unsigned __int128)a.v[i] * b.v[j]; }
+    col += (unsigned __int128)9 * 0x1fffffffULL * 0x1fffffffULL + ((unsigned __int128)1 << 36);
+    assert((col >> 64) == 0);
+  }
   // value(a)*value(b) < r * 2^261, compared in units of 2^406 using the top two limbs (+1 for the tail)
-  unsigned __int128 ah = (((unsigned __int128)a.v[8] << 29) | a.v[7]) + 1;
-  unsigned __int128 bh = (((unsigned __int128)b.v[8] << 29) | b.v[7]) + 1;
+  unsigned __int128 ah = (((unsigned __int128)a.v[8] << 29) + a.v[7]) + 1;
+  unsigned __int128 bh = (((unsigned __int128)b.v[8] << 29) + b.v[7]) + 1;
   // r * 2^261 / 2^406 = r / 2^145 = (r >> 144) >> 1
   const unsigned __int128 lim = (((unsigned __int128)0x30644e72e131ULL << 64) | 0xa029b85045b68181ULL) >> 1;
   assert(ah * bh <= lim);
@@ -311,9 +348,9 @@ BJJ_HD void fr_from_mont_words(const Fr& a, u32 w[8]) {
   fr_to_words(t, w);
 }
 
-// a^(r-2): Fermat inversion, plain left-to-right square-and-multiply (uniform
-// control flow: the exponent is a compile-time constant).  0 -> 0.
-BJJ_HD_NOINLINE Fr fr_inv(const Fr& a) {
+// a^(r-2): Fermat inversion, plain left-to-right square-and-multiply.  0 -> 0.
+// Kept as the independent cross-check of fr_inv_gcd (tests/emul); the kernels use fr_inv.
+BJJ_HD_NOINLINE Fr fr_inv_fermat(const Fr& a) {
   // r - 2, 32-bit words, little-endian
   const u32 E[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
   Fr x = a;  // top bit (bit 253) is set
@@ -323,5 +360,111 @@ BJJ_HD_NOINLINE Fr fr_inv(const Fr& a) {
   }
   return x;
 }
+
+// ---------------------------------------------------------------------------------------
+// Low-latency inversion: binary GCD with 29-bit "jumps" (after T. Pornin, "Optimized Binary
+// GCD for Modular Inversion", 2020, with k - 1 = 29 inner steps per round so that the exact
+// division by 2^29 is a limb shift in this representation).  18 rounds x 29 steps >= 2*254 - 1.
+// Invariants: a == u*y/K, b == v*y/K (mod r) with K = 2^522 (= R^2); at the end b == 1, so
+// v == R^2 / y, which for y = x*R is exactly the Montgomery form of 1/x.  0 -> 0.
+// ~10^4 plain instructions instead of a chain of 381 dependent Montgomery multiplications:
+// the point is LATENCY -- the workgroup-wide inversion of the affine epilogue is a serial
+// section during which the other waves of the workgroup wait.
+// ---------------------------------------------------------------------------------------
+BJJ_HD_NOINLINE Fr fr_inv_gcd(const Fr& x) {
+  constexpr u32 R4[NL] = {0x4u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
+  constexpr u32 R2c[NL] = {0x2u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u, 0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
+  constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
+  Fr a = fr_canon(x);  // y, in [0, r)
+  Fr b, u = fr_r2(), v = fr_zero();
+#pragma unroll
+  for (int i = 0; i < NL; i++) b.v[i] = fr_modlimb(i);
+#pragma unroll 1
+  for (int outer = 0; outer < 18; outer++) {
+    // ---- 60-bit approximations (k = 30): the low k-1 = 29 bits (exact: one limb) and the top
+    //      k+1 = 31 bits of the longer of (a, b); exact values once both fit in 60 bits.
+    u32 ah = 0, al = 0, all_ = 0, bh = 0, bl = 0, bll = 0;
+    int top = 0;  // index of the highest limb in which a | b is non-zero (>= 2), 0 if none
+#pragma unroll
+    for (int i = NL - 1; i >= 2; i--) {
+      const bool hit = (top == 0) && ((a.v[i] | b.v[i]) != 0);
+      ah = hit ? a.v[i] : ah; al = hit ? a.v[i - 1] : al; all_ = hit ? a.v[i - 2] : all_;
+      bh = hit ? b.v[i] : bh; bl = hit ? b.v[i - 1] : bl; bll = hit ? b.v[i - 2] : bll;
+      top = hit ? i : top;
+    }
+    const int L = (top == 0) ? 0 : 32 - __builtin_clz(ah | bh);  // significant bits of the top limb
+    u64 xa, xb;
+    if (29 * top + L > 60) {
+      const u64 ha = ((u64)ah << 29) | al, hb = ((u64)bh << 29) | bl;  // L + 29 significant bits
+      const u64 ta = (L >= 2) ? (ha >> (L >= 2 ? L - 2 : 0)) : ((ha << 1) | (all_ >> 28));
+      const u64 tb = (L >= 2) ? (hb >> (L >= 2 ? L - 2 : 0)) : ((hb << 1) | (bll >> 28));
+      xa = (ta << 29) | a.v[0];
+      xb = (tb << 29) | b.v[0];
+    } else {  // both below 2^60: exact
+      xa = ((u64)a.v[2] << 58) | ((u64)a.v[1] << 29) | a.v[0];
+      xb = ((u64)b.v[2] << 58) | ((u64)b.v[1] << 29) | b.v[0];
+    }
+    // ---- 29 binary-GCD steps on the approximations, recording the transition matrix
+    int64_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+#pragma unroll 1
+    for (int i = 0; i < 29; i++) {
+      const bool odd = (xa & 1) != 0;
+      const bool swp = odd && (xa < xb);
+      const u64 ta = swp ? xb : xa, tb = swp ? xa : xb;
+      const int64_t tf0 = swp ? f1 : f0, tf1 = swp ? f0 : f1, tg0 = swp ? g1 : g0, tg1 = swp ? g0 : g1;
+      xa = (odd ? ta - tb : ta) >> 1; xb = tb;
+      f0 = odd ? tf0 - tf1 : tf0; g0 = odd ? tg0 - tg1 : tg0;
+      f1 = tf1 << 1; g1 = tg1 << 1;
+    }
+    // ---- (a, b) <- (a f0 + b g0, a f1 + b g1) / 2^29   (exact), then make both non-negative
+    Fr na, nb;
+    int64_t ca = 0, cb = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      ca += (int64_t)a.v[i] * f0 + (int64_t)b.v[i] * g0;
+      cb += (int64_t)a.v[i] * f1 + (int64_t)b.v[i] * g1;
+      if (i > 0) { na.v[i - 1] = (u32)ca & MASK29; nb.v[i - 1] = (u32)cb & MASK29; }
+      ca >>= 29; cb >>= 29;
+    }
+    na.v[NL - 1] = (u32)ca & MASK29; nb.v[NL - 1] = (u32)cb & MASK29;
+    const bool nega = ca < 0, negb = cb < 0;
+    {  // conditional negation (two's complement over the 9 x 29-bit limbs)
+      u32 c1 = 1, c2 = 1;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const u32 ia = (~na.v[i] & MASK29) + c1, ib = (~nb.v[i] & MASK29) + c2;
+        c1 = ia >> 29; c2 = ib >> 29;
+        a.v[i] = nega ? (ia & MASK29) : na.v[i];
+        b.v[i] = negb ? (ib & MASK29) : nb.v[i];
+      }
+    }
+    if (nega) { f0 = -f0; g0 = -g0; }
+    if (negb) { f1 = -f1; g1 = -g1; }
+    // ---- (u, v) <- (u f0 + v g0, u f1 + v g1) / 2^29 mod r, back into [0, r)
+    const u32 lu = (u32)((int64_t)u.v[0] * f0 + (int64_t)v.v[0] * g0) & MASK29;
+    const u32 lv = (u32)((int64_t)u.v[0] * f1 + (int64_t)v.v[0] * g1) & MASK29;
+    const u32 qu = (lu * BJJ_NINV29) & MASK29, qv = (lv * BJJ_NINV29) & MASK29;
+    Fr nu, nv;
+    int64_t cu = 0, cv = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      cu += (int64_t)u.v[i] * f0 + (int64_t)v.v[i] * g0 + (int64_t)((u64)qu * fr_modlimb(i));
+      cv += (int64_t)u.v[i] * f1 + (int64_t)v.v[i] * g1 + (int64_t)((u64)qv * fr_modlimb(i));
+      if (i > 0) {  // + 2r (limb i-1 of 2r) keeps the running value non-negative: result in (0, 5r)
+        cu += R2c[i - 1]; cv += R2c[i - 1];
+        nu.v[i - 1] = (u32)cu & MASK29; nv.v[i - 1] = (u32)cv & MASK29;
+      }
+      cu >>= 29; cv >>= 29;
+    }
+    cu += R2c[NL - 1]; cv += R2c[NL - 1];
+    nu.v[NL - 1] = (u32)cu; nv.v[NL - 1] = (u32)cv;
+    nu = fr_cond_sub_kr(nu, R4); nu = fr_cond_sub_kr(nu, R2c); u = fr_cond_sub_kr(nu, R1);
+    nv = fr_cond_sub_kr(nv, R4); nv = fr_cond_sub_kr(nv, R2c); v = fr_cond_sub_kr(nv, R1);
+  }
+  return v;
+}
+
+// 1/x in Montgomery form (0 -> 0): the low-latency binary-GCD inversion.
+BJJ_HD Fr fr_inv(const Fr& x) { return fr_inv_gcd(x); }
 
 }  // namespace bjj

@@ -232,6 +232,7 @@ def main():
     o.append("#define BJJ_K_FINV_PLAIN %s  // 1/sqrt(-A), canonical" % limbs32(inv(f)))
     o.append("#define BJJ_K_DP       %s  // d' = -D/A" % limbs32(mont(dprime)))
     o.append("#define BJJ_K_D2P      %s  // 2 d'" % limbs32(mont(2 * dprime)))
+    o.append("#define BJJ_K_DPINV    %s  // 1/d'" % limbs32(mont(inv(dprime))))
     o.append("#define BJJ_K_B8X      %s" % limbs32(mont(B8[0])))
     o.append("#define BJJ_K_B8Y      %s" % limbs32(mont(B8[1])))
     o.append("#define BJJ_K_ORDER    %s  // PLAIN integer 8*l" % limbs32(ORDER))

@@ -10,7 +10,7 @@
 #include "../../babyjubjub-rs_amd/csrc/bjj_constants.inc"
 using namespace bjj;
 static const Consts K = {
-    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_B8X, BJJ_K_B8Y,
+    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y,
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
     BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M};
 static std::vector<u32> g_table; static int g_W = 0, g_nwin = 0;
@@ -35,7 +35,7 @@ extern "C" {
 void emul_fixed_base(const uint8_t* scalar, int W, uint8_t* out) {
   ensure_table(W);
   alignas(16) u32 sc[8]; memcpy(sc, scalar, 32);
-  ext_out(fixed_base_accumulate(ext_identity(), table_ptr(), g_W, g_nwin, sc), out);
+  ext_out(fixed_base_mul(table_ptr(), g_W, g_nwin, sc, K), out);
 }
 void emul_var_base(const uint8_t* pt, const uint8_t* scalar, uint8_t* out) {
   alignas(16) u32 w[8], sc[8]; alignas(16) static u32 tbl[VB_TABLE_WORDS];
