@@ -114,6 +114,9 @@ BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 sc[8], co
     Niels nxt = cur;
     if (j + 1 < nwin) {
       size_t idx = ((size_t)(j + 1) << W) | scalar_window(sc, j + 1, W);
+#if defined(BJJ_EXPERIMENT) && BJJ_EXPERIMENT == 3  /* timing experiment: every lane hits the same few lines */
+      idx = ((size_t)(j + 1) << W) | (scalar_window(sc, j + 1, W) & 1);
+#endif
       nxt = load_niels(table + idx * NIELS_WORDS);
     }
     acc = ext_madd(acc, cur);
