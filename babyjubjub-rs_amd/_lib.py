@@ -21,6 +21,8 @@ EXPORTED_SYMBOLS = (
     "bjj_mul_fixed_base", "bjj_mul_var_base", "bjj_poseidon5", "bjj_eddsa_verify", "bjj_point_add",
     "bjj_mul_fixed_base_dev", "bjj_mul_var_base_dev", "bjj_poseidon5_dev", "bjj_eddsa_verify_dev",
     "bjj_point_add_dev", "bjj_reserve", "bjj_get_info",
+    "bjj_compress_points", "bjj_decompress_points", "bjj_eddsa_verify_compressed",
+    "bjj_compress_points_dev", "bjj_decompress_points_dev", "bjj_eddsa_verify_compressed_dev",
 )
 
 
@@ -75,4 +77,10 @@ def load():
     lib.bjj_poseidon5_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.bjj_eddsa_verify_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp]
     lib.bjj_point_add_dev.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.bjj_compress_points.argtypes = [vp, vp, sz, vp]
+    lib.bjj_decompress_points.argtypes = [vp, vp, sz, vp, vp]
+    lib.bjj_eddsa_verify_compressed.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.bjj_compress_points_dev.argtypes = [vp, vp, sz, vp, vp]
+    lib.bjj_decompress_points_dev.argtypes = [vp, vp, sz, vp, vp, vp]
+    lib.bjj_eddsa_verify_compressed_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     return lib

@@ -147,6 +147,36 @@ class Context:
         self._ck(self.lib.bjj_point_add(self.handle, a.ctypes.data, b.ctypes.data, n, out.ctypes.data), "bjj_point_add")
         return out.reshape(n, 64)
 
+    def compress_points(self, points):
+        a = _as_u8(points, 64, "points")
+        n = a.size // 64
+        out = np.empty(n * 32, dtype=np.uint8)
+        self._ck(self.lib.bjj_compress_points(self.handle, a.ctypes.data, n, out.ctypes.data), "bjj_compress_points")
+        return out.reshape(n, 32)
+
+    def decompress_points(self, comp):
+        """-> (points (n, 64), ok (n,)): ok == 0 where the reference's decompress_point returns Err"""
+        a = _as_u8(comp, 32, "compressed points")
+        n = a.size // 32
+        out = np.empty(n * 64, dtype=np.uint8)
+        ok = np.empty(n, dtype=np.uint8)
+        self._ck(self.lib.bjj_decompress_points(self.handle, a.ctypes.data, n, out.ctypes.data, ok.ctypes.data),
+                 "bjj_decompress_points")
+        return out.reshape(n, 64), ok
+
+    def eddsa_verify_compressed(self, pk, sig, msg):
+        """pk (n, 32), sig (n, 64) = compressed R then s, msg (n, 32) -> 1 / 0 / 2 (decompression Err)"""
+        a = _as_u8(pk, 32, "pk")
+        g = _as_u8(sig, 64, "sig")
+        m = _as_u8(msg, 32, "msg")
+        n = a.size // 32
+        if g.size != n * 64 or m.size != n * 32:
+            raise BjjError("eddsa_verify_compressed: array lengths disagree")
+        ok = np.empty(n, dtype=np.uint8)
+        self._ck(self.lib.bjj_eddsa_verify_compressed(self.handle, a.ctypes.data, g.ctypes.data, m.ctypes.data, n,
+                                                      ok.ctypes.data), "bjj_eddsa_verify_compressed")
+        return ok
+
     # ---- device-pointer calls (integers: device addresses / hipStream_t) ----
     def mul_fixed_base_dev(self, d_scalars, n, d_out, stream=0):
         self._ck(self.lib.bjj_mul_fixed_base_dev(self.handle, d_scalars, n, d_out, stream), "bjj_mul_fixed_base_dev")
@@ -160,6 +190,17 @@ class Context:
     def eddsa_verify_dev(self, d_pk, d_r, d_s, d_msg, n, d_ok, stream=0):
         self._ck(self.lib.bjj_eddsa_verify_dev(self.handle, d_pk, d_r, d_s, d_msg, n, d_ok, stream),
                  "bjj_eddsa_verify_dev")
+
+    def eddsa_verify_compressed_dev(self, d_pk, d_sig, d_msg, n, d_ok, stream=0):
+        self._ck(self.lib.bjj_eddsa_verify_compressed_dev(self.handle, d_pk, d_sig, d_msg, n, d_ok, stream),
+                 "bjj_eddsa_verify_compressed_dev")
+
+    def decompress_points_dev(self, d_in, n, d_out, d_ok, stream=0):
+        self._ck(self.lib.bjj_decompress_points_dev(self.handle, d_in, n, d_out, d_ok, stream),
+                 "bjj_decompress_points_dev")
+
+    def compress_points_dev(self, d_pts, n, d_out, stream=0):
+        self._ck(self.lib.bjj_compress_points_dev(self.handle, d_pts, n, d_out, stream), "bjj_compress_points_dev")
 
     def point_add_dev(self, d_p, d_q, n, d_out, stream=0):
         self._ck(self.lib.bjj_point_add_dev(self.handle, d_p, d_q, n, d_out, stream), "bjj_point_add_dev")
@@ -200,6 +241,9 @@ class Point:
             out = ctx.mul_var_base([(self.x, self.y)], [n])
         x, y = _ints(out, 2)[0]
         return Point(x, y)
+
+    def compress(self, ctx=None):  # lib.rs:166-178 -> 32 bytes
+        return bytes((ctx or default_context()).compress_points([(self.x, self.y)])[0])
 
     def equals(self, p):  # lib.rs:180-185
         return self.x == p.x and self.y == p.y
@@ -244,6 +288,24 @@ class Signature:
     def __init__(self, r_b8, s):
         self.r_b8 = r_b8
         self.s = int(s)
+
+
+def decompress_point(bb, ctx=None):
+    """decompress_point(bb: [u8; 32]) -> Result<Point, String>  (lib.rs:192-224); raises ValueError for Err"""
+    if len(bb) != 32:
+        raise BjjError("decompress_point: need exactly 32 bytes")
+    pts, ok = (ctx or default_context()).decompress_points(np.frombuffer(bytes(bb), np.uint8))
+    if not ok[0]:
+        raise ValueError("decompress_point: y outside the field or x^2 not a (non-zero) square")
+    x, y = _ints(pts, 2)[0]
+    return Point(x, y)
+
+
+def decompress_signature(b, ctx=None):
+    """decompress_signature(b: &[u8; 64]) -> Result<Signature, String>  (lib.rs:260-268)"""
+    if len(b) != 64:
+        raise BjjError("decompress_signature: need exactly 64 bytes")
+    return Signature(decompress_point(bytes(b[:32]), ctx), int.from_bytes(bytes(b[32:]), "little"))
 
 
 def verify(pk, sig, msg, ctx=None):

@@ -8,6 +8,8 @@
 //   PointProjective { x, y, z }, add(), affine()              lib.rs:62-131
 //   Signature { r_b8, s }                                     lib.rs:239-243
 //   verify(pk, sig, msg) -> bool                              lib.rs:395-412
+//   Point::compress, decompress_point, Signature::compress,
+//   decompress_signature (wire format)                        lib.rs:166-178, 192-224, 245-268
 //   + *_batch forms (what the GPU is for)
 //
 // Every arithmetic operation runs in libbjj_hip.so on the GPU; this header only marshals
@@ -95,10 +97,15 @@ struct Point {  // lib.rs:134-138
   PointProjective projective() const { return PointProjective{x, y, Fr(1)}; }  // lib.rs:141-147
   Point mul_scalar(const U256& n) const;                                       // lib.rs:149-164
   bool equals(const Point& p) const { return x == p.x && y == p.y; }           // lib.rs:180-185
+  std::array<uint8_t, 32> compress() const;                                    // lib.rs:166-178
 };
 struct Signature {  // lib.rs:239-243
   Point r_b8;
   U256 s;
+  std::array<uint8_t, 64> compress() const {  // lib.rs:245-258
+    std::array<uint8_t, 64> b{}; auto r = r_b8.compress();
+    std::memcpy(b.data(), r.data(), 32); std::memcpy(b.data() + 32, s.le.data(), 32); return b;
+  }
 };
 
 inline const Point& B8() {  // lib.rs:37-46
@@ -139,7 +146,42 @@ inline std::vector<uint8_t> verify_batch(const std::vector<Point>& pk, const std
   return ok;
 }
 
+// wire format, batch: ok[i] == 0 where decompress_point returns Err
+inline std::vector<std::array<uint8_t, 32>> compress_batch(const std::vector<Point>& p, Context& c = Context::global()) {
+  std::vector<std::array<uint8_t, 32>> out(p.size());
+  check(bjj_compress_points(c.handle(), (const uint8_t*)p.data(), p.size(), (uint8_t*)out.data()), "bjj_compress_points");
+  return out;
+}
+inline std::vector<Point> decompress_batch(const std::vector<std::array<uint8_t, 32>>& in, std::vector<uint8_t>& ok,
+                                           Context& c = Context::global()) {
+  std::vector<Point> out(in.size()); ok.assign(in.size(), 0);
+  check(bjj_decompress_points(c.handle(), (const uint8_t*)in.data(), in.size(), (uint8_t*)out.data(), ok.data()),
+        "bjj_decompress_points");
+  return out;
+}
+// 1 = valid, 0 = invalid, 2 = pk or R does not decompress (the crate returns Err there)
+inline std::vector<uint8_t> verify_compressed_batch(const std::vector<std::array<uint8_t, 32>>& pk,
+                                                    const std::vector<std::array<uint8_t, 64>>& sig,
+                                                    const std::vector<U256>& msg, Context& c = Context::global()) {
+  if (sig.size() != pk.size() || msg.size() != pk.size()) throw std::runtime_error("verify_compressed_batch: length mismatch");
+  std::vector<uint8_t> ok(pk.size());
+  check(bjj_eddsa_verify_compressed(c.handle(), (const uint8_t*)pk.data(), (const uint8_t*)sig.data(),
+                                    (const uint8_t*)msg.data(), pk.size(), ok.data()), "bjj_eddsa_verify_compressed");
+  return ok;
+}
+
 // ---- scalar (single-item) forms, same signatures as the crate ------------------------------
+inline std::array<uint8_t, 32> Point::compress() const { return compress_batch({*this})[0]; }
+// decompress_point(bb) -> Result<Point, String>: throws std::invalid_argument for Err (lib.rs:192-224)
+inline Point decompress_point(const std::array<uint8_t, 32>& bb) {
+  std::vector<uint8_t> ok; Point p = decompress_batch({bb}, ok)[0];
+  if (!ok[0]) throw std::invalid_argument("decompress_point: y outside the field or x^2 not a non-zero square");
+  return p;
+}
+inline Signature decompress_signature(const std::array<uint8_t, 64>& b) {  // lib.rs:260-268
+  std::array<uint8_t, 32> r; std::memcpy(r.data(), b.data(), 32);
+  Signature s; s.r_b8 = decompress_point(r); std::memcpy(s.s.le.data(), b.data() + 32, 32); return s;
+}
 inline Point Point::mul_scalar(const U256& n) const {
   if (equals(B8())) return mul_fixed_base_batch({n})[0];
   return mul_scalar_batch({*this}, {n})[0];

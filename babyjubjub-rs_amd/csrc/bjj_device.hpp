@@ -236,6 +236,96 @@ BJJ_HD Ext var_base_item(const Fr& x, const Fr& y, const u32 sc[8], u32* tbl, co
   return var_base_exact(x, y, sc, K);
 }
 
+// =============================================================================
+// codec row: Point::compress (src/lib.rs:166-178), decompress_point
+// (src/lib.rs:192-224 with utils.rs modinv / modsqrt).  decompress_point's result does not
+// depend on which square root Tonelli-Shanks returns (the sign rule of lib.rs:217-219 picks
+// by the sign bit), so any correct root is bit-identical to the reference.
+// =============================================================================
+// a^((s-1)/2), s = (r-1)/2^28: fixed 225-bit exponent, plain square-and-multiply
+BJJ_HD_NOINLINE Fr fr_pow_ts(const Fr& a) {
+  const u32 E[8] = {0x1f0fac9fu, 0xcdcb848au, 0x419f4243u, 0x0c0ac2e9u, 0xc2822db4u, 0x098d014du, 0x83227397u, 0x00000001u};
+  Fr x = a;  // bit 224
+#pragma unroll 1
+  for (int bit = 223; bit >= 0; bit--) {
+    x = fr_sqr(x);
+    if ((E[bit >> 5] >> (bit & 31)) & 1) x = fr_mul(x, a);
+  }
+  return x;
+}
+// Tonelli-Shanks with a data-independent schedule (no lane divergence): invariant x^2 = a*b,
+// ord(b) | 2^(v-1), ord(z) = 2^v.  Returns false for a == 0 (the reference's modsqrt errors on
+// 0, utils.rs:117-119) and for non-residues; root in Montgomery form, < 2r.
+BJJ_HD bool fr_sqrt(const Fr& a, Fr& root, const Consts& K) {
+  Fr w = fr_pow_ts(a);
+  Fr x = fr_mul(a, w);   // a^((s+1)/2)
+  Fr b = fr_mul(x, w);   // a^s
+  Fr z = K.TS_G;
+#pragma unroll 1
+  for (int v = 28; v >= 2; v--) {
+    Fr t = b;
+#pragma unroll 1
+    for (int k = 0; k < v - 2; k++) t = fr_sqr(t);
+    const bool fix = !fr_eq(t, fr_one());  // t is 1 or -1 for residues
+    Fr z2 = fr_sqr(z);
+    x = fr_select(fix, fr_mul(x, z), x);
+    b = fr_select(fix, fr_mul(b, z2), b);
+    z = z2;
+  }
+  root = x;
+  return fr_eq(fr_sqr(x), a) && !fr_is_zero(a);
+}
+// plain canonical N-form value > (r-1)/2 ?
+BJJ_HD bool plain_gt_halfq(const Fr& v, const Consts& K) {
+  u32 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) { u32 t = K.HALFQ.v[i] - v.v[i] - borrow; borrow = t >> 31; }
+  return borrow != 0;
+}
+BJJ_HD bool words_ge_modulus(const u32 w[8]) {
+  const u32 M[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  bool gt = false, eq = true;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) { gt = gt || (eq && w[i] > M[i]); eq = eq && (w[i] == M[i]); }
+  return gt || eq;
+}
+// decompress_point (src/lib.rs:192-224): 32 bytes -> canonical (x, y) words; false = Err
+BJJ_HD bool decompress_item(const u32 in[8], u32 ox[8], u32 oy[8], const Consts& K) {
+  u32 w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = in[i];
+  const bool sign = (w[7] >> 31) != 0;                       // :196-199
+  w[7] &= 0x7fffffffu;
+  bool ok = !words_ge_modulus(w);                            // :201-203
+  Fr y = fr_to_mont_words(w);
+  Fr y2 = fr_sqr(y);
+  Fr den = fr_sub(K.A, fr_mul(K.D, y2));                     // A - D y^2 (never 0: A/D is a non-residue)
+  Fr num = fr_sub(fr_one(), y2);
+  Fr x2 = fr_mul(num, fr_inv(den));                          // :207-214
+  Fr x;
+  ok = fr_sqrt(x2, x, K) && ok;                              // :215
+  constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
+  Fr xc = fr_cond_sub_kr(fr_mul(x, fr_one_plain()), R1);     // canonical integer
+  const bool gt = plain_gt_halfq(xc, K);
+  if (sign != gt) {                                          // :217-219: x <- -x
+    Fr neg;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) { u32 t = R1[i] - xc.v[i] - borrow; borrow = t >> 31; neg.v[i] = (i < NL - 1) ? (t & MASK29) : t; }
+    xc = neg;
+  }
+  fr_to_words(xc, ox);
+#pragma unroll
+  for (int i = 0; i < 8; i++) { oy[i] = ok ? w[i] : 0u; ox[i] = ok ? ox[i] : 0u; }
+  return ok;
+}
+// Point::compress (src/lib.rs:166-178): y little-endian, bit 255 = (x > (r-1)/2); inputs >= r are reduced
+BJJ_HD void compress_item(const u32 xw[8], const u32 yw[8], u32 out[8], const Consts& K) {
+  Fr x = fr_canon(fr_from_words(xw)), y = fr_canon(fr_from_words(yw));
+  fr_to_words(y, out);
+  if (plain_gt_halfq(x, K)) out[7] |= 0x80000000u;
+}
+
 // msg > Q ?   (src/lib.rs:396-398; msg == Q is accepted and wraps to 0)
 BJJ_HD bool words_gt_modulus(const u32 w[8]) {
   const u32 M[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};

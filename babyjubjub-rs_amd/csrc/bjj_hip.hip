@@ -32,7 +32,7 @@ using namespace bjj;
 #define BJJ_EPI_BLOCK 512
 
 __constant__ Consts c_K = {
-    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y,
+    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y, BJJ_K_TS_G, BJJ_K_HALFQ,
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
     BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M};
 
@@ -326,6 +326,45 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_point_add(const uint8_t* __re
   }
 }
 
+// ---------------------------------------------------------------------------
+// codec row: Point::compress, decompress_point, decompress_signature
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_compress_points(const uint8_t* __restrict__ in_xy, size_t n,
+                                                                   uint8_t* __restrict__ out) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    u32 x[8], y[8], o[8];
+    load_w8(in_xy + i * 64, x); load_w8(in_xy + i * 64 + 32, y);
+    compress_item(x, y, o, c_K);
+    store_w8(out + i * 32, o);
+  }
+}
+// in: records of `stride` bytes whose first 32 bytes are a compressed point.  When out_s is
+// given (signatures, stride 64: lib.rs:260-268) bytes 32..63 are copied there unchanged.
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_decompress_points(const uint8_t* __restrict__ in, size_t stride,
+                                                                        size_t n, uint8_t* __restrict__ out_xy,
+                                                                        uint8_t* __restrict__ ok,
+                                                                        uint8_t* __restrict__ out_s) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    u32 w[8], ox[8], oy[8];
+    load_w8(in + i * stride, w);
+    const bool good = decompress_item(w, ox, oy, c_K);
+    store_w8(out_xy + i * 64, ox); store_w8(out_xy + i * 64 + 32, oy);
+    ok[i] = good ? 1 : 0;
+    if (out_s) { load_w8(in + i * stride + 32, w); store_w8(out_s + i * 32, w); }
+  }
+}
+// verdict byte of the compressed-input verify: 2 where a point failed to decompress (the
+// reference returns Err there and never reaches verify), else verify()'s 1 / 0.
+__global__ void bjj_k_merge_codec_flags(uint8_t* __restrict__ ok, const uint8_t* __restrict__ f_pk,
+                                        const uint8_t* __restrict__ f_r, size_t n) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads)
+    if (!(f_pk[i] && f_r[i])) ok[i] = 2;
+}
+
 // ===========================================================================
 // host side: context + extern "C" boundary
 // ===========================================================================
@@ -354,6 +393,9 @@ struct bjj_ctx {
   size_t vb_threads = 0;
   u32* slow = nullptr;         // [0] = count, [1..] item indices deferred to the exact-path kernels
   size_t slow_items = 0;
+  uint8_t* codec = nullptr;    // verify_compressed: n * (64 pk + 64 R + 32 s + 2 flags) bytes
+  size_t codec_items = 0;
+  int occ_decomp = 1;
   // staging buffers for the host-pointer API
   uint8_t* stage = nullptr;
   size_t stage_bytes = 0;
@@ -434,6 +476,7 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->occ_verify = occupancy_of(bjj_k_eddsa_verify, BJJ_BLOCK);
   c->occ_scan = occupancy_of(bjj_k_eddsa_verify_scan, BJJ_BLOCK);
   c->occ_add = occupancy_of(bjj_k_point_add, BJJ_BLOCK);
+  c->occ_decomp = occupancy_of(bjj_k_decompress_points, BJJ_BLOCK);
   hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (se != hipSuccess) { delete c; return set_err(BJJ_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
   size_t entries = (size_t)c->nwin << W;
@@ -460,6 +503,7 @@ void bjj_free(bjj_ctx* c) {
   if (c->scratch) hipFree(c->scratch);
   if (c->vb_tables) hipFree(c->vb_tables);
   if (c->slow) hipFree(c->slow);
+  if (c->codec) hipFree(c->codec);
   if (c->stage) hipFree(c->stage);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -563,6 +607,59 @@ int bjj_point_add_dev(bjj_ctx* c, const void* d_p, const void* d_q, size_t n, vo
   return BJJ_OK;
 }
 
+int bjj_compress_points_dev(bjj_ctx* c, const void* d_pts, size_t n, void* d_out, void* stream) {
+  CHECK_CTX(c, "bjj_compress_points_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_pts, "bjj_compress_points_dev"); CHECK_PTR(d_out, "bjj_compress_points_dev");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_compress_points, dim3(grid_for(c, n, 8)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pts, n,
+                     (uint8_t*)d_out);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+int bjj_decompress_points_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out_xy, void* d_ok, void* stream) {
+  CHECK_CTX(c, "bjj_decompress_points_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_in, "bjj_decompress_points_dev"); CHECK_PTR(d_out_xy, "bjj_decompress_points_dev");
+  if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_decompress_points_dev: d_ok is NULL");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_decompress_points, dim3(grid_for(c, n, c->occ_decomp)), dim3(BJJ_BLOCK), 0, st,
+                     (const uint8_t*)d_in, (size_t)32, n, (uint8_t*)d_out_xy, (uint8_t*)d_ok, (uint8_t*)nullptr);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+int bjj_eddsa_verify_compressed_dev(bjj_ctx* c, const void* d_pk32, const void* d_sig64, const void* d_msg, size_t n,
+                                    void* d_ok, void* stream) {
+  CHECK_CTX(c, "bjj_eddsa_verify_compressed_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_pk32, "bjj_eddsa_verify_compressed_dev"); CHECK_PTR(d_sig64, "bjj_eddsa_verify_compressed_dev");
+  CHECK_PTR(d_msg, "bjj_eddsa_verify_compressed_dev");
+  if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_compressed_dev: d_ok is NULL");
+  HIPCK(hipSetDevice(c->device));
+  if (n > c->codec_items) {
+    if (c->codec) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->codec)); c->codec = nullptr; }
+    HIPCK(hipMalloc((void**)&c->codec, n * 162 + 64));
+    c->codec_items = n;
+  }
+  uint8_t* pk_xy = c->codec;
+  uint8_t* r_xy = pk_xy + n * 64;
+  uint8_t* s32 = r_xy + n * 64;
+  uint8_t* f_pk = s32 + n * 32;
+  uint8_t* f_r = f_pk + n;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const int g = grid_for(c, n, c->occ_decomp);
+  hipLaunchKernelGGL(bjj_k_decompress_points, dim3(g), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pk32, (size_t)32, n,
+                     pk_xy, f_pk, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(bjj_k_decompress_points, dim3(g), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_sig64, (size_t)64, n,
+                     r_xy, f_r, s32);
+  HIPCK(hipGetLastError());
+  int rc = bjj_eddsa_verify_dev(c, pk_xy, r_xy, s32, d_msg, n, d_ok, (void*)st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bjj_k_merge_codec_flags, dim3(grid_for(c, n, 8)), dim3(BJJ_BLOCK), 0, st, (uint8_t*)d_ok, f_pk, f_r, n);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+
 // ---- host-pointer API: stage -> *_dev -> copy back ----------------------------
 static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 
@@ -635,6 +732,51 @@ int bjj_point_add(bjj_ctx* c, const uint8_t* p, const uint8_t* q, size_t n, uint
   HIPCK(hipMemcpyAsync(c->stage + o_q, q, n * 64, hipMemcpyHostToDevice, c->stream));
   rc = bjj_point_add_dev(c, c->stage, c->stage + o_q, n, c->stage + o_out, nullptr); if (rc) return rc;
   HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+
+int bjj_compress_points(bjj_ctx* c, const uint8_t* pts, size_t n, uint8_t* out) {
+  CHECK_CTX(c, "bjj_compress_points");
+  if (n == 0) return BJJ_OK;
+  if (!pts || !out) return set_err(BJJ_E_INVALID, "bjj_compress_points: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_out = up16(n * 64);
+  int rc = ensure_stage(c, o_out + n * 32); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage, pts, n * 64, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_compress_points_dev(c, c->stage, n, c->stage + o_out, nullptr); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+int bjj_decompress_points(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out_xy, uint8_t* ok) {
+  CHECK_CTX(c, "bjj_decompress_points");
+  if (n == 0) return BJJ_OK;
+  if (!in || !out_xy || !ok) return set_err(BJJ_E_INVALID, "bjj_decompress_points: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_out = up16(n * 32), o_ok = o_out + up16(n * 64);
+  int rc = ensure_stage(c, o_ok + n); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage, in, n * 32, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_decompress_points_dev(c, c->stage, n, c->stage + o_out, c->stage + o_ok, nullptr); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(out_xy, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+int bjj_eddsa_verify_compressed(bjj_ctx* c, const uint8_t* pk32, const uint8_t* sig64, const uint8_t* msg, size_t n,
+                                uint8_t* ok) {
+  CHECK_CTX(c, "bjj_eddsa_verify_compressed");
+  if (n == 0) return BJJ_OK;
+  if (!pk32 || !sig64 || !msg || !ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_compressed: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_sig = up16(n * 32), o_m = o_sig + up16(n * 64), o_ok = o_m + up16(n * 32);
+  int rc = ensure_stage(c, o_ok + n); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage, pk32, n * 32, hipMemcpyHostToDevice, c->stream));
+  HIPCK(hipMemcpyAsync(c->stage + o_sig, sig64, n * 64, hipMemcpyHostToDevice, c->stream));
+  HIPCK(hipMemcpyAsync(c->stage + o_m, msg, n * 32, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_eddsa_verify_compressed_dev(c, c->stage, c->stage + o_sig, c->stage + o_m, n, c->stage + o_ok, nullptr);
+  if (rc) return rc;
+  HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
   HIPCK(hipStreamSynchronize(c->stream));
   return BJJ_OK;
 }

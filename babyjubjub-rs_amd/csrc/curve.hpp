@@ -27,6 +27,8 @@ struct Consts {
   Fr FINV_PLAIN;    // 1/F, canonical (so that mont_mul(x_mont, FINV_PLAIN) is canonical x/F)
   Fr DP, D2P, DPINV;  // D', 2D', 1/D' Montgomery
   Fr B8X, B8Y;      // generator, Montgomery (reference curve)
+  Fr TS_G;          // generator of the 2^28-order subgroup (Tonelli-Shanks), Montgomery
+  Fr HALFQ;         // plain integer (r-1)/2: the sign threshold of compress/decompress
   Fr ORDER, ORDER2, ORDER4;  // plain integers 8l, 16l, 32l in 29-bit limbs
   Fr L, L2, L4;              // plain integers l, 2l, 4l
   // Poseidon t=6 in its sparse-partial-round form (gen_tables.py: poseidon_sparse_constants)

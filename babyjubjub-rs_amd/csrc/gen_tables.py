@@ -235,6 +235,13 @@ def main():
     o.append("#define BJJ_K_DPINV    %s  // 1/d'" % limbs32(mont(inv(dprime))))
     o.append("#define BJJ_K_B8X      %s" % limbs32(mont(B8[0])))
     o.append("#define BJJ_K_B8Y      %s" % limbs32(mont(B8[1])))
+    # Tonelli-Shanks: r - 1 = 2^28 * s; generator of the 2^28 subgroup = n^s, n the least non-residue
+    ts_s = (Q - 1) >> 28
+    n = 2
+    while pow(n, (Q - 1) // 2, Q) != Q - 1:
+        n += 1
+    o.append("#define BJJ_K_TS_G     %s  // %d^((r-1)/2^28): order 2^28" % (limbs32(mont(pow(n, ts_s, Q))), n))
+    o.append("#define BJJ_K_HALFQ    %s  // PLAIN (r-1)/2" % limbs32((Q - 1) // 2))
     o.append("#define BJJ_K_ORDER    %s  // PLAIN integer 8*l" % limbs32(ORDER))
     o.append("#define BJJ_K_ORDER2   %s  // PLAIN 2*8*l" % limbs32(2 * ORDER))
     o.append("#define BJJ_K_ORDER4   %s  // PLAIN 4*8*l" % limbs32(4 * ORDER))

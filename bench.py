@@ -33,8 +33,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-ALGO_BYTES = {"fixed_base": 96, "var_base": 160, "verify": 193, "poseidon5": 192}
-UNITS = {"fixed_base": "scalar mults/s", "var_base": "scalar mults/s", "verify": "verifies/s", "poseidon5": "hashes/s"}
+ALGO_BYTES = {"fixed_base": 96, "var_base": 160, "verify": 193, "poseidon5": 192,
+              "verify_compressed": 129, "decompress": 97}  # 8(f) row 1: 32 pk + 64 sig + 32 msg -> 1; 32 -> 64 + 1
+UNITS = {"fixed_base": "scalar mults/s", "var_base": "scalar mults/s", "verify": "verifies/s", "poseidon5": "hashes/s",
+         "verify_compressed": "verifies/s", "decompress": "points/s"}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -74,13 +76,30 @@ class Workload:
             self.host["in"] = w.random_u256(w.SEED_MSGS, 5 * n, 5 * offset, top_bits_cleared=3).reshape(n, 160)
             self.d_in = up(self.host["in"])
             self.d_out = torch.empty(n * 32, dtype=torch.uint8, device=dev)
-        else:  # verify: cfg 4 signatures, 1/64 corrupted
+        elif kind == "decompress":
+            pts = ctx.mul_fixed_base(w.random_u256(w.SEED_POINTS, n, offset))
+            self.host["comp"] = ctx.compress_points(pts)
+            self.host["points"] = pts
+            self.d_in = up(self.host["comp"])
+            self.d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+            self.d_ok = torch.empty(n, dtype=torch.uint8, device=dev)
+        else:  # verify / verify_compressed: cfg 4 signatures, 1/64 corrupted
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from test_gpu_parity import make_signatures, corrupt
             A, R, S, msg = make_signatures(ctx.mul_fixed_base, ctx.poseidon5, n, offset)
-            self.bad = corrupt(A, R, S, msg, n, offset)
-            self.host.update(pk=A, r=R, s=S, msg=msg)
-            self.d_pk, self.d_r, self.d_s, self.d_msg = up(A), up(R), up(S), up(msg)
+            if kind == "verify":
+                self.bad = corrupt(A, R, S, msg, n, offset)
+                self.host.update(pk=A, r=R, s=S, msg=msg)
+                self.d_pk, self.d_r, self.d_s, self.d_msg = up(A), up(R), up(S), up(msg)
+            else:  # wire format: 32-byte pk, 64-byte signature; corruption lands in s / msg / the y bytes
+                z = np.zeros((n, 32), np.uint8)
+                A_t = np.concatenate([ctx.compress_points(A), z], axis=1)   # corrupt() flips A[i, :32] ...
+                R_t = np.concatenate([z, ctx.compress_points(R)], axis=1)   # ... and R[i, 32:]: the compressed bytes
+                self.bad = corrupt(A_t, R_t, S, msg, n, offset)
+                pkc = np.ascontiguousarray(A_t[:, :32])
+                sig = np.concatenate([R_t[:, 32:], S], axis=1)
+                self.host.update(pk=pkc, sig=sig, msg=msg)
+                self.d_pk, self.d_sig, self.d_msg = up(pkc), up(sig), up(msg)
             self.d_out = torch.empty(n, dtype=torch.uint8, device=dev)
 
     def launch(self):
@@ -91,6 +110,11 @@ class Workload:
             c.mul_var_base_dev(self.d_pts.data_ptr(), self.d_sc.data_ptr(), n, self.d_out.data_ptr(), s)
         elif self.kind == "poseidon5":
             c.poseidon5_dev(self.d_in.data_ptr(), n, self.d_out.data_ptr(), s)
+        elif self.kind == "decompress":
+            c.decompress_points_dev(self.d_in.data_ptr(), n, self.d_out.data_ptr(), self.d_ok.data_ptr(), s)
+        elif self.kind == "verify_compressed":
+            c.eddsa_verify_compressed_dev(self.d_pk.data_ptr(), self.d_sig.data_ptr(), self.d_msg.data_ptr(), n,
+                                          self.d_out.data_ptr(), s)
         else:
             c.eddsa_verify_dev(self.d_pk.data_ptr(), self.d_r.data_ptr(), self.d_s.data_ptr(), self.d_msg.data_ptr(), n,
                                self.d_out.data_ptr(), s)
@@ -109,6 +133,14 @@ class Workload:
         if self.kind == "poseidon5":
             got = self.d_out.view(n, 32)[torch.from_numpy(idx).to(self.d_out.device)].cpu().numpy()
             return bool((got == orc.poseidon5(h["in"][idx])).all())
+        if self.kind == "decompress":
+            got = self.d_out.view(n, 64).cpu().numpy()
+            return bool((got == h["points"]).all()) and bool(self.d_ok.cpu().numpy().all()) and \
+                bool((got[idx] == orc.decompress(h["comp"][idx])[0]).all())
+        if self.kind == "verify_compressed":
+            got = self.d_out.cpu().numpy()
+            return bool((got[~self.bad] == 1).all()) and bool((got[self.bad] != 1).all()) and \
+                bool((got[idx] == orc.verify_compressed(h["pk"][idx], h["sig"][idx], h["msg"][idx])).all())
         got = self.d_out.cpu().numpy()
         ok_mask = bool((got == (~self.bad).astype(np.uint8)).all())
         return ok_mask and bool((got[idx] == orc.verify(h["pk"][idx], h["r"][idx], h["s"][idx], h["msg"][idx])).all())
@@ -156,13 +188,18 @@ def cpu_baseline(kind, wl, budget_cpu_s=25.0):
             o.mul_var_base(h["points"][:m], h["scalars"][:m])
         elif kind == "poseidon5":
             o.poseidon5(h["in"][:m])
+        elif kind == "decompress":
+            o.decompress(h["comp"][:m])
+        elif kind == "verify_compressed":
+            o.verify_compressed(h["pk"][:m], h["sig"][:m], h["msg"][:m])
         else:
             o.verify(h["pk"][:m], h["r"][:m], h["s"][:m], h["msg"][:m])
         return time.perf_counter() - t0
 
     # single-thread rate on a small slice (also calibrates the sample size)
     orc.threads = 1
-    m1 = {"fixed_base": 1024, "var_base": 1024, "verify": 384, "poseidon5": 2048}[kind]
+    m1 = {"fixed_base": 1024, "var_base": 1024, "verify": 384, "poseidon5": 2048, "verify_compressed": 384,
+          "decompress": 2048}[kind]
     m1 = min(m1, wl.n)
     dt1 = run(orc, m1)
     rate1 = m1 / dt1
@@ -222,17 +259,18 @@ def main():
     if args.scatter and world > 1:
         # cfg 5 shape: time scatter + kernel + gather of rank-0 resident data
         from babyjubjub_rs_amd import shard
-        rows = {"fixed_base": [32], "var_base": [64, 32], "verify": [64, 64, 32, 32], "poseidon5": [160]}[kind]
-        outb = {"fixed_base": 64, "var_base": 64, "verify": 1, "poseidon5": 32}[kind]
+        rows = {"fixed_base": [32], "var_base": [64, 32], "verify": [64, 64, 32, 32], "poseidon5": [160],
+                "verify_compressed": [32, 64, 32]}[kind]
+        outb = {"fixed_base": 64, "var_base": 64, "verify": 1, "poseidon5": 32, "verify_compressed": 1}[kind]
         total = n * world
         full = None
         if rank == 0:
             full = [torch.zeros(total * rb, dtype=torch.uint8, device=dev) for rb in rows]
         tensors = {"fixed_base": ["d_sc"], "var_base": ["d_pts", "d_sc"], "verify": ["d_pk", "d_r", "d_s", "d_msg"],
-                   "poseidon5": ["d_in"]}[kind]
+                   "poseidon5": ["d_in"], "verify_compressed": ["d_pk", "d_sig", "d_msg"]}[kind]
         # assemble the global batch on rank 0 from every rank's block (untimed setup)
         for ti, (name, rb) in enumerate(zip(tensors, rows)):
-            g = shard.gather_rows(getattr(wl, name), total, rb, dev) if True else None
+            g = shard.gather_rows(getattr(wl, name), total, rb, dev)
             if rank == 0:
                 full[ti] = g
 
@@ -270,14 +308,18 @@ def main():
         result = {
             "metric": "BabyJubJub %s, %d-item batch per GPU" % (
                 {"fixed_base": "fixed-base scalar mults/sec", "var_base": "variable-base scalar mults/sec",
-                 "verify": "EdDSA-Poseidon verifies/sec", "poseidon5": "Poseidon(t=6) hashes/sec"}[kind], n),
+                 "verify": "EdDSA-Poseidon verifies/sec", "poseidon5": "Poseidon(t=6) hashes/sec",
+                 "verify_compressed": "EdDSA-Poseidon verifies/sec (compressed pk + signature)",
+                 "decompress": "point decompressions/sec"}[kind], n),
             "value": value, "unit": UNITS[kind], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": {"fixed_base": "1M fixed-base scalar mults (generator B8), BASELINE configs[1]",
                                     "var_base": "1M variable-base scalar mults, BASELINE configs[2]",
                                     "verify": "1M EdDSA-Poseidon verifies, 1/64 corrupted, BASELINE configs[3]",
-                                    "poseidon5": "Poseidon t=6 hashes (component of configs[3])"}[kind],
+                                    "poseidon5": "Poseidon t=6 hashes (component of configs[3])",
+                                    "verify_compressed": "1M EdDSA-Poseidon verifies on wire-format inputs (SURVEY 8f row 1)",
+                                    "decompress": "1M decompress_point (SURVEY 8f row 1)"}[kind],
                        "batch_per_gpu": n, "global_batch": n * world, "window_bits": info.window_bits,
                        "fixed_base_table_mb": info.table_bytes / 1e6,
                        "limbs": "9 x 29-bit, 64-bit column accumulators (v_mad_u64_u32)",
@@ -290,7 +332,9 @@ def main():
             result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": ach / HBM_PEAK_GBPS, "traffic": load_traffic(kind),
                                   "kernel": {"fixed_base": info.kernel_fixed_base, "var_base": info.kernel_var_base,
-                                             "verify": info.kernel_verify, "poseidon5": info.kernel_poseidon5}[kind].decode(),
+                                             "verify": info.kernel_verify, "poseidon5": info.kernel_poseidon5,
+                                             "verify_compressed": info.kernel_verify,
+                                             "decompress": b"bjj_k_decompress_points"}[kind].decode(),
                                   "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": algo,
                                   "note": "integer-ALU bound path (see DESIGN.md): HBM fraction is reported as measured"}
         orc = None

@@ -16,6 +16,10 @@
  *   bjj_eddsa_verify     verify(pk, sig, msg)        src/lib.rs:395-412
  *   bjj_point_add        PointProjective::add(..).affine()
  *                        src/lib.rs:88-131 + 70-85 on affine inputs (z = 1)
+ *   bjj_compress_points  Point::compress(&self)      src/lib.rs:166-178
+ *   bjj_decompress_points decompress_point(bb)       src/lib.rs:192-224 (+ utils.rs modinv/modsqrt)
+ *   bjj_eddsa_verify_compressed  decompress_point(pk), decompress_signature(sig)
+ *                        (src/lib.rs:260-268), then verify -- the wire-format ingest path
  *
  * Data formats (all little-endian, caller-owned, tightly packed arrays):
  *   field element  32 bytes, the canonical integer < r  (== Fr::into_repr().0
@@ -90,6 +94,17 @@ int bjj_eddsa_verify(bjj_ctx* ctx, const uint8_t* pk_xy /* n*64 */, const uint8_
                      uint8_t* ok /* n */);
 int bjj_point_add(bjj_ctx* ctx, const uint8_t* p_xy /* n*64 */, const uint8_t* q_xy /* n*64 */,
                   size_t n, uint8_t* out_xy /* n*64 */);
+/* Wire format (src/lib.rs:166-178): 32 bytes = y little-endian, bit 255 = (x > (r-1)/2). */
+int bjj_compress_points(bjj_ctx* ctx, const uint8_t* pts_xy /* n*64 */, size_t n, uint8_t* out /* n*32 */);
+/* ok[i] = 1 where decompress_point returns Ok, 0 where it returns Err (y >= r, x^2 a non-residue,
+ * or x^2 == 0 -- the reference's modsqrt rejects 0); out_xy[i] is all-zero for Err. */
+int bjj_decompress_points(bjj_ctx* ctx, const uint8_t* in /* n*32 */, size_t n, uint8_t* out_xy /* n*64 */,
+                          uint8_t* ok /* n */);
+/* pk: compressed point; sig: compressed R (32) then s (32), i.e. Signature::compress()'s layout
+ * (src/lib.rs:245-258).  ok[i] = 1 / 0 as bjj_eddsa_verify, or 2 where pk or R fails to
+ * decompress (the reference returns Err before verify is reached). */
+int bjj_eddsa_verify_compressed(bjj_ctx* ctx, const uint8_t* pk /* n*32 */, const uint8_t* sig /* n*64 */,
+                                const uint8_t* msg /* n*32 */, size_t n, uint8_t* ok /* n */);
 
 /* ---- device-pointer batch API (asynchronous on `stream`) -------------------- */
 int bjj_mul_fixed_base_dev(bjj_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* stream);
@@ -100,6 +115,10 @@ int bjj_eddsa_verify_dev(bjj_ctx* ctx, const void* d_pk_xy, const void* d_r_xy, 
                          const void* d_msg, size_t n, void* d_ok, void* stream);
 int bjj_point_add_dev(bjj_ctx* ctx, const void* d_p_xy, const void* d_q_xy, size_t n, void* d_out_xy,
                       void* stream);
+int bjj_compress_points_dev(bjj_ctx* ctx, const void* d_pts_xy, size_t n, void* d_out, void* stream);
+int bjj_decompress_points_dev(bjj_ctx* ctx, const void* d_in, size_t n, void* d_out_xy, void* d_ok, void* stream);
+int bjj_eddsa_verify_compressed_dev(bjj_ctx* ctx, const void* d_pk, const void* d_sig, const void* d_msg, size_t n,
+                                    void* d_ok, void* stream);
 
 /* Makes sure the context's scratch can serve batches of up to n items, so that
  * later *_dev calls do not allocate (call once before timing). */

@@ -109,6 +109,76 @@ def compress(pt):
 
 
 # ---------------------------------------------------------------------------
+# Point / signature codec (lib.rs:166-178, 192-224, 245-268; utils.rs:7-29, 109-160, 215-223)
+# ---------------------------------------------------------------------------
+def legendre_symbol(a):
+    """utils.rs:215-223: -1 for a non-residue, 1 otherwise (also for 0)."""
+    return -1 if pow(a % Q, (Q - 1) >> 1, Q) == Q - 1 else 1
+
+
+def modsqrt(a):
+    """utils.rs:109-160 (Tonelli-Shanks, Go style).  None where the reference returns Err:
+    non-residue or a == 0.  (Which of the two roots comes out does not matter to
+    decompress_point: the sign rule of lib.rs:217-219 picks by the sign bit.)"""
+    a %= Q
+    if legendre_symbol(a) != 1 or a == 0:
+        return None
+    s, e = Q - 1, 0
+    while s % 2 == 0:
+        s >>= 1
+        e += 1
+    n = 2
+    while legendre_symbol(n) != -1:
+        n += 1
+    y, b, g, r = pow(a, (s + 1) >> 1, Q), pow(a, s, Q), pow(n, s, Q), e
+    while True:
+        t, m = b, 0
+        while t != 1:
+            t = t * t % Q
+            m += 1
+        if m == 0:
+            return y
+        t = pow(g, 1 << (r - m - 1), Q)
+        g = pow(g, 1 << (r - m), Q)
+        y = y * t % Q
+        b = b * g % Q
+        r = m
+
+
+def decompress_point(bb):
+    """lib.rs:192-224.  Returns (x, y) or None where the reference returns Err."""
+    b = bytearray(bb)
+    sign = bool(b[31] & 0x80)
+    b[31] &= 0x7F
+    y = int.from_bytes(bytes(b), "little")
+    if y >= Q:                                     # lib.rs:201-203
+        return None
+    den_in = (A - (D * (y * y)) % Q) % Q           # lib.rs:207-213
+    if den_in == 0:
+        return None                                # modinv(0) -> Err (utils.rs:13-15); unreachable: A/D is a non-residue
+    x2 = ((1 - (y * y) % Q) * finv(den_in)) % Q    # lib.rs:214
+    x = modsqrt(x2)                                # lib.rs:215
+    if x is None:
+        return None
+    if (sign and x <= (Q >> 1)) or ((not sign) and x > (Q >> 1)):   # lib.rs:217-219
+        x = (-x) % Q
+    return (x % Q, y)
+
+
+def compress_signature(r_b8, s):
+    """Signature::compress, lib.rs:245-258 (s must fit 32 bytes there as well)."""
+    return compress(r_b8) + int(s).to_bytes(32, "little")
+
+
+def decompress_signature(b):
+    """lib.rs:260-268: (R, s) or None if R does not decompress; s is taken as-is."""
+    r = decompress_point(bytes(b[:32]))
+    if r is None:
+        return None
+    return r, int.from_bytes(bytes(b[32:64]), "little")
+
+
+# ---------------------------------------------------------------------------
 # Poseidon (third-party poseidon-rs 0.0.8; SURVEY.md Appendix B)
 # ---------------------------------------------------------------------------
 _RP_TABLE = [56, 57, 56, 60, 60, 63, 64, 63]  # t = 2..9

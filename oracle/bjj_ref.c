@@ -12,6 +12,9 @@
  *                                               add also used for doubling)
  *   test_bit               src/lib.rs:188-190
  *   verify                 src/lib.rs:395-412
+ *   compress / decompress_point / decompress_signature
+ *                          src/lib.rs:166-178, 192-224, 245-268 with utils.rs:11-29 (modinv),
+ *                          109-160 (Tonelli-Shanks modsqrt), 215-223 (legendre_symbol)
  *   Fr                     third-party ff_ce 0.11 derive (Cargo.toml:12): 4 x u64
  *                          Montgomery limbs, R = 2^256; restated from the
  *                          published algorithm
@@ -258,6 +261,81 @@ static int verify1(const uint8_t *pk, const uint8_t *rb8, const uint8_t *s, cons
   return fr_eq(&l.x, &ra.x) && fr_eq(&l.y, &ra.y);   /* lib.rs:180-185 */
 }
 
+
+/* ---- codec (lib.rs:166-178, 192-224; utils.rs:109-160, 215-223) -------- */
+static void fr_pow(fr_t *out, const fr_t *base, const uint64_t e[4]) {
+  fr_t r = R1;
+  for (int i = 255; i >= 0; i--) {
+    fr_square(&r);
+    if ((e[i / 64] >> (i % 64)) & 1) fr_mul(&r, base);
+  }
+  *out = r;
+}
+static int legendre_symbol(const fr_t *a) { /* utils.rs:215-223: -1 only for a non-residue */
+  static const uint64_t HALF[4] = {0xa1f0fac9f8000000ULL, 0x9419f4243cdcb848ULL, 0xdc2822db40c0ac2eULL, 0x183227397098d014ULL}; /* (r-1)/2 */
+  fr_t ls; fr_pow(&ls, a, HALF);
+  fr_t m1 = ZERO; fr_sub(&m1, &R1); /* -1 */
+  return fr_eq(&ls, &m1) ? -1 : 1;
+}
+static fr_t TS_G;          /* n^s for the smallest non-residue n */
+static const uint64_t TS_S[4] = {0x9b9709143e1f593fULL, 0x181585d2833e8487ULL, 0x131a029b85045b68ULL, 0x000000030644e72eULL};       /* s = (r-1) >> 28 */
+static const uint64_t TS_S1H[4] = {0xcdcb848a1f0faca0ULL, 0x0c0ac2e9419f4243ULL, 0x098d014dc2822db4ULL, 0x0000000183227397ULL};     /* (s+1) >> 1 */
+static pthread_once_t g_once_ts = PTHREAD_ONCE_INIT;
+static void init_ts(void) {
+  uint64_t n = 2; fr_t f;
+  for (;; n++) { fr_from_u64(&f, n); if (legendre_symbol(&f) == -1) break; }   /* utils.rs:127-130 */
+  fr_pow(&TS_G, &f, TS_S);
+}
+static void fr_pow2k(fr_t *x, unsigned k) { while (k--) fr_square(x); }
+static int modsqrt(fr_t *out, const fr_t *a) { /* utils.rs:109-160 */
+  pthread_once(&g_once_ts, init_ts);
+  if (legendre_symbol(a) != 1 || fr_is_zero(a)) return 0;   /* "not a mod p square" */
+  fr_t y, b, g = TS_G;
+  fr_pow(&y, a, TS_S1H);
+  fr_pow(&b, a, TS_S);
+  unsigned r = 28;
+  for (;;) {
+    fr_t t = b; unsigned m = 0;
+    while (!fr_eq(&t, &R1)) { fr_square(&t); m++; }
+    if (m == 0) { *out = y; return 1; }
+    t = g; fr_pow2k(&t, r - m - 1);
+    fr_pow2k(&g, r - m);
+    fr_mul(&y, &t);
+    fr_mul(&b, &g);
+    r = m;
+  }
+}
+static int decompress_point(point_t *o, const uint8_t bb[32]) { /* lib.rs:192-224 */
+  uint8_t b[32]; memcpy(b, bb, 32);
+  int sign = (b[31] & 0x80) != 0;
+  b[31] &= 0x7F;
+  fr_t yr; memcpy(yr.l, b, 32);
+  if (fr_geq(&yr, &MODULUS)) return 0;                      /* lib.rs:201-203 */
+  fr_t y; fr_from_le(&y, b);
+  fr_t y2 = y; fr_square(&y2);
+  fr_t den = C_D; fr_mul(&den, &y2);
+  fr_t t = C_A; fr_sub(&t, &den);                           /* A - D y^2 */
+  fr_t deninv;
+  if (!fr_inverse(&deninv, &t)) return 0;                   /* modinv(0) -> Err, utils.rs:13-15 */
+  fr_t num = R1; fr_sub(&num, &y2);
+  fr_mul(&num, &deninv);                                    /* x^2, lib.rs:214 */
+  fr_t x;
+  if (!modsqrt(&x, &num)) return 0;                         /* lib.rs:215 */
+  uint8_t xb[32]; fr_to_le(xb, &x);
+  fr_t xr; memcpy(xr.l, xb, 32);
+  static const fr_t HALFQ = {{0xa1f0fac9f8000000ULL, 0x9419f4243cdcb848ULL, 0xdc2822db40c0ac2eULL, 0x183227397098d014ULL}}; /* Q >> 1 */
+  int gt = fr_geq(&xr, &HALFQ) && !fr_eq(&xr, &HALFQ);      /* x > Q/2 */
+  if ((sign && !gt) || (!sign && gt)) { fr_t z = ZERO; fr_sub(&z, &x); x = z; }   /* lib.rs:217-219 */
+  o->x = x; o->y = y;
+  return 1;
+}
+static void compress_point(uint8_t r[32], const point_t *p) { /* lib.rs:166-178 */
+  uint8_t xb[32]; fr_to_le(xb, &p->x); fr_to_le(r, &p->y);
+  fr_t xr; memcpy(xr.l, xb, 32);
+  static const fr_t HALFQ = {{0xa1f0fac9f8000000ULL, 0x9419f4243cdcb848ULL, 0xdc2822db40c0ac2eULL, 0x183227397098d014ULL}};
+  if (fr_geq(&xr, &HALFQ) && !fr_eq(&xr, &HALFQ)) r[31] |= 0x80;
+}
+
 /* ======================= exported C entry points ======================== */
 #define EXPORT __attribute__((visibility("default")))
 
@@ -311,9 +389,33 @@ EXPORT int bjjref_verify(const uint8_t *pk, const uint8_t *rb8, const uint8_t *s
   return verify1(pk, rb8, s, msg);
 }
 
+
+/* out: 64-byte point, returns 1 = Ok, 0 = Err (out zeroed) */
+EXPORT int bjjref_decompress_point(const uint8_t *in, uint8_t *out) {
+  ensure_init();
+  point_t p;
+  if (!decompress_point(&p, in)) { memset(out, 0, 64); return 0; }
+  fr_to_le(out, &p.x); fr_to_le(out + 32, &p.y);
+  return 1;
+}
+EXPORT void bjjref_compress_point(const uint8_t *in, uint8_t *out) {
+  ensure_init();
+  point_t p; fr_from_le(&p.x, in); fr_from_le(&p.y, in + 32);
+  compress_point(out, &p);
+}
+/* decompress pk (32 B) and the signature (64 B: compressed R, then s) as lib.rs:192-224, 260-268,
+ * then verify (lib.rs:395-412).  1 = true, 0 = false, 2 = a point failed to decompress (Err). */
+EXPORT int bjjref_verify_compressed(const uint8_t *pk32, const uint8_t *sig64, const uint8_t *msg) {
+  ensure_init();
+  uint8_t pk[64], r[64];
+  if (!bjjref_decompress_point(pk32, pk)) return 2;
+  if (!bjjref_decompress_point(sig64, r)) return 2;
+  return verify1(pk, r, sig64 + 32, msg);
+}
+
 /* ---- threaded batch drivers (CPU baseline + bulk expected values) ------ */
 typedef struct {
-  int kind; /* 0 fixed-base, 1 var-base, 2 poseidon5, 3 verify */
+  int kind; /* 0 fixed-base, 1 var-base, 2 poseidon5, 3 verify, 4 decompress, 5 compress, 6 verify-compressed */
   const uint8_t *a, *b, *c, *d; uint8_t *out; size_t lo, hi;
 } job_t;
 static void *worker(void *arg) {
@@ -324,6 +426,9 @@ static void *worker(void *arg) {
       case 1: bjjref_mul_scalar(j->a + 64 * i, j->b + 32 * i, 32, j->out + 64 * i); break;
       case 2: bjjref_poseidon5(j->a + 160 * i, j->out + 32 * i); break;
       case 3: j->out[i] = (uint8_t)verify1(j->a + 64 * i, j->b + 64 * i, j->c + 32 * i, j->d + 32 * i); break;
+      case 4: ((uint8_t *)j->b)[i] = (uint8_t)bjjref_decompress_point(j->a + 32 * i, j->out + 64 * i); break;
+      case 5: bjjref_compress_point(j->a + 64 * i, j->out + 32 * i); break;
+      case 6: j->out[i] = (uint8_t)bjjref_verify_compressed(j->a + 32 * i, j->b + 64 * i, j->c + 32 * i); break;
     }
   }
   return NULL;
@@ -354,4 +459,14 @@ EXPORT void bjjref_poseidon5_batch(const uint8_t *in, size_t n, uint8_t *out, in
 EXPORT void bjjref_verify_batch(const uint8_t *pk, const uint8_t *rb8, const uint8_t *s, const uint8_t *msg,
                                 size_t n, uint8_t *ok, int nthreads) {
   run_batch(3, pk, rb8, s, msg, ok, n, nthreads);
+}
+EXPORT void bjjref_decompress_batch(const uint8_t *in, size_t n, uint8_t *out_xy, uint8_t *ok, int nthreads) {
+  run_batch(4, in, ok, NULL, NULL, out_xy, n, nthreads);
+}
+EXPORT void bjjref_compress_batch(const uint8_t *in_xy, size_t n, uint8_t *out, int nthreads) {
+  run_batch(5, in_xy, NULL, NULL, NULL, out, n, nthreads);
+}
+EXPORT void bjjref_verify_compressed_batch(const uint8_t *pk32, const uint8_t *sig64, const uint8_t *msg, size_t n,
+                                           uint8_t *ok, int nthreads) {
+  run_batch(6, pk32, sig64, msg, NULL, ok, n, nthreads);
 }

@@ -67,6 +67,29 @@ class Oracle:
                                      self.threads)
         return out
 
+    def decompress(self, comp):
+        a = np.ascontiguousarray(comp, dtype=np.uint8).reshape(-1)
+        n = a.size // 32
+        out = np.empty(n * 64, np.uint8)
+        ok = np.empty(n, np.uint8)
+        self.lib.bjjref_decompress_batch(self._p(a), ctypes.c_size_t(n), self._p(out), self._p(ok), self.threads)
+        return out.reshape(n, 64), ok
+
+    def compress(self, pts):
+        a = np.ascontiguousarray(pts, dtype=np.uint8).reshape(-1)
+        n = a.size // 64
+        out = np.empty(n * 32, np.uint8)
+        self.lib.bjjref_compress_batch(self._p(a), ctypes.c_size_t(n), self._p(out), self.threads)
+        return out.reshape(n, 32)
+
+    def verify_compressed(self, pk, sig, msg):
+        pk, sig, msg = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1) for x in (pk, sig, msg))
+        n = pk.size // 32
+        out = np.empty(n, np.uint8)
+        self.lib.bjjref_verify_compressed_batch(self._p(pk), self._p(sig), self._p(msg), ctypes.c_size_t(n),
+                                                self._p(out), self.threads)
+        return out
+
     def point_add(self, p, q):
         p = np.ascontiguousarray(p, dtype=np.uint8).reshape(-1, 64)
         q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 64)

@@ -53,6 +53,23 @@ static void test_circomlib_testvector() {  // lib.rs:689-738 (everything downstr
   U256 big = U256::from_str("21888242871839275222246405745257275088548364400416034343698204186575808495618");  // Q + 1
   ASSERT_TRUE(!verify(pk, sig, big));  // lib.rs:396-398
 }
+static void test_point_compress_decompress() {  // lib.rs:575-594
+  Point p = P();
+  auto c = p.compress();
+  U256 cc; std::memcpy(cc.le.data(), c.data(), 32);
+  // hex::encode(p_comp) is byte order; U256::to_hex prints big-endian, so compare bytes
+  const char* want = "53b81ed5bffe9545b54016234682e7b2f699bd42a5e9eae27ff4051bc698ce85";
+  char got[65]; for (int i = 0; i < 32; i++) snprintf(got + 2 * i, 3, "%02x", c[i]);
+  ASSERT_EQ(std::string(got), std::string(want));
+  Point p2 = decompress_point(c);
+  ASSERT_EQ(p.x, p2.x); ASSERT_EQ(p.y, p2.y);
+  Signature sig{p, U256(12345)};
+  Signature sig2 = decompress_signature(sig.compress());   // lib.rs:657-675 shape
+  ASSERT_TRUE(sig2.r_b8.equals(p)); ASSERT_EQ(sig2.s, sig.s);
+  bool threw = false;
+  try { std::array<uint8_t, 32> bad; bad.fill(0xff); decompress_point(bad); } catch (const std::invalid_argument&) { threw = true; }
+  ASSERT_TRUE(threw);
+}
 static void test_batch() {
   std::vector<U256> n; for (uint64_t i = 0; i < 1000; i++) n.push_back(U256(i * 0x9E3779B97F4A7C15ULL + 1));
   std::vector<Point> a = mul_fixed_base_batch(n);
@@ -62,7 +79,7 @@ static void test_batch() {
 }
 int main() {
   try {
-    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_batch();
+    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_point_compress_decompress(); test_batch();
   } catch (const std::exception& e) { printf("EXCEPTION %s\n", e.what()); return 2; }
   printf(failures ? "FAILED %d\n" : "ok (reference tests re-stated in C++)\n", failures);
   return failures ? 1 : 0;

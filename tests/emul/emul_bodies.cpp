@@ -10,7 +10,7 @@
 #include "../../babyjubjub-rs_amd/csrc/bjj_constants.inc"
 using namespace bjj;
 static const Consts K = {
-    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y,
+    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y, BJJ_K_TS_G, BJJ_K_HALFQ,
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
     BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M};
 static std::vector<u32> g_table; static int g_W = 0, g_nwin = 0;
@@ -48,6 +48,16 @@ void emul_poseidon5(const uint8_t* in, uint8_t* out) {
   Fr h[5]; alignas(16) u32 w[8];
   for (int j = 0; j < 5; j++) { memcpy(w, in + 32 * j, 32); h[j] = fr_to_mont_words(w); }
   fr_from_mont_words(poseidon5(h, K), w); memcpy(out, w, 32);
+}
+int emul_decompress(const uint8_t* in, uint8_t* out) {
+  alignas(16) u32 w[8], ox[8], oy[8]; memcpy(w, in, 32);
+  bool ok = decompress_item(w, ox, oy, K);
+  memcpy(out, ox, 32); memcpy(out + 32, oy, 32);
+  return ok ? 1 : 0;
+}
+void emul_compress(const uint8_t* in, uint8_t* out) {
+  alignas(16) u32 x[8], y[8], o[8]; memcpy(x, in, 32); memcpy(y, in + 32, 32);
+  compress_item(x, y, o, K); memcpy(out, o, 32);
 }
 int emul_verify(const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, int W) {
   ensure_table(W);

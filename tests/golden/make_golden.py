@@ -48,6 +48,11 @@ def kats():
                      4014745322800118607127020275658861516666525056516280575712425373174125159339)}]},
         "point_compress": {"src": "src/lib.rs:575-594", "p": P,
                            "hex": "53b81ed5bffe9545b54016234682e7b2f699bd42a5e9eae27ff4051bc698ce85"},
+        "point_decompress": {"src": "src/lib.rs:597-632", "cases": [
+            {"y_bytes": "b5328f8791d48f20bec6e481d91c7ada235f1facf22547901c18656b6c3e042f",
+             "x_le_bytes": "b86cc8d9c97daef0afe1a4753c54fb2d8a530dc74c7eee4e72b3fdf2496d2113"},
+            {"y_bytes": "70552d3ff548e09266ded29b33ce75139672b062b02aa66bb0d9247ffecf1d0b",
+             "x_le_bytes": "30f1635ba7d56f9cb32c3ffbe6dca508a68c7f43936af11a23c785ce98cb3404"}]},
         "circomlib_testvector": {
             "src": "src/lib.rs:689-738",
             "scalar_key": 6466070937662820620902051049739362987537906109895538826186780010858059362905,
@@ -138,6 +143,39 @@ def oracle_vectors():
     rec(A0, (0, 1), 0, 0, "R = identity, s = 0")
     rec(o.T8, R0, S0, 0, "pk of order 8")
     out["verify"] = ver
+
+    # ---- codec row: compress / decompress_point / verify on compressed inputs
+    rc = o.SplitMix64(o.SEED_POINTS ^ 0xC0DEC)
+    comp = []
+    for P in pts + [(Q - p[0], p[1]) for p in pts[:6]]:
+        comp.append({"in": o.compress(P).hex(), "note": "on-curve point"})
+    for raw, note in ((o.to_le32(Q), "y == Q -> Err"), (o.to_le32(Q - 1), "y = Q-1 = -1: x^2 == 0 -> Err (modsqrt rejects 0)"),
+                      (o.to_le32(1), "y = 1: x^2 == 0 -> Err"), (bytes([0xff] * 32), "all ones: y >= Q after clearing the sign"),
+                      (bytes(32), "y = 0"), (o.to_le32(2), "y = 2"), (o.to_le32((1 << 255) | 2), "y = 2 with sign bit")):
+        comp.append({"in": raw.hex(), "note": note})
+    for i in range(24):
+        v = (rc.u256() % Q) | ((rc.next() & 1) << 255)
+        comp.append({"in": o.to_le32(v).hex(), "note": "random y"})
+    for c in comp:
+        d = o.decompress_point(bytes.fromhex(c["in"]))
+        c["ok"] = d is not None
+        c["out"] = [hx(d[0]), hx(d[1])] if d else [hx(0), hx(0)]
+        if d:
+            assert o.compress(d) == bytes.fromhex(c["in"])
+    out["decompress"] = comp
+    vc = []
+    for rec in ver[:9] + ver[14:16]:
+        A = tuple(int(v, 16) for v in rec["pk"]); R = tuple(int(v, 16) for v in rec["r_b8"])
+        if not (o.on_curve(A) and o.on_curve(R)) or A[0] == 0 or R[0] == 0:
+            continue  # only points that have a compressed form
+        s_int = int(rec["s"], 16)
+        vc.append({"pk": o.compress(A).hex(), "sig": o.compress_signature(R, s_int).hex(), "msg": rec["msg"],
+                   "ok": 1 if rec["ok"] else 0, "note": rec["note"]})
+    good = vc[0]
+    vc.append({"pk": o.to_le32(Q).hex(), "sig": good["sig"], "msg": good["msg"], "ok": 2, "note": "pk does not decompress"})
+    vc.append({"pk": good["pk"], "sig": o.to_le32(3).hex() + good["sig"][64:], "msg": good["msg"],
+               "ok": 2 if o.decompress_point(o.to_le32(3)) is None else 0, "note": "R replaced by y = 3"})
+    out["verify_compressed"] = vc
     return out
 
 
