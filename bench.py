@@ -239,13 +239,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    # BJJ_BENCH_BACKEND=gloo + BJJ_BENCH_SHARE_GPU=1 is a developer mode that runs several ranks on ONE
+    # GPU to exercise the N > 1 control flow on a single-GPU box (RCCL refuses two ranks per device).
+    backend = os.environ.get("BJJ_BENCH_BACKEND", "nccl")
+    if os.environ.get("BJJ_BENCH_SHARE_GPU", "0") == "1":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import babyjubjub_rs_amd as bjj
     ctx = bjj.Context(local_rank, args.window_bits)
@@ -296,7 +305,7 @@ def main():
     else:
         dt, kernel_ms = timed_steps(wl, args.steps, args.warmup, world)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
