@@ -147,6 +147,37 @@ class Context:
         self._ck(self.lib.bjj_point_add(self.handle, a.ctypes.data, b.ctypes.data, n, out.ctypes.data), "bjj_point_add")
         return out.reshape(n, 64)
 
+    def scalar_keys(self, keys):
+        a = _as_u8(keys, 32, "keys")
+        n = a.size // 32
+        out = np.empty(n * 32, dtype=np.uint8)
+        self._ck(self.lib.bjj_scalar_keys(self.handle, a.ctypes.data, n, out.ctypes.data), "bjj_scalar_keys")
+        return out.reshape(n, 32)
+
+    def public_keys(self, keys):
+        a = _as_u8(keys, 32, "keys")
+        n = a.size // 32
+        out = np.empty(n * 64, dtype=np.uint8)
+        self._ck(self.lib.bjj_public_keys(self.handle, a.ctypes.data, n, out.ctypes.data), "bjj_public_keys")
+        return out.reshape(n, 64)
+
+    def sign(self, keys, msgs):
+        """-> (r_b8 (n, 64), s (n, 32), ok (n,)); ok == 0 where the reference returns Err (msg > Q)"""
+        a = _as_u8(keys, 32, "keys")
+        m = _as_u8(msgs, 32, "msgs")
+        n = a.size // 32
+        if m.size != a.size:
+            raise BjjError("sign: array lengths disagree")
+        r = np.empty(n * 64, dtype=np.uint8)
+        s = np.empty(n * 32, dtype=np.uint8)
+        ok = np.empty(n, dtype=np.uint8)
+        self._ck(self.lib.bjj_sign(self.handle, a.ctypes.data, m.ctypes.data, n, r.ctypes.data, s.ctypes.data,
+                                   ok.ctypes.data), "bjj_sign")
+        return r.reshape(n, 64), s.reshape(n, 32), ok
+
+    def sign_dev(self, d_keys, d_msgs, n, d_r, d_s, d_ok, stream=0):
+        self._ck(self.lib.bjj_sign_dev(self.handle, d_keys, d_msgs, n, d_r, d_s, d_ok, stream), "bjj_sign_dev")
+
     def compress_points(self, points):
         a = _as_u8(points, 64, "points")
         n = a.size // 64
@@ -288,6 +319,40 @@ class Signature:
     def __init__(self, r_b8, s):
         self.r_b8 = r_b8
         self.s = int(s)
+
+
+class PrivateKey:
+    """`pub struct PrivateKey { pub key: [u8; 32] }` (lib.rs:270-342)."""
+
+    __slots__ = ("key",)
+
+    def __init__(self, key):
+        self.key = bytes(key)
+
+    @staticmethod
+    def import_(b):  # PrivateKey::import, lib.rs:275-282
+        if len(b) != 32:
+            raise ValueError("imported key can not be bigger than 32 bytes")
+        return PrivateKey(bytes(b))
+
+    def scalar_key(self, ctx=None):  # lib.rs:284-302
+        return _ints((ctx or default_context()).scalar_keys(np.frombuffer(self.key, np.uint8)), 1)[0]
+
+    def public(self, ctx=None):  # lib.rs:304-306
+        x, y = _ints((ctx or default_context()).public_keys(np.frombuffer(self.key, np.uint8)), 2)[0]
+        return Point(x, y)
+
+    def sign(self, msg, ctx=None):  # lib.rs:308-342 -> Signature; ValueError for the reference's Err
+        msg = int(msg)
+        if msg < 0:
+            raise BjjError("sign: negative msg")
+        if msg > Q:
+            raise ValueError("msg outside the Finite Field")
+        r, s, ok = (ctx or default_context()).sign(np.frombuffer(self.key, np.uint8), [msg])
+        if not ok[0]:
+            raise ValueError("msg outside the Finite Field")
+        x, y = _ints(r, 2)[0]
+        return Signature(Point(x, y), _ints(s, 1)[0])
 
 
 def decompress_point(bb, ctx=None):

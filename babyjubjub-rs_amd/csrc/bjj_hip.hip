@@ -20,7 +20,7 @@
 #include <new>
 
 #include "../../include/bjj_hip.h"
-#include "bjj_device.hpp"
+#include "sign.hpp"
 #include "bjj_constants.inc"
 
 using namespace bjj;
@@ -32,7 +32,7 @@ using namespace bjj;
 #define BJJ_EPI_BLOCK 512
 
 __constant__ Consts c_K = {
-    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y, BJJ_K_TS_G, BJJ_K_HALFQ,
+    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_FINV, BJJ_K_L_R1, BJJ_K_L_R2, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y, BJJ_K_TS_G, BJJ_K_HALFQ,
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
     BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M};
 
@@ -365,6 +365,38 @@ __global__ void bjj_k_merge_codec_flags(uint8_t* __restrict__ ok, const uint8_t*
     if (!(f_pk[i] && f_r[i])) ok[i] = 2;
 }
 
+// ---------------------------------------------------------------------------
+// signer row: PrivateKey::scalar_key / public / sign, src/lib.rs:284-342
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_scalar_keys(const uint8_t* __restrict__ keys, size_t n,
+                                                               uint8_t* __restrict__ out) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    u32 k[8], sk[8], pr[8], hi[8];
+    load_w8(keys + i * 32, k);
+    scalar_key_words(k, sk, pr, hi);
+    store_w8(out + i * 32, sk);
+  }
+}
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign(const u32* __restrict__ table, int W, int nwin,
+                                                           const uint8_t* __restrict__ keys,
+                                                           const uint8_t* __restrict__ msgs, size_t n,
+                                                           uint8_t* __restrict__ out_r, uint8_t* __restrict__ out_s,
+                                                           uint8_t* __restrict__ ok) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    u32 k[8], m[8], rx[8], ry[8], s[8];
+    load_w8(keys + i * 32, k); load_w8(msgs + i * 32, m);
+    const bool good = sign_item(k, m, table, W, nwin, rx, ry, s, c_K);
+#pragma unroll
+    for (int j = 0; j < 8; j++) { rx[j] = good ? rx[j] : 0u; ry[j] = good ? ry[j] : 0u; s[j] = good ? s[j] : 0u; }
+    store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry); store_w8(out_s + i * 32, s);
+    ok[i] = good ? 1 : 0;
+  }
+}
+
 // ===========================================================================
 // host side: context + extern "C" boundary
 // ===========================================================================
@@ -395,7 +427,7 @@ struct bjj_ctx {
   size_t slow_items = 0;
   uint8_t* codec = nullptr;    // verify_compressed: n * (64 pk + 64 R + 32 s + 2 flags) bytes
   size_t codec_items = 0;
-  int occ_decomp = 1;
+  int occ_decomp = 1, occ_sign = 1;
   // staging buffers for the host-pointer API
   uint8_t* stage = nullptr;
   size_t stage_bytes = 0;
@@ -443,6 +475,15 @@ static int ensure_stage(bjj_ctx* c, size_t bytes) {
   }
   return BJJ_OK;
 }
+static int ensure_codec(bjj_ctx* c, size_t n) {  // 162 bytes per item of intermediate records
+  HIPCK(hipSetDevice(c->device));
+  if (n > c->codec_items) {
+    if (c->codec) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->codec)); c->codec = nullptr; }
+    HIPCK(hipMalloc((void**)&c->codec, n * 162 + 64));
+    c->codec_items = n;
+  }
+  return BJJ_OK;
+}
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" {
@@ -477,6 +518,7 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->occ_scan = occupancy_of(bjj_k_eddsa_verify_scan, BJJ_BLOCK);
   c->occ_add = occupancy_of(bjj_k_point_add, BJJ_BLOCK);
   c->occ_decomp = occupancy_of(bjj_k_decompress_points, BJJ_BLOCK);
+  c->occ_sign = occupancy_of(bjj_k_sign, BJJ_BLOCK);
   hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (se != hipSuccess) { delete c; return set_err(BJJ_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
   size_t entries = (size_t)c->nwin << W;
@@ -635,12 +677,7 @@ int bjj_eddsa_verify_compressed_dev(bjj_ctx* c, const void* d_pk32, const void* 
   CHECK_PTR(d_pk32, "bjj_eddsa_verify_compressed_dev"); CHECK_PTR(d_sig64, "bjj_eddsa_verify_compressed_dev");
   CHECK_PTR(d_msg, "bjj_eddsa_verify_compressed_dev");
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_compressed_dev: d_ok is NULL");
-  HIPCK(hipSetDevice(c->device));
-  if (n > c->codec_items) {
-    if (c->codec) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->codec)); c->codec = nullptr; }
-    HIPCK(hipMalloc((void**)&c->codec, n * 162 + 64));
-    c->codec_items = n;
-  }
+  int rc0 = ensure_codec(c, n); if (rc0) return rc0;
   uint8_t* pk_xy = c->codec;
   uint8_t* r_xy = pk_xy + n * 64;
   uint8_t* s32 = r_xy + n * 64;
@@ -656,6 +693,39 @@ int bjj_eddsa_verify_compressed_dev(bjj_ctx* c, const void* d_pk32, const void* 
   int rc = bjj_eddsa_verify_dev(c, pk_xy, r_xy, s32, d_msg, n, d_ok, (void*)st);
   if (rc) return rc;
   hipLaunchKernelGGL(bjj_k_merge_codec_flags, dim3(grid_for(c, n, 8)), dim3(BJJ_BLOCK), 0, st, (uint8_t*)d_ok, f_pk, f_r, n);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+
+int bjj_scalar_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out, void* stream) {
+  CHECK_CTX(c, "bjj_scalar_keys_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_keys, "bjj_scalar_keys_dev"); CHECK_PTR(d_out, "bjj_scalar_keys_dev");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_scalar_keys, dim3(grid_for(c, n, 4)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_keys, n,
+                     (uint8_t*)d_out);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+int bjj_public_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy, void* stream) {
+  CHECK_CTX(c, "bjj_public_keys_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_keys, "bjj_public_keys_dev"); CHECK_PTR(d_out_xy, "bjj_public_keys_dev");
+  int rc = ensure_codec(c, n); if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  rc = bjj_scalar_keys_dev(c, d_keys, n, c->codec, (void*)st); if (rc) return rc;   // B8.mul_scalar(&self.scalar_key())
+  return bjj_mul_fixed_base_dev(c, c->codec, n, d_out_xy, (void*)st);
+}
+int bjj_sign_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, void* d_out_r, void* d_out_s, void* d_ok,
+                 void* stream) {
+  CHECK_CTX(c, "bjj_sign_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_PTR(d_keys, "bjj_sign_dev"); CHECK_PTR(d_msgs, "bjj_sign_dev"); CHECK_PTR(d_out_r, "bjj_sign_dev");
+  CHECK_PTR(d_out_s, "bjj_sign_dev");
+  if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_sign_dev: d_ok is NULL");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_sign, dim3(grid_for(c, n, c->occ_sign)), dim3(BJJ_BLOCK), 0, st, c->table, c->W, c->nwin,
+                     (const uint8_t*)d_keys, (const uint8_t*)d_msgs, n, (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok);
   HIPCK(hipGetLastError());
   return BJJ_OK;
 }
@@ -776,6 +846,50 @@ int bjj_eddsa_verify_compressed(bjj_ctx* c, const uint8_t* pk32, const uint8_t* 
   HIPCK(hipMemcpyAsync(c->stage + o_m, msg, n * 32, hipMemcpyHostToDevice, c->stream));
   rc = bjj_eddsa_verify_compressed_dev(c, c->stage, c->stage + o_sig, c->stage + o_m, n, c->stage + o_ok, nullptr);
   if (rc) return rc;
+  HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+
+int bjj_scalar_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out) {
+  CHECK_CTX(c, "bjj_scalar_keys");
+  if (n == 0) return BJJ_OK;
+  if (!keys || !out) return set_err(BJJ_E_INVALID, "bjj_scalar_keys: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_out = up16(n * 32);
+  int rc = ensure_stage(c, o_out + n * 32); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage, keys, n * 32, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_scalar_keys_dev(c, c->stage, n, c->stage + o_out, nullptr); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+int bjj_public_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out_xy) {
+  CHECK_CTX(c, "bjj_public_keys");
+  if (n == 0) return BJJ_OK;
+  if (!keys || !out_xy) return set_err(BJJ_E_INVALID, "bjj_public_keys: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_out = up16(n * 32);
+  int rc = ensure_stage(c, o_out + n * 64); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage, keys, n * 32, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_public_keys_dev(c, c->stage, n, c->stage + o_out, nullptr); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(out_xy, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return BJJ_OK;
+}
+int bjj_sign(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
+  CHECK_CTX(c, "bjj_sign");
+  if (n == 0) return BJJ_OK;
+  if (!keys || !msgs || !out_r || !out_s || !ok) return set_err(BJJ_E_INVALID, "bjj_sign: NULL buffer");
+  HIPCK(hipSetDevice(c->device));
+  size_t o_m = up16(n * 32), o_r = o_m + up16(n * 32), o_s = o_r + up16(n * 64), o_ok = o_s + up16(n * 32);
+  int rc = ensure_stage(c, o_ok + n); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(c->stage, keys, n * 32, hipMemcpyHostToDevice, c->stream));
+  HIPCK(hipMemcpyAsync(c->stage + o_m, msgs, n * 32, hipMemcpyHostToDevice, c->stream));
+  rc = bjj_sign_dev(c, c->stage, c->stage + o_m, n, c->stage + o_r, c->stage + o_s, c->stage + o_ok, nullptr);
+  if (rc) return rc;
+  HIPCK(hipMemcpyAsync(out_r, c->stage + o_r, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipMemcpyAsync(out_s, c->stage + o_s, n * 32, hipMemcpyDeviceToHost, c->stream));
   HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
   HIPCK(hipStreamSynchronize(c->stream));
   return BJJ_OK;

@@ -25,6 +25,8 @@ struct Consts {
   Fr A, D;          // reference curve constants, Montgomery
   Fr F;             // sqrt(-A), Montgomery
   Fr FINV_PLAIN;    // 1/F, canonical (so that mont_mul(x_mont, FINV_PLAIN) is canonical x/F)
+  Fr FINV;          // 1/F, Montgomery
+  Fr L_R1, L_R2;    // plain 2^261 mod l, 2^522 mod l (Montgomery constants of the mod-l arithmetic)
   Fr DP, D2P, DPINV;  // D', 2D', 1/D' Montgomery
   Fr B8X, B8Y;      // generator, Montgomery (reference curve)
   Fr TS_G;          // generator of the 2^28-order subgroup (Tonelli-Shanks), Montgomery

@@ -242,6 +242,12 @@ def main():
         n += 1
     o.append("#define BJJ_K_TS_G     %s  // %d^((r-1)/2^28): order 2^28" % (limbs32(mont(pow(n, ts_s, Q))), n))
     o.append("#define BJJ_K_HALFQ    %s  // PLAIN (r-1)/2" % limbs32((Q - 1) // 2))
+    o.append("#define BJJ_K_FINV     %s  // 1/sqrt(-A), Montgomery" % limbs32(mont(inv(f))))
+    # arithmetic mod l (scalar side of sign, lib.rs:328, 335-339): Montgomery radix 2^261 as well
+    Lm = SUBORDER
+    o.append("#define BJJ_L_NINV29   0x%08xu  // -l^-1 mod 2^29" % ((-pow(Lm, -1, 1 << 29)) % (1 << 29)))
+    o.append("#define BJJ_K_L_R1     %s  // PLAIN 2^261 mod l" % limbs32(R % Lm))
+    o.append("#define BJJ_K_L_R2     %s  // PLAIN 2^522 mod l" % limbs32(R * R % Lm))
     o.append("#define BJJ_K_ORDER    %s  // PLAIN integer 8*l" % limbs32(ORDER))
     o.append("#define BJJ_K_ORDER2   %s  // PLAIN 2*8*l" % limbs32(2 * ORDER))
     o.append("#define BJJ_K_ORDER4   %s  // PLAIN 4*8*l" % limbs32(4 * ORDER))

@@ -18,6 +18,9 @@
  *                        src/lib.rs:88-131 + 70-85 on affine inputs (z = 1)
  *   bjj_compress_points  Point::compress(&self)      src/lib.rs:166-178
  *   bjj_decompress_points decompress_point(bb)       src/lib.rs:192-224 (+ utils.rs modinv/modsqrt)
+ *   bjj_scalar_keys      PrivateKey::scalar_key()    src/lib.rs:284-302 (Blake-512, prune, >> 3)
+ *   bjj_public_keys      PrivateKey::public()        src/lib.rs:304-306
+ *   bjj_sign             PrivateKey::sign(msg)       src/lib.rs:308-342
  *   bjj_eddsa_verify_compressed  decompress_point(pk), decompress_signature(sig)
  *                        (src/lib.rs:260-268), then verify -- the wire-format ingest path
  *
@@ -105,6 +108,13 @@ int bjj_decompress_points(bjj_ctx* ctx, const uint8_t* in /* n*32 */, size_t n, 
  * decompress (the reference returns Err before verify is reached). */
 int bjj_eddsa_verify_compressed(bjj_ctx* ctx, const uint8_t* pk /* n*32 */, const uint8_t* sig /* n*64 */,
                                 const uint8_t* msg /* n*32 */, size_t n, uint8_t* ok /* n */);
+/* Signer side.  keys: the 32-byte PrivateKey.key; msg as for verify.  bjj_sign: ok[i] = 0 where the
+ * reference returns Err ("msg outside the Finite Field", msg > Q, src/lib.rs:309-311; outputs zeroed);
+ * out_s is the canonical integer s < l that Signature.s holds. */
+int bjj_scalar_keys(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, size_t n, uint8_t* out /* n*32 */);
+int bjj_public_keys(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, size_t n, uint8_t* out_xy /* n*64 */);
+int bjj_sign(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, const uint8_t* msgs /* n*32 */, size_t n,
+             uint8_t* out_r_xy /* n*64 */, uint8_t* out_s /* n*32 */, uint8_t* ok /* n */);
 
 /* ---- device-pointer batch API (asynchronous on `stream`) -------------------- */
 int bjj_mul_fixed_base_dev(bjj_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* stream);
@@ -115,6 +125,10 @@ int bjj_eddsa_verify_dev(bjj_ctx* ctx, const void* d_pk_xy, const void* d_r_xy, 
                          const void* d_msg, size_t n, void* d_ok, void* stream);
 int bjj_point_add_dev(bjj_ctx* ctx, const void* d_p_xy, const void* d_q_xy, size_t n, void* d_out_xy,
                       void* stream);
+int bjj_scalar_keys_dev(bjj_ctx* ctx, const void* d_keys, size_t n, void* d_out, void* stream);
+int bjj_public_keys_dev(bjj_ctx* ctx, const void* d_keys, size_t n, void* d_out_xy, void* stream);
+int bjj_sign_dev(bjj_ctx* ctx, const void* d_keys, const void* d_msgs, size_t n, void* d_out_r_xy, void* d_out_s,
+                 void* d_ok, void* stream);
 int bjj_compress_points_dev(bjj_ctx* ctx, const void* d_pts_xy, size_t n, void* d_out, void* stream);
 int bjj_decompress_points_dev(bjj_ctx* ctx, const void* d_in, size_t n, void* d_out_xy, void* d_ok, void* stream);
 int bjj_eddsa_verify_compressed_dev(bjj_ctx* ctx, const void* d_pk, const void* d_sig, const void* d_msg, size_t n,

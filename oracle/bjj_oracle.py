@@ -268,6 +268,100 @@ def poseidon(inputs):
 
 
 # ---------------------------------------------------------------------------
+# Blake-512 (the original BLAKE, SHA-3 finalist -- NOT BLAKE2), third-party blake-hash 0.4.0 /
+# blake 2.0.1 (Cargo.toml:17-18), called through blh() at lib.rs:226-237.  Restated from the
+# published specification; pinned by the digest KAT of lib.rs:695-696.
+# ---------------------------------------------------------------------------
+_BLAKE_IV = [0x6A09E667F3BCC908, 0xBB67AE8584CAA73B, 0x3C6EF372FE94F82B, 0xA54FF53A5F1D36F1,
+             0x510E527FADE682D1, 0x9B05688C2B3E6C1F, 0x1F83D9ABFB41BD6B, 0x5BE0CD19137E2179]
+_BLAKE_C = [0x243F6A8885A308D3, 0x13198A2E03707344, 0xA4093822299F31D0, 0x082EFA98EC4E6C89,
+            0x452821E638D01377, 0xBE5466CF34E90C6C, 0xC0AC29B7C97C50DD, 0x3F84D5B5B5470917,
+            0x9216D5D98979FB1B, 0xD1310BA698DFB5AC, 0x2FFD72DBD01ADFB7, 0xB8E1AFED6A267E96,
+            0xBA7C9045F12C7F99, 0x24A19947B3916CF7, 0x0801F2E2858EFC16, 0x636920D871574E69]
+_BLAKE_SIGMA = [
+    [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15], [14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3],
+    [11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4], [7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8],
+    [9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13], [2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9],
+    [12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11], [13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10],
+    [6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5], [10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0]]
+
+
+def _ror64(x, n):
+    return ((x >> n) | (x << (64 - n))) & MASK64_
+
+
+MASK64_ = (1 << 64) - 1
+
+
+def _blake_compress(h, block, t):
+    m = [int.from_bytes(block[8 * i:8 * i + 8], "big") for i in range(16)]
+    c = _BLAKE_C
+    v = h[:] + [c[0], c[1], c[2], c[3], c[4] ^ (t & MASK64_), c[5] ^ (t & MASK64_), c[6] ^ (t >> 64), c[7] ^ (t >> 64)]
+
+    def g(a, b, cc, d, r, i):
+        j, k = _BLAKE_SIGMA[r % 10][2 * i], _BLAKE_SIGMA[r % 10][2 * i + 1]
+        v[a] = (v[a] + v[b] + (m[j] ^ c[k])) & MASK64_
+        v[d] = _ror64(v[d] ^ v[a], 32)
+        v[cc] = (v[cc] + v[d]) & MASK64_
+        v[b] = _ror64(v[b] ^ v[cc], 25)
+        v[a] = (v[a] + v[b] + (m[k] ^ c[j])) & MASK64_
+        v[d] = _ror64(v[d] ^ v[a], 16)
+        v[cc] = (v[cc] + v[d]) & MASK64_
+        v[b] = _ror64(v[b] ^ v[cc], 11)
+
+    for r in range(16):
+        g(0, 4, 8, 12, r, 0); g(1, 5, 9, 13, r, 1); g(2, 6, 10, 14, r, 2); g(3, 7, 11, 15, r, 3)
+        g(0, 5, 10, 15, r, 4); g(1, 6, 11, 12, r, 5); g(2, 7, 8, 13, r, 6); g(3, 4, 9, 14, r, 7)
+    return [h[i] ^ v[i] ^ v[i + 8] for i in range(8)]
+
+
+def blake512(msg):
+    """64-byte digest.  Padding: 1-bit, zeros, 1-bit, 128-bit big-endian bit length; the counter t is the
+    number of message bits hashed up to and including the block (0 for a block of pure padding)."""
+    msg = bytes(msg)
+    h = _BLAKE_IV[:]
+    nbits = len(msg) * 8
+    rem = len(msg) % 128
+    padlen = (111 - rem) if rem <= 111 else (239 - rem)
+    p = bytearray(msg) + (b"\x81" if padlen == 0 else b"\x80" + b"\x00" * (padlen - 1) + b"\x01") + nbits.to_bytes(16, "big")
+    for blk in range(len(p) // 128):
+        t = min(nbits, (blk + 1) * 1024) if blk * 1024 < nbits else 0
+        h = _blake_compress(h, bytes(p[128 * blk:128 * blk + 128]), t)
+    return b"".join(x.to_bytes(8, "big") for x in h)
+
+
+# ---------------------------------------------------------------------------
+# PrivateKey (lib.rs:270-342)
+# ---------------------------------------------------------------------------
+def scalar_key(key):
+    """PrivateKey::scalar_key, lib.rs:284-302: Blake-512, RFC 8032 pruning of the low half, >> 3."""
+    h = bytearray(blake512(bytes(key))[:32])
+    h[0] &= 0xF8
+    h[31] &= 0x7F
+    h[31] |= 0x40
+    return int.from_bytes(bytes(h), "little") >> 3
+
+
+def public(key):
+    """PrivateKey::public, lib.rs:304-306."""
+    return mul_scalar(B8, scalar_key(key))
+
+
+def sign(key, msg):
+    """PrivateKey::sign, lib.rs:308-342 -> (R, s) or None where the reference returns Err (msg > Q)."""
+    if msg > Q:                                              # lib.rs:309-311
+        return None
+    h = blake512(bytes(key))                                 # lib.rs:316
+    msg32 = int(msg).to_bytes(32, "little")                  # lib.rs:318-320
+    r = int.from_bytes(blake512(h[32:64] + msg32), "little") % SUBORDER   # lib.rs:323-328
+    r_b8 = mul_scalar(B8, r)                                 # lib.rs:329
+    a = public(key)                                          # lib.rs:330
+    hm = poseidon([r_b8[0], r_b8[1], a[0], a[1], msg % Q])   # lib.rs:332-333
+    s = (r + hm * (scalar_key(key) << 3)) % SUBORDER         # lib.rs:335-339
+    return r_b8, s
+
+
+# ---------------------------------------------------------------------------
 # verify (lib.rs:395-412)
 # ---------------------------------------------------------------------------
 def verify(pk, sig_r, sig_s, msg):

@@ -12,6 +12,9 @@
  *                                               add also used for doubling)
  *   test_bit               src/lib.rs:188-190
  *   verify                 src/lib.rs:395-412
+ *   blh / scalar_key / public / sign   src/lib.rs:226-237, 284-342 (Blake-512: third-party
+ *                          blake-hash 0.4.0, Cargo.toml:17; restated from the BLAKE specification and
+ *                          pinned by the digest KAT of src/lib.rs:695-696)
  *   compress / decompress_point / decompress_signature
  *                          src/lib.rs:166-178, 192-224, 245-268 with utils.rs:11-29 (modinv),
  *                          109-160 (Tonelli-Shanks modsqrt), 215-223 (legendre_symbol)
@@ -262,6 +265,111 @@ static int verify1(const uint8_t *pk, const uint8_t *rb8, const uint8_t *s, cons
 }
 
 
+/* ---- Blake-512 (original BLAKE; lib.rs:226-237 via blake-hash) ---------- */
+static const uint64_t BLAKE_IV[8] = {0x6A09E667F3BCC908ULL, 0xBB67AE8584CAA73BULL, 0x3C6EF372FE94F82BULL, 0xA54FF53A5F1D36F1ULL,
+                                     0x510E527FADE682D1ULL, 0x9B05688C2B3E6C1FULL, 0x1F83D9ABFB41BD6BULL, 0x5BE0CD19137E2179ULL};
+static const uint64_t BLAKE_C[16] = {0x243F6A8885A308D3ULL, 0x13198A2E03707344ULL, 0xA4093822299F31D0ULL, 0x082EFA98EC4E6C89ULL,
+                                     0x452821E638D01377ULL, 0xBE5466CF34E90C6CULL, 0xC0AC29B7C97C50DDULL, 0x3F84D5B5B5470917ULL,
+                                     0x9216D5D98979FB1BULL, 0xD1310BA698DFB5ACULL, 0x2FFD72DBD01ADFB7ULL, 0xB8E1AFED6A267E96ULL,
+                                     0xBA7C9045F12C7F99ULL, 0x24A19947B3916CF7ULL, 0x0801F2E2858EFC16ULL, 0x636920D871574E69ULL};
+static const uint8_t BLAKE_SIGMA[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+static uint64_t ror64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+static void blake_compress(uint64_t h[8], const uint8_t blk[128], uint64_t t) {
+  uint64_t m[16], v[16];
+  for (int i = 0; i < 16; i++) { m[i] = 0; for (int b = 0; b < 8; b++) m[i] = (m[i] << 8) | blk[8 * i + b]; }
+  for (int i = 0; i < 8; i++) v[i] = h[i];
+  for (int i = 0; i < 4; i++) v[8 + i] = BLAKE_C[i];
+  v[12] = BLAKE_C[4] ^ t; v[13] = BLAKE_C[5] ^ t; v[14] = BLAKE_C[6]; v[15] = BLAKE_C[7];
+#define BG(a, b, c, d, i)                                                   \
+  do { int j = BLAKE_SIGMA[r % 10][2 * (i)], k = BLAKE_SIGMA[r % 10][2 * (i) + 1]; \
+    v[a] += v[b] + (m[j] ^ BLAKE_C[k]); v[d] = ror64(v[d] ^ v[a], 32); v[c] += v[d]; v[b] = ror64(v[b] ^ v[c], 25); \
+    v[a] += v[b] + (m[k] ^ BLAKE_C[j]); v[d] = ror64(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = ror64(v[b] ^ v[c], 11); } while (0)
+  for (int r = 0; r < 16; r++) {
+    BG(0, 4, 8, 12, 0); BG(1, 5, 9, 13, 1); BG(2, 6, 10, 14, 2); BG(3, 7, 11, 15, 3);
+    BG(0, 5, 10, 15, 4); BG(1, 6, 11, 12, 5); BG(2, 7, 8, 13, 6); BG(3, 4, 9, 14, 7);
+  }
+#undef BG
+  for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+}
+static void blake512(const uint8_t *msg, size_t len, uint8_t out[64]) { /* len < 2^61 */
+  uint64_t h[8]; memcpy(h, BLAKE_IV, sizeof(h));
+  uint64_t nbits = (uint64_t)len * 8, done = 0;
+  uint8_t blk[128];
+  while (len - done >= 128) { blake_compress(h, msg + done, (done + 128) * 8); done += 128; }
+  size_t rem = len - done;
+  memset(blk, 0, 128); memcpy(blk, msg + done, rem);
+  if (rem <= 111) {
+    blk[rem] |= 0x80; blk[111] |= 0x01;
+    for (int i = 0; i < 8; i++) blk[127 - i] = (uint8_t)(nbits >> (8 * i));
+    blake_compress(h, blk, rem ? nbits : 0);
+  } else {
+    blk[rem] |= 0x80;
+    blake_compress(h, blk, nbits);
+    memset(blk, 0, 128); blk[111] = 0x01;
+    for (int i = 0; i < 8; i++) blk[127 - i] = (uint8_t)(nbits >> (8 * i));
+    blake_compress(h, blk, 0);
+  }
+  for (int i = 0; i < 8; i++) for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(h[i] >> (56 - 8 * b));
+}
+
+/* ---- PrivateKey::scalar_key / public / sign (lib.rs:284-342) ------------ */
+static const uint64_t SUBORDER_L[4] = {0x677297dc392126f1ULL, 0xab3eedb83920ee0aULL, 0x370a08b6d0302b0bULL, 0x060c89ce5c263405ULL};
+/* x (nw 64-bit words, LE) mod l by binary long division; out 4 words */
+static void mod_l(const uint64_t *x, int nw, uint64_t out[4]) {
+  uint64_t r[5] = {0, 0, 0, 0, 0};
+  for (int bit = nw * 64 - 1; bit >= 0; bit--) {
+    for (int i = 4; i > 0; i--) r[i] = (r[i] << 1) | (r[i - 1] >> 63);
+    r[0] = (r[0] << 1) | ((x[bit / 64] >> (bit % 64)) & 1);
+    /* r >= l ? */
+    int ge = r[4] != 0;
+    if (!ge) { ge = 1; for (int i = 3; i >= 0; i--) { if (r[i] > SUBORDER_L[i]) break; if (r[i] < SUBORDER_L[i]) { ge = 0; break; } } }
+    if (ge) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)r[i] - SUBORDER_L[i] - br; r[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } r[4] -= br; }
+  }
+  memcpy(out, r, 32);
+}
+static void scalar_key_pruned(const uint8_t key[32], uint8_t h64[64], uint8_t pruned[32]) {
+  blake512(key, 32, h64);                         /* lib.rs:292 */
+  memcpy(pruned, h64, 32);
+  pruned[0] &= 0xF8; pruned[31] &= 0x7F; pruned[31] |= 0x40;   /* lib.rs:297-299 */
+}
+static void shr3(const uint8_t in[32], uint8_t out[32]) {         /* sk >> 3, lib.rs:301-302 */
+  for (int i = 0; i < 32; i++) out[i] = (uint8_t)((in[i] >> 3) | (i < 31 ? (in[i + 1] << 5) : 0));
+}
+/* returns 1 = Ok, 0 = Err ("msg outside the Finite Field", lib.rs:309-311) */
+static int sign1(const uint8_t key[32], const uint8_t msg[32], uint8_t out_r[64], uint8_t out_s[32]) {
+  fr_t m; memcpy(m.l, msg, 32);
+  if (fr_geq(&m, &MODULUS) && !fr_eq(&m, &MODULUS)) return 0;
+  uint8_t h[64], pruned[32], sk[32];
+  scalar_key_pruned(key, h, pruned);              /* lib.rs:316 */
+  uint8_t rb[64]; memcpy(rb, h + 32, 32); memcpy(rb + 32, msg, 32);   /* lib.rs:318-325 */
+  uint8_t rh[64]; blake512(rb, 64, rh);           /* lib.rs:326 */
+  uint64_t rw[8], r[4]; memcpy(rw, rh, 64);       /* from_bytes_le */
+  mod_l(rw, 8, r);                                /* lib.rs:328 */
+  point_t rp, ap;
+  mul_scalar(&rp, &C_B8, (const uint8_t *)r, 32); /* lib.rs:329 */
+  shr3(pruned, sk);
+  mul_scalar(&ap, &C_B8, sk, 32);                 /* lib.rs:330 (public) */
+  fr_t in[5] = {rp.x, rp.y, ap.x, ap.y, ZERO};
+  fr_from_le(&in[4], msg);
+  fr_t hm; poseidon5(&hm, in);                    /* lib.rs:332-333 */
+  uint8_t hmb[32]; fr_to_le(hmb, &hm);
+  /* s = r + hm * (sk << 3) mod l ; sk << 3 == pruned (its low 3 bits are already 0) */
+  uint64_t a[4], b[4], prod[9] = {0};
+  memcpy(a, hmb, 32); memcpy(b, pruned, 32);
+  for (int i = 0; i < 4; i++) { u128 c = 0; for (int j = 0; j < 4; j++) { c += (u128)a[i] * b[j] + prod[i + j]; prod[i + j] = (uint64_t)c; c >>= 64; } prod[i + 4] = (uint64_t)c; }
+  u128 c = 0;
+  for (int i = 0; i < 9; i++) { c += (u128)prod[i] + (i < 4 ? r[i] : 0); prod[i] = (uint64_t)c; c >>= 64; }
+  uint64_t s[4]; mod_l(prod, 9, s);               /* lib.rs:335-339 */
+  fr_to_le(out_r, &rp.x); fr_to_le(out_r + 32, &rp.y);
+  memcpy(out_s, s, 32);
+  return 1;
+}
+
 /* ---- codec (lib.rs:166-178, 192-224; utils.rs:109-160, 215-223) -------- */
 static void fr_pow(fr_t *out, const fr_t *base, const uint64_t e[4]) {
   fr_t r = R1;
@@ -413,9 +521,23 @@ EXPORT int bjjref_verify_compressed(const uint8_t *pk32, const uint8_t *sig64, c
   return verify1(pk, r, sig64 + 32, msg);
 }
 
+EXPORT void bjjref_blake512(const uint8_t *msg, size_t len, uint8_t *out) { blake512(msg, len, out); }
+EXPORT void bjjref_scalar_key(const uint8_t *key, uint8_t *out32) {
+  uint8_t h[64], pr[32]; scalar_key_pruned(key, h, pr); shr3(pr, out32);
+}
+EXPORT void bjjref_public(const uint8_t *key, uint8_t *out_xy) {
+  uint8_t sk[32]; bjjref_scalar_key(key, sk);
+  bjjref_mul_scalar(NULL, sk, 32, out_xy);
+}
+EXPORT int bjjref_sign(const uint8_t *key, const uint8_t *msg, uint8_t *out_r, uint8_t *out_s) {
+  ensure_init();
+  if (!sign1(key, msg, out_r, out_s)) { memset(out_r, 0, 64); memset(out_s, 0, 32); return 0; }
+  return 1;
+}
+
 /* ---- threaded batch drivers (CPU baseline + bulk expected values) ------ */
 typedef struct {
-  int kind; /* 0 fixed-base, 1 var-base, 2 poseidon5, 3 verify, 4 decompress, 5 compress, 6 verify-compressed */
+  int kind; /* 0 fixed-base, 1 var-base, 2 poseidon5, 3 verify, 4 decompress, 5 compress, 6 verify-compressed, 7 sign, 8 public */
   const uint8_t *a, *b, *c, *d; uint8_t *out; size_t lo, hi;
 } job_t;
 static void *worker(void *arg) {
@@ -429,6 +551,8 @@ static void *worker(void *arg) {
       case 4: ((uint8_t *)j->b)[i] = (uint8_t)bjjref_decompress_point(j->a + 32 * i, j->out + 64 * i); break;
       case 5: bjjref_compress_point(j->a + 64 * i, j->out + 32 * i); break;
       case 6: j->out[i] = (uint8_t)bjjref_verify_compressed(j->a + 32 * i, j->b + 64 * i, j->c + 32 * i); break;
+      case 7: ((uint8_t *)j->d)[i] = (uint8_t)bjjref_sign(j->a + 32 * i, j->b + 32 * i, j->out + 64 * i, (uint8_t *)j->c + 32 * i); break;
+      case 8: bjjref_public(j->a + 32 * i, j->out + 64 * i); break;
     }
   }
   return NULL;
@@ -469,4 +593,11 @@ EXPORT void bjjref_compress_batch(const uint8_t *in_xy, size_t n, uint8_t *out, 
 EXPORT void bjjref_verify_compressed_batch(const uint8_t *pk32, const uint8_t *sig64, const uint8_t *msg, size_t n,
                                            uint8_t *ok, int nthreads) {
   run_batch(6, pk32, sig64, msg, NULL, ok, n, nthreads);
+}
+EXPORT void bjjref_sign_batch(const uint8_t *keys, const uint8_t *msgs, size_t n, uint8_t *out_r, uint8_t *out_s,
+                              uint8_t *ok, int nthreads) {
+  run_batch(7, keys, msgs, out_s, ok, out_r, n, nthreads);
+}
+EXPORT void bjjref_public_batch(const uint8_t *keys, size_t n, uint8_t *out_xy, int nthreads) {
+  run_batch(8, keys, NULL, NULL, NULL, out_xy, n, nthreads);
 }

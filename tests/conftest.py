@@ -90,6 +90,22 @@ class Oracle:
                                                 self._p(out), self.threads)
         return out
 
+    def sign(self, keys, msgs):
+        k = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1)
+        m = np.ascontiguousarray(msgs, dtype=np.uint8).reshape(-1)
+        n = k.size // 32
+        r, s, ok = np.empty(n * 64, np.uint8), np.empty(n * 32, np.uint8), np.empty(n, np.uint8)
+        self.lib.bjjref_sign_batch(self._p(k), self._p(m), ctypes.c_size_t(n), self._p(r), self._p(s), self._p(ok),
+                                   self.threads)
+        return r.reshape(n, 64), s.reshape(n, 32), ok
+
+    def public_keys(self, keys):
+        k = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1)
+        n = k.size // 32
+        out = np.empty(n * 64, np.uint8)
+        self.lib.bjjref_public_batch(self._p(k), ctypes.c_size_t(n), self._p(out), self.threads)
+        return out.reshape(n, 64)
+
     def point_add(self, p, q):
         p = np.ascontiguousarray(p, dtype=np.uint8).reshape(-1, 64)
         q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 64)

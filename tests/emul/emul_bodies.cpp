@@ -6,11 +6,11 @@
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
-#include "../../babyjubjub-rs_amd/csrc/bjj_device.hpp"
+#include "../../babyjubjub-rs_amd/csrc/sign.hpp"
 #include "../../babyjubjub-rs_amd/csrc/bjj_constants.inc"
 using namespace bjj;
 static const Consts K = {
-    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y, BJJ_K_TS_G, BJJ_K_HALFQ,
+    BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_FINV, BJJ_K_L_R1, BJJ_K_L_R2, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y, BJJ_K_TS_G, BJJ_K_HALFQ,
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
     BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M};
 static std::vector<u32> g_table; static int g_W = 0, g_nwin = 0;
@@ -48,6 +48,19 @@ void emul_poseidon5(const uint8_t* in, uint8_t* out) {
   Fr h[5]; alignas(16) u32 w[8];
   for (int j = 0; j < 5; j++) { memcpy(w, in + 32 * j, 32); h[j] = fr_to_mont_words(w); }
   fr_from_mont_words(poseidon5(h, K), w); memcpy(out, w, 32);
+}
+void emul_blake512(const uint8_t* msg, int nbytes, uint8_t* out) {  // nbytes in {32, 64}
+  alignas(16) u32 w[16], d[16]; memcpy(w, msg, nbytes); blake512_words(w, nbytes / 4, d); memcpy(out, d, 64);
+}
+void emul_scalar_key(const uint8_t* key, uint8_t* out) {
+  alignas(16) u32 k[8], sk[8], pr[8], hi[8]; memcpy(k, key, 32); scalar_key_words(k, sk, pr, hi); memcpy(out, sk, 32);
+}
+int emul_sign(const uint8_t* key, const uint8_t* msg, int W, uint8_t* out_r, uint8_t* out_s) {
+  ensure_table(W);
+  alignas(16) u32 k[8], m[8], rx[8], ry[8], s[8]; memcpy(k, key, 32); memcpy(m, msg, 32);
+  bool ok = sign_item(k, m, table_ptr(), g_W, g_nwin, rx, ry, s, K);
+  if (!ok) { memset(out_r, 0, 64); memset(out_s, 0, 32); return 0; }
+  memcpy(out_r, rx, 32); memcpy(out_r + 32, ry, 32); memcpy(out_s, s, 32); return 1;
 }
 int emul_decompress(const uint8_t* in, uint8_t* out) {
   alignas(16) u32 w[8], ox[8], oy[8]; memcpy(w, in, 32);

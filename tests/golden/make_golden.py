@@ -55,6 +55,8 @@ def kats():
              "x_le_bytes": "30f1635ba7d56f9cb32c3ffbe6dca508a68c7f43936af11a23c785ce98cb3404"}]},
         "circomlib_testvector": {
             "src": "src/lib.rs:689-738",
+            "key": "0001020304050607080900010203040506070809000102030405060708090001",
+            "blake512": "c992db23d6290c70ffcc02f7abeb00b9d00fa8b43e55d7949c28ba6be7545d3253882a61bd004a236ef1cdba01b27ba0aedfb08eefdbfb7c19657c880b43ddf1",
             "scalar_key": 6466070937662820620902051049739362987537906109895538826186780010858059362905,
             "pk": (0x1d5ac1f31407018b7d413a4f52c8f74463b30e6ac2238220ad8b254de4eaa3a2,
                    0x1e1de8a908826c3f9ac2e0ceee929ecd0caf3b99b3ef24523aaab796a6f733c4),
@@ -176,6 +178,19 @@ def oracle_vectors():
     vc.append({"pk": good["pk"], "sig": o.to_le32(3).hex() + good["sig"][64:], "msg": good["msg"],
                "ok": 2 if o.decompress_point(o.to_le32(3)) is None else 0, "note": "R replaced by y = 3"})
     out["verify_compressed"] = vc
+
+    # ---- signer row: scalar_key / public / sign (lib.rs:284-342), keys from the SEED_KEYS stream
+    rs = o.SplitMix64(o.SEED_KEYS ^ 0x5167)
+    sg = []
+    for i in range(10):
+        key = o.to_le32(rs.u256())
+        m = [0, 1, Q, Q - 1, 5, 123456789012345678901234567890][i] if i < 6 else rm.u256() % Q
+        R, S = o.sign(key, m)
+        sg.append({"key": key.hex(), "msg": hx(m), "scalar_key": hx(o.scalar_key(key)), "pk": [hx(v) for v in o.public(key)],
+                   "r_b8": [hx(R[0]), hx(R[1])], "s": hx(S), "ok": True})
+    sg.append({"key": sg[0]["key"], "msg": hx(Q + 1), "scalar_key": sg[0]["scalar_key"], "pk": sg[0]["pk"],
+               "r_b8": [hx(0), hx(0)], "s": hx(0), "ok": False})
+    out["sign"] = sg
     return out
 
 
