@@ -10,6 +10,7 @@
 //   verify(pk, sig, msg) -> bool                              lib.rs:395-412
 //   Point::compress, decompress_point, Signature::compress,
 //   decompress_signature (wire format)                        lib.rs:166-178, 192-224, 245-268
+//   PrivateKey { key }, import, scalar_key, public, sign       lib.rs:270-342
 //   + *_batch forms (what the GPU is for)
 //
 // Every arithmetic operation runs in libbjj_hip.so on the GPU; this header only marshals
@@ -108,6 +109,17 @@ struct Signature {  // lib.rs:239-243
   }
 };
 
+struct PrivateKey {  // lib.rs:270-342
+  std::array<uint8_t, 32> key{};
+  static PrivateKey import(const std::vector<uint8_t>& b) {  // lib.rs:275-282
+    if (b.size() != 32) throw std::invalid_argument("imported key can not be bigger than 32 bytes");
+    PrivateKey k; std::memcpy(k.key.data(), b.data(), 32); return k;
+  }
+  U256 scalar_key() const;               // lib.rs:284-302
+  Point public_key() const;              // lib.rs:304-306 (`public` is a C++ keyword)
+  Signature sign(const U256& msg) const; // lib.rs:308-342; throws std::invalid_argument where the crate returns Err
+};
+
 inline const Point& B8() {  // lib.rs:37-46
   static const Point p{Fr::from_str("5299619240641551281634865583518297030282874472190772894086521144482721001553"),
                        Fr::from_str("16950150798460657717958625567821834550301663161624707787222815936182638968203")};
@@ -170,7 +182,33 @@ inline std::vector<uint8_t> verify_compressed_batch(const std::vector<std::array
   return ok;
 }
 
+// signer side, batch: ok[i] == 0 where sign returns Err (msg > Q)
+inline std::vector<Point> public_keys_batch(const std::vector<PrivateKey>& k, Context& c = Context::global()) {
+  std::vector<Point> out(k.size());
+  check(bjj_public_keys(c.handle(), (const uint8_t*)k.data(), k.size(), (uint8_t*)out.data()), "bjj_public_keys");
+  return out;
+}
+inline std::vector<Signature> sign_batch(const std::vector<PrivateKey>& k, const std::vector<U256>& msg,
+                                         std::vector<uint8_t>& ok, Context& c = Context::global()) {
+  if (k.size() != msg.size()) throw std::runtime_error("sign_batch: length mismatch");
+  std::vector<Point> r(k.size()); std::vector<U256> s(k.size()); ok.assign(k.size(), 0);
+  check(bjj_sign(c.handle(), (const uint8_t*)k.data(), (const uint8_t*)msg.data(), k.size(), (uint8_t*)r.data(),
+                 (uint8_t*)s.data(), ok.data()), "bjj_sign");
+  std::vector<Signature> out(k.size());
+  for (size_t i = 0; i < k.size(); i++) out[i] = Signature{r[i], s[i]};
+  return out;
+}
+
 // ---- scalar (single-item) forms, same signatures as the crate ------------------------------
+inline U256 PrivateKey::scalar_key() const {
+  U256 out; check(bjj_scalar_keys(Context::global().handle(), key.data(), 1, out.le.data()), "bjj_scalar_keys"); return out;
+}
+inline Point PrivateKey::public_key() const { return public_keys_batch({*this})[0]; }
+inline Signature PrivateKey::sign(const U256& msg) const {
+  std::vector<uint8_t> ok; Signature s = sign_batch({*this}, {msg}, ok)[0];
+  if (!ok[0]) throw std::invalid_argument("msg outside the Finite Field");
+  return s;
+}
 inline std::array<uint8_t, 32> Point::compress() const { return compress_batch({*this})[0]; }
 // decompress_point(bb) -> Result<Point, String>: throws std::invalid_argument for Err (lib.rs:192-224)
 inline Point decompress_point(const std::array<uint8_t, 32>& bb) {

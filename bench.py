@@ -34,9 +34,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 ALGO_BYTES = {"fixed_base": 96, "var_base": 160, "verify": 193, "poseidon5": 192,
-              "verify_compressed": 129, "decompress": 97}  # 8(f) row 1: 32 pk + 64 sig + 32 msg -> 1; 32 -> 64 + 1
+              "verify_compressed": 129, "decompress": 97, "sign": 160}  # 8(f) row 1: 32 pk + 64 sig + 32 msg -> 1; 32 -> 64 + 1
 UNITS = {"fixed_base": "scalar mults/s", "var_base": "scalar mults/s", "verify": "verifies/s", "poseidon5": "hashes/s",
-         "verify_compressed": "verifies/s", "decompress": "points/s"}
+         "verify_compressed": "verifies/s", "decompress": "points/s", "sign": "signatures/s"}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -76,6 +76,13 @@ class Workload:
             self.host["in"] = w.random_u256(w.SEED_MSGS, 5 * n, 5 * offset, top_bits_cleared=3).reshape(n, 160)
             self.d_in = up(self.host["in"])
             self.d_out = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+        elif kind == "sign":
+            self.host["keys"] = w.random_u256(w.SEED_KEYS, n, offset)
+            self.host["msgs"] = w.random_u256(w.SEED_MSGS, n, offset, top_bits_cleared=3)
+            self.d_keys, self.d_msgs = up(self.host["keys"]), up(self.host["msgs"])
+            self.d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+            self.d_s = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+            self.d_ok = torch.empty(n, dtype=torch.uint8, device=dev)
         elif kind == "decompress":
             pts = ctx.mul_fixed_base(w.random_u256(w.SEED_POINTS, n, offset))
             self.host["comp"] = ctx.compress_points(pts)
@@ -110,6 +117,9 @@ class Workload:
             c.mul_var_base_dev(self.d_pts.data_ptr(), self.d_sc.data_ptr(), n, self.d_out.data_ptr(), s)
         elif self.kind == "poseidon5":
             c.poseidon5_dev(self.d_in.data_ptr(), n, self.d_out.data_ptr(), s)
+        elif self.kind == "sign":
+            c.sign_dev(self.d_keys.data_ptr(), self.d_msgs.data_ptr(), n, self.d_out.data_ptr(), self.d_s.data_ptr(),
+                       self.d_ok.data_ptr(), s)
         elif self.kind == "decompress":
             c.decompress_points_dev(self.d_in.data_ptr(), n, self.d_out.data_ptr(), self.d_ok.data_ptr(), s)
         elif self.kind == "verify_compressed":
@@ -133,6 +143,11 @@ class Workload:
         if self.kind == "poseidon5":
             got = self.d_out.view(n, 32)[torch.from_numpy(idx).to(self.d_out.device)].cpu().numpy()
             return bool((got == orc.poseidon5(h["in"][idx])).all())
+        if self.kind == "sign":
+            t = torch.from_numpy(idx).to(self.d_out.device)
+            ro, so, oko = orc.sign(h["keys"][idx], h["msgs"][idx])
+            return bool((self.d_out.view(n, 64)[t].cpu().numpy() == ro).all()) and \
+                bool((self.d_s.view(n, 32)[t].cpu().numpy() == so).all()) and bool(self.d_ok.cpu().numpy().all())
         if self.kind == "decompress":
             got = self.d_out.view(n, 64).cpu().numpy()
             return bool((got == h["points"]).all()) and bool(self.d_ok.cpu().numpy().all()) and \
@@ -188,6 +203,8 @@ def cpu_baseline(kind, wl, budget_cpu_s=25.0):
             o.mul_var_base(h["points"][:m], h["scalars"][:m])
         elif kind == "poseidon5":
             o.poseidon5(h["in"][:m])
+        elif kind == "sign":
+            o.sign(h["keys"][:m], h["msgs"][:m])
         elif kind == "decompress":
             o.decompress(h["comp"][:m])
         elif kind == "verify_compressed":
@@ -199,7 +216,7 @@ def cpu_baseline(kind, wl, budget_cpu_s=25.0):
     # single-thread rate on a small slice (also calibrates the sample size)
     orc.threads = 1
     m1 = {"fixed_base": 1024, "var_base": 1024, "verify": 384, "poseidon5": 2048, "verify_compressed": 384,
-          "decompress": 2048}[kind]
+          "decompress": 2048, "sign": 512}[kind]
     m1 = min(m1, wl.n)
     dt1 = run(orc, m1)
     rate1 = m1 / dt1
@@ -319,7 +336,7 @@ def main():
                 {"fixed_base": "fixed-base scalar mults/sec", "var_base": "variable-base scalar mults/sec",
                  "verify": "EdDSA-Poseidon verifies/sec", "poseidon5": "Poseidon(t=6) hashes/sec",
                  "verify_compressed": "EdDSA-Poseidon verifies/sec (compressed pk + signature)",
-                 "decompress": "point decompressions/sec"}[kind], n),
+                 "decompress": "point decompressions/sec", "sign": "EdDSA-Poseidon signatures/sec"}[kind], n),
             "value": value, "unit": UNITS[kind], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
@@ -328,7 +345,8 @@ def main():
                                     "verify": "1M EdDSA-Poseidon verifies, 1/64 corrupted, BASELINE configs[3]",
                                     "poseidon5": "Poseidon t=6 hashes (component of configs[3])",
                                     "verify_compressed": "1M EdDSA-Poseidon verifies on wire-format inputs (SURVEY 8f row 1)",
-                                    "decompress": "1M decompress_point (SURVEY 8f row 1)"}[kind],
+                                    "decompress": "1M decompress_point (SURVEY 8f row 1)",
+                                    "sign": "1M PrivateKey::sign (Blake-512 x2, 2 fixed-base mults, Poseidon; SURVEY 8f row 2)"}[kind],
                        "batch_per_gpu": n, "global_batch": n * world, "window_bits": info.window_bits,
                        "fixed_base_table_mb": info.table_bytes / 1e6,
                        "limbs": "9 x 29-bit, 64-bit column accumulators (v_mad_u64_u32)",
@@ -343,7 +361,7 @@ def main():
                                   "kernel": {"fixed_base": info.kernel_fixed_base, "var_base": info.kernel_var_base,
                                              "verify": info.kernel_verify, "poseidon5": info.kernel_poseidon5,
                                              "verify_compressed": info.kernel_verify,
-                                             "decompress": b"bjj_k_decompress_points"}[kind].decode(),
+                                             "decompress": b"bjj_k_decompress_points", "sign": b"bjj_k_sign"}[kind].decode(),
                                   "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": algo,
                                   "note": "integer-ALU bound path (see DESIGN.md): HBM fraction is reported as measured"}
         orc = None

@@ -44,6 +44,15 @@ static void test_circomlib_testvector() {  // lib.rs:689-738 (everything downstr
   ASSERT_EQ(pk.x.to_hex(), std::string("1d5ac1f31407018b7d413a4f52c8f74463b30e6ac2238220ad8b254de4eaa3a2"));
   ASSERT_EQ(pk.y.to_hex(), std::string("1e1de8a908826c3f9ac2e0ceee929ecd0caf3b99b3ef24523aaab796a6f733c4"));
   U256 msg; for (int i = 0; i < 10; i++) msg.le[i] = (uint8_t)i;  // BigInt::from_bytes_le("00010203040506070809")
+  // the signer half of the same test (lib.rs:699-735): import -> scalar_key -> public -> sign
+  std::vector<uint8_t> kb(32); for (int i = 0; i < 32; i++) kb[i] = (uint8_t)(i % 10);
+  PrivateKey sk = PrivateKey::import(kb);
+  ASSERT_EQ(sk.scalar_key(), scalar_key);
+  ASSERT_TRUE(sk.public_key().equals(pk));
+  Signature made = sk.sign(msg);
+  ASSERT_EQ(made.r_b8.x.to_hex(), std::string("192b4e51adf302c8139d356d0e08e2404b5ace440ef41fc78f5c4f2428df0765"));
+  ASSERT_EQ(made.s, U256::from_str("1672775540645840396591609181675628451599263765380031905495115170613215233181"));
+  ASSERT_TRUE(verify(pk, made, msg));
   Signature sig{Point{Fr::from_hex("192b4e51adf302c8139d356d0e08e2404b5ace440ef41fc78f5c4f2428df0765"),
                       Fr::from_hex("2202bebcf57b820863e0acc88970b6ca7d987a0d513c2ddeb42e3f5d31b4eddf")},
                 U256::from_str("1672775540645840396591609181675628451599263765380031905495115170613215233181")};
