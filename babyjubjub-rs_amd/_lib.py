@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = (
     "bjj_mul_fixed_base_dev", "bjj_mul_var_base_dev", "bjj_poseidon5_dev", "bjj_eddsa_verify_dev",
     "bjj_point_add_dev", "bjj_reserve", "bjj_get_info",
     "bjj_compress_points", "bjj_decompress_points", "bjj_eddsa_verify_compressed",
+    "bjj_schnorr_verify", "bjj_schnorr_verify_dev",
     "bjj_scalar_keys", "bjj_public_keys", "bjj_sign", "bjj_scalar_keys_dev", "bjj_public_keys_dev", "bjj_sign_dev",
     "bjj_compress_points_dev", "bjj_decompress_points_dev", "bjj_eddsa_verify_compressed_dev",
 )
@@ -73,6 +74,8 @@ def load():
     lib.bjj_poseidon5.argtypes = [vp, vp, sz, vp]
     lib.bjj_eddsa_verify.argtypes = [vp, vp, vp, vp, vp, sz, vp]
     lib.bjj_point_add.argtypes = [vp, vp, vp, sz, vp]
+    lib.bjj_schnorr_verify.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    lib.bjj_schnorr_verify_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp]
     lib.bjj_mul_fixed_base_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.bjj_mul_var_base_dev.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.bjj_poseidon5_dev.argtypes = [vp, vp, sz, vp, vp]

@@ -137,6 +137,20 @@ class Context:
                                            ok.ctypes.data), "bjj_eddsa_verify")
         return ok
 
+    def schnorr_verify(self, pk, r, s, msg):
+        """verify_schnorr in bulk: 1 / 0 = Ok(true / false), 2 = Err (msg > Q).  s: 32-byte integers."""
+        a = _as_u8(pk, 64, "pk")
+        rr = _as_u8(r, 64, "r")
+        sv = _as_u8(s, 32, "s")
+        m = _as_u8(msg, 32, "msg")
+        n = sv.size // 32
+        if a.size != n * 64 or rr.size != n * 64 or m.size != n * 32:
+            raise BjjError("schnorr_verify: array lengths disagree")
+        ok = np.empty(n, dtype=np.uint8)
+        self._ck(self.lib.bjj_schnorr_verify(self.handle, a.ctypes.data, rr.ctypes.data, sv.ctypes.data, m.ctypes.data, n,
+                                             ok.ctypes.data), "bjj_schnorr_verify")
+        return ok
+
     def point_add(self, p, q):
         a = _as_u8(p, 64, "p")
         b = _as_u8(q, 64, "q")
@@ -384,6 +398,21 @@ def verify(pk, sig, msg, ctx=None):
         raise BjjError("verify: s outside the 32-byte record of the C ABI")
     ctx = ctx or default_context()
     ok = ctx.eddsa_verify([(pk.x, pk.y)], [(sig.r_b8.x, sig.r_b8.y)], [sig.s], [msg])
+    return bool(ok[0])
+
+
+def verify_schnorr(pk, m, r, s, ctx=None):
+    """verify_schnorr(pk: Point, m: BigInt, r: Point, s: BigInt) -> Result<bool, String>  (lib.rs:375-385).
+    ValueError for the reference's Err.  s may be any non-negative integer: it is reduced mod 8l on the
+    host, which is exact because it only multiplies B8 (lib.rs:377)."""
+    m, s = int(m), int(s)
+    if m < 0 or s < 0:
+        raise BjjError("verify_schnorr: negative integer")
+    if m > Q:
+        raise ValueError("msg outside the Finite Field")
+    ok = (ctx or default_context()).schnorr_verify([(pk.x, pk.y)], [(r.x, r.y)], [s % (8 * SUBORDER)], [m])
+    if ok[0] == 2:
+        raise ValueError("msg outside the Finite Field")
     return bool(ok[0])
 
 

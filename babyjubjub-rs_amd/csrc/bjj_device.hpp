@@ -114,9 +114,6 @@ BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 sc[8], co
     Niels nxt = cur;
     if (j + 1 < nwin) {
       size_t idx = ((size_t)(j + 1) << W) | scalar_window(sc, j + 1, W);
-#if defined(BJJ_EXPERIMENT) && BJJ_EXPERIMENT == 3  /* timing experiment: every lane hits the same few lines */
-      idx = ((size_t)(j + 1) << W) | (scalar_window(sc, j + 1, W) & 1);
-#endif
       nxt = load_niels(table + idx * NIELS_WORDS);
     }
     acc = ext_madd(acc, cur);
@@ -355,72 +352,99 @@ BJJ_HD bool verify_needs_exact(const VerifyIn& in, const Consts& K) {
   load_w8((const char*)in.pk + 32, w); Fr ay = fr_to_mont_words(w);
   return !ref_on_curve(ax, ay, K);
 }
-// Fast path.  Sets need_exact (and returns false) when pk or R is off the curve.
-BJJ_HD bool verify_fast(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K,
-                        bool& need_exact) {
+// Fast path of verify (src/lib.rs:395-412) and, with SCHNORR, of verify_schnorr (src/lib.rs:375-385:
+// hash input order (pk, R, msg) instead of (R, pk, msg), the hash is NOT multiplied by 8, and msg > Q is
+// an Err -- verdict 2 -- rather than `false`).  Verdict 0 / 1 / 2; need_exact is set when pk or R is off
+// the curve (the item then belongs to the exact path and the verdict returned here is meaningless).
+template <bool SCHNORR>
+BJJ_HD int verify_fast_t(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K,
+                         bool& need_exact) {
   u32 w[8];
   need_exact = false;
   load_w8(in.msg, w);
-  if (words_gt_modulus(w)) return false;                        // :396-398
+  if (words_gt_modulus(w)) return SCHNORR ? 2 : 0;              // :396-398 / :365-367
   Fr h[5];
   h[4] = fr_to_mont_words(w);                                   // :399
-  load_w8(in.r, w);                   h[0] = fr_to_mont_words(w);
-  load_w8((const char*)in.r + 32, w); h[1] = fr_to_mont_words(w);
-  load_w8(in.pk, w);                  h[2] = fr_to_mont_words(w);
-  load_w8((const char*)in.pk + 32, w); h[3] = fr_to_mont_words(w);
-  if (!(ref_on_curve(h[0], h[1], K) && ref_on_curve(h[2], h[3], K))) { need_exact = true; return false; }
+  Fr rx, ry, ax, ay;
+  load_w8(in.r, w);                    rx = fr_to_mont_words(w);
+  load_w8((const char*)in.r + 32, w);  ry = fr_to_mont_words(w);
+  load_w8(in.pk, w);                   ax = fr_to_mont_words(w);
+  load_w8((const char*)in.pk + 32, w); ay = fr_to_mont_words(w);
+  if (!(ref_on_curve(rx, ry, K) && ref_on_curve(ax, ay, K))) { need_exact = true; return 0; }
+  if (SCHNORR) { h[0] = ax; h[1] = ay; h[2] = rx; h[3] = ry; }  // :369
+  else         { h[0] = rx; h[1] = ry; h[2] = ax; h[3] = ay; }  // :400
   Fr hm = poseidon5(h, K);                                      // :400-404
   Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // canonical integer, :406
-  // s*B8 == R + 8*hm*A   <=>   8*(hm mod l)*(-A) + s*B8 == R      (group order 8l)
+  // EdDSA:   s*B8 == R + 8*hm*A  <=>  8*(hm mod l)*(-A) + s*B8 == R   (group order 8l)
+  // Schnorr: s*B8 == R + hm*A    <=>     hm*(-A)        + s*B8 == R   (hm < r < 8l: no reduction)
   u32 kw[8], sw[8];
-  fr_to_words(plain_mod_l(hm_plain, K), kw);
-  Ext negA = ext_from_ref_affine(fr_neg(h[2]), h[3], K);
+  fr_to_words(SCHNORR ? hm_plain : plain_mod_l(hm_plain, K), kw);
+  Ext negA = ext_from_ref_affine(fr_neg(ax), ay, K);
   vb_build_table(negA, vb_tbl, K);
-  Ext q = vb_mul_windowed(vb_tbl, kw, 64);                      // k < l < 2^251
-  q = ext_dbl<false>(q); q = ext_dbl<false>(q); q = ext_dbl<true>(q);
+  Ext q = vb_mul_windowed(vb_tbl, kw, 64);                      // scalar < 2^254
+  if (!SCHNORR) { q = ext_dbl<false>(q); q = ext_dbl<false>(q); q = ext_dbl<true>(q); }
   load_w8(in.s, sw);
-  q = fixed_base_accumulate(q, fb_table, W, nwin, sw);          // + s*B8   (:405)
+  q = fixed_base_accumulate(q, fb_table, W, nwin, sw);          // + s*B8   (:405 / :377)
   // compare with R on the a'=-1 curve: X == (F Rx) Z, Y == Ry Z
-  load_w8(in.r, w);                   Fr rx = fr_mul(fr_to_mont_words(w), K.F);
-  load_w8((const char*)in.r + 32, w); Fr ry = fr_to_mont_words(w);
-  return fr_eq(q.X, fr_mul(rx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z));
+  Fr fx = fr_mul(rx, K.F);
+  return (fr_eq(q.X, fr_mul(fx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z))) ? 1 : 0;
 }
-// Exact path: replays src/lib.rs:395-412 operation by operation (any input).
-BJJ_HD bool verify_exact(const VerifyIn& in, const Consts& K) {
+// Exact path: replays src/lib.rs:395-412 (or :375-385) operation by operation (any input).
+template <bool SCHNORR>
+BJJ_HD int verify_exact_t(const VerifyIn& in, const Consts& K) {
   u32 w[8];
   load_w8(in.msg, w);
-  if (words_gt_modulus(w)) return false;                        // :396-398
+  if (words_gt_modulus(w)) return SCHNORR ? 2 : 0;
   Fr h[5];
-  h[4] = fr_to_mont_words(w);                                   // :399
-  load_w8(in.r, w);                   h[0] = fr_to_mont_words(w);
-  load_w8((const char*)in.r + 32, w); h[1] = fr_to_mont_words(w);
-  load_w8(in.pk, w);                  h[2] = fr_to_mont_words(w);
-  load_w8((const char*)in.pk + 32, w); h[3] = fr_to_mont_words(w);
-  Fr hm = poseidon5(h, K);                                      // :400-404
-  Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // :406
+  h[4] = fr_to_mont_words(w);
+  Fr rx, ry, ax, ay;
+  load_w8(in.r, w);                    rx = fr_to_mont_words(w);
+  load_w8((const char*)in.r + 32, w);  ry = fr_to_mont_words(w);
+  load_w8(in.pk, w);                   ax = fr_to_mont_words(w);
+  load_w8((const char*)in.pk + 32, w); ay = fr_to_mont_words(w);
+  if (SCHNORR) { h[0] = ax; h[1] = ay; h[2] = rx; h[3] = ry; }
+  else         { h[0] = rx; h[1] = ry; h[2] = ax; h[3] = ay; }
+  Fr hm = poseidon5(h, K);
+  Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));
   u32 sw[8];
   load_w8(in.s, sw);
   Fr lx, ly, tx, ty;
-  ref_mul_scalar(K.B8X, K.B8Y, sw, 8, lx, ly, K);               // :405
+  ref_mul_scalar(K.B8X, K.B8Y, sw, 8, lx, ly, K);               // :405 / :377
   u32 h8[9], hw[8];
   fr_to_words(hm_plain, hw);
-  h8[0] = hw[0] << 3;
+  if (SCHNORR) {
 #pragma unroll
-  for (int i = 1; i < 8; i++) h8[i] = (hw[i] << 3) | (hw[i - 1] >> 29);
-  h8[8] = hw[7] >> 29;                                          // 8 * hm_b, :410
-  ref_mul_scalar(h[2], h[3], h8, 9, tx, ty, K);
-  RefProj rp; rp.x = h[0]; rp.y = h[1]; rp.z = fr_one();
+    for (int i = 0; i < 8; i++) h8[i] = hw[i];
+    h8[8] = 0;                                                  // pk.mul_scalar(&h), :381
+  } else {
+    h8[0] = hw[0] << 3;
+#pragma unroll
+    for (int i = 1; i < 8; i++) h8[i] = (hw[i] << 3) | (hw[i - 1] >> 29);
+    h8[8] = hw[7] >> 29;                                        // 8 * hm_b, :410
+  }
+  ref_mul_scalar(ax, ay, h8, 9, tx, ty, K);
+  RefProj rp; rp.x = rx; rp.y = ry; rp.z = fr_one();
   RefProj tp; tp.x = tx; tp.y = ty; tp.z = fr_one();
-  RefProj sum = ref_add(rp, tp, K);                             // :407-410
-  Fr ax, ay;
-  if (fr_is_zero(sum.z)) { ax = fr_zero(); ay = fr_zero(); }    // :71-76
-  else { Fr zi = fr_inv(sum.z); ax = fr_mul(sum.x, zi); ay = fr_mul(sum.y, zi); }
-  return fr_eq(lx, ax) && fr_eq(ly, ay);                        // :411, :180-185
+  RefProj sum = ref_add(rp, tp, K);                             // :407-410 / :382
+  Fr qx, qy;
+  if (fr_is_zero(sum.z)) { qx = fr_zero(); qy = fr_zero(); }    // :71-76
+  else { Fr zi = fr_inv(sum.z); qx = fr_mul(sum.x, zi); qy = fr_mul(sum.y, zi); }
+  return (fr_eq(lx, qx) && fr_eq(ly, qy)) ? 1 : 0;              // :411 / :384
 }
+BJJ_HD bool verify_fast(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K,
+                        bool& need_exact) {
+  return verify_fast_t<false>(in, fb_table, W, nwin, vb_tbl, K, need_exact) == 1;
+}
+BJJ_HD bool verify_exact(const VerifyIn& in, const Consts& K) { return verify_exact_t<false>(in, K) == 1; }
 BJJ_HD bool verify_item(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K) {
   bool need_exact;
   bool ok = verify_fast(in, fb_table, W, nwin, vb_tbl, K, need_exact);
   return need_exact ? verify_exact(in, K) : ok;
+}
+BJJ_HD int verify_schnorr_item(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K) {
+  bool need_exact;
+  int v = verify_fast_t<true>(in, fb_table, W, nwin, vb_tbl, K, need_exact);
+  return need_exact ? verify_exact_t<true>(in, K) : v;
 }
 
 }  // namespace bjj

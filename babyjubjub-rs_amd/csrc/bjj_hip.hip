@@ -81,11 +81,7 @@ __device__ Fr block_invert(const Fr& x, u32* lds /* NL * BJJ_EPI_BLOCK words */)
   Fr esuf = (t + 1 < BJJ_EPI_BLOCK) ? lds_get(lds, t + 1) : fr_one();
   __syncthreads();
   if (t < 64) {  // one wave inverts the workgroup product
-#ifdef BJJ_EXPERIMENT_NO_INV
-    Fr inv = total;  // timing experiment only: wrong results
-#else
     Fr inv = fr_inv(total);
-#endif
     if (t == 0) lds_put(lds, 0, inv);
   }
   __syncthreads();
@@ -162,19 +158,9 @@ __global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_fixed_base(const u32*
     u32 sc[8];
     load_w8(scalars + i * 32, sc);
     Ext p = fixed_base_mul(table, W, nwin, sc, c_K);
-#if defined(BJJ_EXPERIMENT) && BJJ_EXPERIMENT == 1   /* timing experiment: main loop only */
-    run = fr_add(run, fr_add(fr_add(p.X, p.Y), fr_add(p.Z, p.T)));
-#else
     epilogue_stash(p, run, out + i * 64, scratch + i * 16);
-#endif
   }
-#if defined(BJJ_EXPERIMENT) && BJJ_EXPERIMENT == 1
-  if (run.v[0] == 0x12345u) out[tid] = 1;
-#elif defined(BJJ_EXPERIMENT) && BJJ_EXPERIMENT == 2  /* main loop + stash, no inversion / finish */
-  if (run.v[0] == 0x12345u) out[tid] = 1;
-#else
   epilogue_run(run, n, tid, nthreads, out, scratch, lds);
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -268,13 +254,12 @@ __device__ __forceinline__ unsigned long long wave_grab(u32* cursor_words, int l
   if (lane == 0) c = atomicAdd((unsigned long long*)cursor_words, 64ULL);
   return __shfl(c, 0, 64);
 }
-__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
-                                                                   const uint8_t* __restrict__ pk,
-                                                                   const uint8_t* __restrict__ rb8,
-                                                                   const uint8_t* __restrict__ s,
-                                                                   const uint8_t* __restrict__ msg, size_t n,
-                                                                   uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
-                                                                   u32* __restrict__ wl) {
+template <bool SCHNORR>
+__device__ __forceinline__ void verify_kernel_body(const u32* __restrict__ table, int W, int nwin,
+                                                   const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
+                                                   const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg, size_t n,
+                                                   uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
+                                                   u32* __restrict__ wl) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
@@ -286,7 +271,7 @@ __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_eddsa_verify(const u32* __
     if (c + lane < nexact) {
       const size_t i = wl[WL_HDR + c + lane];
       VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
-      ok[i] = verify_exact(in, c_K) ? 1 : 0;
+      ok[i] = (uint8_t)verify_exact_t<SCHNORR>(in, c_K);
     }
   }
 #pragma unroll 1
@@ -297,10 +282,29 @@ __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_eddsa_verify(const u32* __
     if (i < n) {
       VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
       bool need_exact;
-      bool v = verify_fast(in, table, W, nwin, tbl, c_K, need_exact);
-      if (!need_exact) ok[i] = v ? 1 : 0;  // exact items were written by the first loop
+      const int v = verify_fast_t<SCHNORR>(in, table, W, nwin, tbl, c_K, need_exact);
+      if (!need_exact) ok[i] = (uint8_t)v;  // exact items were written by the first loop
     }
   }
+}
+// verify_schnorr (src/lib.rs:375-385): same structure, verdict 2 = Err (msg > Q)
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_schnorr_verify(const u32* __restrict__ table, int W, int nwin,
+                                                                     const uint8_t* __restrict__ pk,
+                                                                     const uint8_t* __restrict__ rb8,
+                                                                     const uint8_t* __restrict__ s,
+                                                                     const uint8_t* __restrict__ msg, size_t n,
+                                                                     uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
+                                                                     u32* __restrict__ wl) {
+  verify_kernel_body<true>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+}
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
+                                                                   const uint8_t* __restrict__ pk,
+                                                                   const uint8_t* __restrict__ rb8,
+                                                                   const uint8_t* __restrict__ s,
+                                                                   const uint8_t* __restrict__ msg, size_t n,
+                                                                   uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
+                                                                   u32* __restrict__ wl) {
+  verify_kernel_body<false>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
 }
 
 // ---------------------------------------------------------------------------
@@ -618,25 +622,38 @@ int bjj_poseidon5_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out, void*
   HIPCK(hipGetLastError());
   return BJJ_OK;
 }
-int bjj_eddsa_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
-                         void* d_ok, void* stream) {
-  CHECK_CTX(c, "bjj_eddsa_verify_dev");
+static int verify_launch(bjj_ctx* c, bool schnorr, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg,
+                         size_t n, void* d_ok, void* stream, const char* who) {
+  if (!c) return set_err(BJJ_E_INVALID, std::string(who) + ": ctx is NULL");
   if (n == 0) return BJJ_OK;
-  CHECK_PTR(d_pk, "bjj_eddsa_verify_dev"); CHECK_PTR(d_r, "bjj_eddsa_verify_dev");
-  CHECK_PTR(d_s, "bjj_eddsa_verify_dev"); CHECK_PTR(d_msg, "bjj_eddsa_verify_dev");
-  if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_dev: d_ok is NULL");
+  if (!d_pk || !d_r || !d_s || !d_msg || !aligned16(d_pk) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_msg))
+    return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
+  if (!d_ok) return set_err(BJJ_E_INVALID, std::string(who) + ": d_ok is NULL");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  if (n >> 32) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_dev: batches are limited to 2^32 - 1 items");
+  if (n >> 32) return set_err(BJJ_E_INVALID, std::string(who) + ": batches are limited to 2^32 - 1 items");
   HIPCK(hipMemsetAsync(c->slow, 0, WL_HDR * sizeof(u32), st));
-  hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_for(c, n, c->occ_scan)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pk,
-                     (const uint8_t*)d_r, (const uint8_t*)d_msg, n, c->slow);
+  hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_for(c, n, c->occ_scan)), dim3(BJJ_BLOCK), 0, st,
+                     (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_msg, n, c->slow);
   HIPCK(hipGetLastError());
-  hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid_for(c, n, c->occ_verify)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
-                     c->nwin, (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n,
-                     (uint8_t*)d_ok, c->vb_tables, c->slow);
+  if (schnorr)
+    hipLaunchKernelGGL(bjj_k_schnorr_verify, dim3(grid_for(c, n, c->occ_verify)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
+                       c->nwin, (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n,
+                       (uint8_t*)d_ok, c->vb_tables, c->slow);
+  else
+    hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid_for(c, n, c->occ_verify)), dim3(BJJ_BLOCK), 0, st, c->table, c->W,
+                       c->nwin, (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n,
+                       (uint8_t*)d_ok, c->vb_tables, c->slow);
   HIPCK(hipGetLastError());
   return BJJ_OK;
+}
+int bjj_eddsa_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
+                         void* d_ok, void* stream) {
+  return verify_launch(c, false, d_pk, d_r, d_s, d_msg, n, d_ok, stream, "bjj_eddsa_verify_dev");
+}
+int bjj_schnorr_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
+                           void* d_ok, void* stream) {
+  return verify_launch(c, true, d_pk, d_r, d_s, d_msg, n, d_ok, stream, "bjj_schnorr_verify_dev");
 }
 int bjj_point_add_dev(bjj_ctx* c, const void* d_p, const void* d_q, size_t n, void* d_out, void* stream) {
   CHECK_CTX(c, "bjj_point_add_dev");
@@ -773,11 +790,21 @@ int bjj_poseidon5(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out) {
   HIPCK(hipStreamSynchronize(c->stream));
   return BJJ_OK;
 }
+static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg,
+                       size_t n, uint8_t* ok);
 int bjj_eddsa_verify(bjj_ctx* c, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n,
                      uint8_t* ok) {
-  CHECK_CTX(c, "bjj_eddsa_verify");
+  return verify_host(c, false, pk, r, s, msg, n, ok);
+}
+int bjj_schnorr_verify(bjj_ctx* c, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n,
+                       uint8_t* ok) {
+  return verify_host(c, true, pk, r, s, msg, n, ok);
+}
+static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg,
+                       size_t n, uint8_t* ok) {
+  CHECK_CTX(c, "bjj_eddsa_verify / bjj_schnorr_verify");
   if (n == 0) return BJJ_OK;
-  if (!pk || !r || !s || !msg || !ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify: NULL buffer");
+  if (!pk || !r || !s || !msg || !ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify / bjj_schnorr_verify: NULL buffer");
   HIPCK(hipSetDevice(c->device));
   size_t o_pk = 0, o_r = up16(n * 64), o_s = o_r + up16(n * 64), o_m = o_s + up16(n * 32), o_ok = o_m + up16(n * 32);
   int rc = ensure_stage(c, o_ok + n); if (rc) return rc;
@@ -785,7 +812,8 @@ int bjj_eddsa_verify(bjj_ctx* c, const uint8_t* pk, const uint8_t* r, const uint
   HIPCK(hipMemcpyAsync(c->stage + o_r, r, n * 64, hipMemcpyHostToDevice, c->stream));
   HIPCK(hipMemcpyAsync(c->stage + o_s, s, n * 32, hipMemcpyHostToDevice, c->stream));
   HIPCK(hipMemcpyAsync(c->stage + o_m, msg, n * 32, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_eddsa_verify_dev(c, c->stage + o_pk, c->stage + o_r, c->stage + o_s, c->stage + o_m, n, c->stage + o_ok, nullptr);
+  rc = verify_launch(c, schnorr, c->stage + o_pk, c->stage + o_r, c->stage + o_s, c->stage + o_m, n, c->stage + o_ok, nullptr,
+                     schnorr ? "bjj_schnorr_verify" : "bjj_eddsa_verify");
   if (rc) return rc;
   HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
   HIPCK(hipStreamSynchronize(c->stream));

@@ -14,6 +14,7 @@
  *   bjj_poseidon5        POSEIDON.hash(vec![a,b,c,d,e]) as called at
  *                        src/lib.rs:400-404 (poseidon-rs 0.0.8, Cargo.toml:20)
  *   bjj_eddsa_verify     verify(pk, sig, msg)        src/lib.rs:395-412
+ *   bjj_schnorr_verify   verify_schnorr(pk, m, r, s) src/lib.rs:375-385 (+ schnorr_hash :364-373)
  *   bjj_point_add        PointProjective::add(..).affine()
  *                        src/lib.rs:88-131 + 70-85 on affine inputs (z = 1)
  *   bjj_compress_points  Point::compress(&self)      src/lib.rs:166-178
@@ -95,6 +96,11 @@ int bjj_poseidon5(bjj_ctx* ctx, const uint8_t* in /* n*160 */, size_t n, uint8_t
 int bjj_eddsa_verify(bjj_ctx* ctx, const uint8_t* pk_xy /* n*64 */, const uint8_t* r_xy /* n*64 */,
                      const uint8_t* s /* n*32 */, const uint8_t* msg /* n*32 */, size_t n,
                      uint8_t* ok /* n */);
+/* Schnorr variant: ok[i] = 1 / 0 for Ok(true) / Ok(false), 2 for Err ("msg outside the Finite Field").
+ * `s` is a 32-byte integer; the crate's unreduced k + x*h may be wider -- reduce it mod 8l first (exact:
+ * it only multiplies the on-curve generator B8). */
+int bjj_schnorr_verify(bjj_ctx* ctx, const uint8_t* pk_xy /* n*64 */, const uint8_t* r_xy /* n*64 */,
+                       const uint8_t* s /* n*32 */, const uint8_t* msg /* n*32 */, size_t n, uint8_t* ok /* n */);
 int bjj_point_add(bjj_ctx* ctx, const uint8_t* p_xy /* n*64 */, const uint8_t* q_xy /* n*64 */,
                   size_t n, uint8_t* out_xy /* n*64 */);
 /* Wire format (src/lib.rs:166-178): 32 bytes = y little-endian, bit 255 = (x > (r-1)/2). */
@@ -123,6 +129,8 @@ int bjj_mul_var_base_dev(bjj_ctx* ctx, const void* d_pts_xy, const void* d_scala
 int bjj_poseidon5_dev(bjj_ctx* ctx, const void* d_in, size_t n, void* d_out, void* stream);
 int bjj_eddsa_verify_dev(bjj_ctx* ctx, const void* d_pk_xy, const void* d_r_xy, const void* d_s,
                          const void* d_msg, size_t n, void* d_ok, void* stream);
+int bjj_schnorr_verify_dev(bjj_ctx* ctx, const void* d_pk_xy, const void* d_r_xy, const void* d_s,
+                           const void* d_msg, size_t n, void* d_ok, void* stream);
 int bjj_point_add_dev(bjj_ctx* ctx, const void* d_p_xy, const void* d_q_xy, size_t n, void* d_out_xy,
                       void* stream);
 int bjj_scalar_keys_dev(bjj_ctx* ctx, const void* d_keys, size_t n, void* d_out, void* stream);

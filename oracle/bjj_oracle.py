@@ -377,6 +377,36 @@ def verify(pk, sig_r, sig_s, msg):
     return l[0] == ra[0] and l[1] == ra[1]
 
 
+def schnorr_hash(pk, msg, c):
+    """schnorr_hash(pk, msg, c), lib.rs:364-373: Poseidon(pk.x, pk.y, c.x, c.y, msg); None for Err (msg > Q)."""
+    if msg > Q:
+        return None
+    return poseidon([pk[0], pk[1], c[0], c[1], msg % Q])
+
+
+def verify_schnorr(pk, m, r, s):
+    """verify_schnorr(pk, m, r, s) -> Result<bool, String>, lib.rs:375-385; None for Err."""
+    sg = mul_scalar(B8, s)                                   # lib.rs:377
+    h = schnorr_hash(pk, m, r)                               # lib.rs:380
+    if h is None:
+        return None
+    pk_h = mul_scalar(pk, h)                                 # lib.rs:381
+    right = proj_add((r[0] % Q, r[1] % Q, 1), (pk_h[0], pk_h[1], 1))   # lib.rs:382
+    ra = proj_affine(right)
+    return sg[0] == ra[0] and sg[1] == ra[1]                 # lib.rs:384
+
+
+def sign_schnorr_with_nonce(key, m, k):
+    """PrivateKey::sign_schnorr (lib.rs:345-361) with the random nonce k supplied by the caller
+    (the reference draws 1024 random bits, lib.rs:347-348).  Returns (r, s) with s = k + scalar_key*h
+    UNREDUCED as in the reference, or None for Err."""
+    r = mul_scalar(B8, k)
+    h = schnorr_hash(public(key), m, r)
+    if h is None:
+        return None
+    return r, k + scalar_key(key) * h
+
+
 def sign_with_scalars(k, rho, msg):
     """Algebraic equivalent of PrivateKey::sign (lib.rs:308-342) given the
     already-derived secret scalar k (= scalar_key() << 3 >> 3 ... i.e. the

@@ -12,6 +12,7 @@
  *                                               add also used for doubling)
  *   test_bit               src/lib.rs:188-190
  *   verify                 src/lib.rs:395-412
+ *   schnorr_hash / verify_schnorr   src/lib.rs:364-385
  *   blh / scalar_key / public / sign   src/lib.rs:226-237, 284-342 (Blake-512: third-party
  *                          blake-hash 0.4.0, Cargo.toml:17; restated from the BLAKE specification and
  *                          pinned by the digest KAT of src/lib.rs:695-696)
@@ -444,6 +445,26 @@ static void compress_point(uint8_t r[32], const point_t *p) { /* lib.rs:166-178 
   if (fr_geq(&xr, &HALFQ) && !fr_eq(&xr, &HALFQ)) r[31] |= 0x80;
 }
 
+/* ---- Schnorr variant (lib.rs:364-385) ----------------------------------- */
+/* 1 = Ok(true), 0 = Ok(false), 2 = Err ("msg outside the Finite Field") */
+static int verify_schnorr1(const uint8_t *pk, const uint8_t *msg, const uint8_t *rb, const uint8_t *s) {
+  fr_t m; memcpy(m.l, msg, 32);
+  point_t sg; mul_scalar(&sg, &C_B8, s, 32);          /* lib.rs:377 (computed before the hash, as there) */
+  if (fr_geq(&m, &MODULUS) && !fr_eq(&m, &MODULUS)) return 2;   /* lib.rs:365-367 */
+  point_t A_, R_;
+  fr_from_le(&A_.x, pk); fr_from_le(&A_.y, pk + 32);
+  fr_from_le(&R_.x, rb); fr_from_le(&R_.y, rb + 32);
+  fr_t in[5] = {A_.x, A_.y, R_.x, R_.y, ZERO};        /* lib.rs:369 */
+  fr_from_le(&in[4], msg);
+  fr_t h; poseidon5(&h, in);
+  uint8_t hb[32]; fr_to_le(hb, &h);
+  point_t t; mul_scalar(&t, &A_, hb, 32);             /* lib.rs:381 */
+  proj_t rp = {R_.x, R_.y, R1}, tp = {t.x, t.y, R1}, sum;
+  proj_add(&sum, &rp, &tp);                           /* lib.rs:382 */
+  point_t ra; proj_affine(&ra, &sum);
+  return fr_eq(&sg.x, &ra.x) && fr_eq(&sg.y, &ra.y);  /* lib.rs:384 */
+}
+
 /* ======================= exported C entry points ======================== */
 #define EXPORT __attribute__((visibility("default")))
 
@@ -535,9 +556,14 @@ EXPORT int bjjref_sign(const uint8_t *key, const uint8_t *msg, uint8_t *out_r, u
   return 1;
 }
 
+EXPORT int bjjref_verify_schnorr(const uint8_t *pk, const uint8_t *msg, const uint8_t *rb, const uint8_t *s) {
+  ensure_init();
+  return verify_schnorr1(pk, msg, rb, s);
+}
+
 /* ---- threaded batch drivers (CPU baseline + bulk expected values) ------ */
 typedef struct {
-  int kind; /* 0 fixed-base, 1 var-base, 2 poseidon5, 3 verify, 4 decompress, 5 compress, 6 verify-compressed, 7 sign, 8 public */
+  int kind; /* 0 fixed-base, 1 var-base, 2 poseidon5, 3 verify, 4 decompress, 5 compress, 6 verify-compressed, 7 sign, 8 public, 9 verify_schnorr */
   const uint8_t *a, *b, *c, *d; uint8_t *out; size_t lo, hi;
 } job_t;
 static void *worker(void *arg) {
@@ -553,6 +579,7 @@ static void *worker(void *arg) {
       case 6: j->out[i] = (uint8_t)bjjref_verify_compressed(j->a + 32 * i, j->b + 64 * i, j->c + 32 * i); break;
       case 7: ((uint8_t *)j->d)[i] = (uint8_t)bjjref_sign(j->a + 32 * i, j->b + 32 * i, j->out + 64 * i, (uint8_t *)j->c + 32 * i); break;
       case 8: bjjref_public(j->a + 32 * i, j->out + 64 * i); break;
+      case 9: j->out[i] = (uint8_t)verify_schnorr1(j->a + 64 * i, j->d + 32 * i, j->b + 64 * i, j->c + 32 * i); break;
     }
   }
   return NULL;
@@ -600,4 +627,8 @@ EXPORT void bjjref_sign_batch(const uint8_t *keys, const uint8_t *msgs, size_t n
 }
 EXPORT void bjjref_public_batch(const uint8_t *keys, size_t n, uint8_t *out_xy, int nthreads) {
   run_batch(8, keys, NULL, NULL, NULL, out_xy, n, nthreads);
+}
+EXPORT void bjjref_verify_schnorr_batch(const uint8_t *pk, const uint8_t *rb, const uint8_t *s, const uint8_t *msg,
+                                        size_t n, uint8_t *ok, int nthreads) {
+  run_batch(9, pk, rb, s, msg, ok, n, nthreads);
 }

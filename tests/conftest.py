@@ -90,6 +90,14 @@ class Oracle:
                                                 self._p(out), self.threads)
         return out
 
+    def verify_schnorr(self, pk, r, s, m):
+        pk, r, s, m = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1) for x in (pk, r, s, m))
+        n = s.size // 32
+        out = np.empty(n, np.uint8)
+        self.lib.bjjref_verify_schnorr_batch(self._p(pk), self._p(r), self._p(s), self._p(m), ctypes.c_size_t(n),
+                                             self._p(out), self.threads)
+        return out
+
     def sign(self, keys, msgs):
         k = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1)
         m = np.ascontiguousarray(msgs, dtype=np.uint8).reshape(-1)

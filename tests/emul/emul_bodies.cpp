@@ -62,6 +62,13 @@ int emul_sign(const uint8_t* key, const uint8_t* msg, int W, uint8_t* out_r, uin
   if (!ok) { memset(out_r, 0, 64); memset(out_s, 0, 32); return 0; }
   memcpy(out_r, rx, 32); memcpy(out_r + 32, ry, 32); memcpy(out_s, s, 32); return 1;
 }
+int emul_verify_schnorr(const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, int W) {
+  ensure_table(W);
+  alignas(16) uint8_t b[192]; alignas(16) static u32 tbl[VB_TABLE_WORDS];
+  memcpy(b, pk, 64); memcpy(b + 64, r, 64); memcpy(b + 128, s, 32); memcpy(b + 160, msg, 32);
+  VerifyIn in = {b, b + 64, b + 128, b + 160};
+  return verify_schnorr_item(in, table_ptr(), g_W, g_nwin, tbl, K);
+}
 int emul_decompress(const uint8_t* in, uint8_t* out) {
   alignas(16) u32 w[8], ox[8], oy[8]; memcpy(w, in, 32);
   bool ok = decompress_item(w, ox, oy, K);

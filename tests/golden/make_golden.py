@@ -191,6 +191,28 @@ def oracle_vectors():
     sg.append({"key": sg[0]["key"], "msg": hx(Q + 1), "scalar_key": sg[0]["scalar_key"], "pk": sg[0]["pk"],
                "r_b8": [hx(0), hx(0)], "s": hx(0), "ok": False})
     out["sign"] = sg
+
+    # ---- Schnorr variant (lib.rs:344-385): nonce from the SEED_NONCES stream instead of thread_rng
+    sch = []
+    rk2 = o.SplitMix64(o.SEED_NONCES ^ 0x5C)
+    for i in range(5):
+        key = o.to_le32(rs.u256())
+        m = 123456789012345678901234567890 if i == 0 else rm.u256() % Q
+        k = rk2.u256() | (rk2.u256() << 256) | (rk2.u256() << 512) | (rk2.u256() << 768)   # 1024-bit nonce, lib.rs:347-348
+        r, s_big = o.sign_schnorr_with_nonce(key, m, k)
+        pkp = o.public(key)
+        base = {"pk": [hx(pkp[0]), hx(pkp[1])], "r": [hx(r[0]), hx(r[1])], "msg": hx(m), "s_unreduced_bits": s_big.bit_length()}
+        s_red = s_big % o.ORDER
+        assert o.verify_schnorr(pkp, m, r, s_big) is True and o.verify_schnorr(pkp, m, r, s_red) is True
+        sch.append(dict(base, s=hx(s_red), ok=1, note="valid (s reduced mod 8l)"))
+        if i == 0:
+            sch.append(dict(base, s=hx(s_red ^ 1), ok=0, note="bit flipped in s"))
+            sch.append(dict(base, s=hx(s_red), msg=hx((m + 1) % Q), ok=0, note="wrong msg"))
+            sch.append(dict(base, s=hx(s_red), msg=hx(Q + 1), ok=2, note="msg > Q -> Err (lib.rs:365-367)"))
+            for pkx, note in (((1, 2), "pk off curve"), ((0, 1), "pk = identity")):
+                sch.append(dict(base, pk=[hx(pkx[0]), hx(pkx[1])], s=hx(s_red), ok=int(o.verify_schnorr(pkx, m, r, s_red)), note=note))
+            sch.append(dict(base, r=[hx(3), hx(4)], s=hx(s_red), ok=int(o.verify_schnorr(pkp, m, (3, 4), s_red)), note="r off curve"))
+    out["schnorr"] = sch
     return out
 
 
