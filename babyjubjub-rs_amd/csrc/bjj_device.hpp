@@ -3,6 +3,7 @@
 // shipped library only instantiates them inside HIP kernels (bjj_kernels.hip).
 #pragma once
 #include "poseidon.hpp"
+#include "bjj_constants.inc"  // BJJ_L_NINV29 (macros only; safe to include repeatedly)
 
 namespace bjj {
 
@@ -59,6 +60,7 @@ BJJ_HD void store_niels(u32* p, const Niels& n) {
 constexpr int PNIELS_WORDS = 36;
 constexpr int VB_TABLE_ENTRIES = 9;  // 0*P .. 8*P
 constexpr int VB_TABLE_WORDS = PNIELS_WORDS * VB_TABLE_ENTRIES;
+constexpr int VB_VERIFY_WORDS = 2 * VB_TABLE_WORDS;  // verify keeps two per-lane tables (-8A and -+R)
 BJJ_HD PNiels load_pniels(const u32* p) {
   const U4* q = (const U4*)p;
   U4 t[9];
@@ -139,9 +141,9 @@ BJJ_HD void vb_build_table(const Ext& P, u32* tbl, const Consts& K) {
     store_pniels(tbl + k * PNIELS_WORDS, ext_to_pniels(cur, K));
   }
 }
-// nwin windows of 4 bits, most significant first; needs sc < 2^(4*nwin - 1) so that the
-// signed recoding (add 0x88..8, digit = nibble - 8) cannot carry out of the top window
-// (callers pass nwin = 64 with sc < 2^254).
+// nwin windows of 4 bits, most significant first; needs sc < 2^(4*nwin - 2) so that the
+// signed recoding (add 0x88..8, digit = nibble - 8) cannot carry out of the top window: the top
+// nibble plus an incoming carry must stay below 8 (callers pass nwin = 64 with sc < 2^254).
 BJJ_HD Ext vb_mul_windowed(const u32* tbl, const u32 sc[8], int nwin) {
   u32 t[8];
   u64 c = 0;
@@ -352,6 +354,175 @@ BJJ_HD bool verify_needs_exact(const VerifyIn& in, const Consts& K) {
   load_w8((const char*)in.pk + 32, w); Fr ay = fr_to_mont_words(w);
   return !ref_on_curve(ax, ay, K);
 }
+// ---------------------------------------------------------------------------
+// arithmetic mod l (the prime subgroup order) in the same 9 x 29-bit limb form, Montgomery
+// radix 2^261.  Only three products per signature, so it is not tuned.
+// ---------------------------------------------------------------------------
+BJJ_HD Fr fl_mul(const Fr& a, const Fr& b, const Consts& K) {  // a*b*2^-261 mod l, needs a*b < l*2^261; result < 2l
+  u32 m[NL];
+  Fr r;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (u64)a.v[i] * b.v[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (u64)m[i] * K.L.v[k - i];
+    m[k] = ((u32)acc * BJJ_L_NINV29) & MASK29;
+    acc += (u64)m[k] * K.L.v[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)a.v[i] * b.v[k - i];
+#pragma unroll
+    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)m[i] * K.L.v[k - i];
+    r.v[k - NL] = (u32)acc & MASK29;
+    acc >>= 29;
+  }
+  r.v[NL - 1] = (u32)acc;
+  return r;
+}
+// canonical value mod l of a plain N-form x < 4l
+BJJ_HD Fr fl_canon4(const Fr& x, const Consts& K) {
+  Fr t = fr_cond_sub_kr(x, K.L2.v);
+  return fr_cond_sub_kr(t, K.L.v);
+}
+
+
+// =============================================================================
+// Half-size scalars for EdDSA verification (Antipa, Brown, Gallant, Lambert, Struik, Vanstone:
+// "Accelerated verification of ECDSA signatures", SAC 2005).  The check
+//     D := s*B8 - 8*kappa*A - R == O            (kappa = hm mod l)
+// is multiplied by an ODD integer v that is non-zero mod l -- hence invertible modulo the group
+// order 8l, so v*D == O <=> D == O exactly, whatever torsion component R or A carry -- chosen
+// such that u = v*kappa mod l is small as well.  Then
+//     v*D = (v*s mod l)*B8 + u*(-8A) + v*(-R)
+// needs one fixed-base multiplication and ONE joint double-and-add over ~126-bit u, |v| instead
+// of a 251-bit variable-base multiplication.  (u, v) comes from the classical extended Euclid
+// sequence r_i = s_i*l + t_i*kappa, stopped at the first r_i < 2^126: (r_i, t_i) if t_i is odd,
+// otherwise the better of the previous pair (t odd because consecutive t's are never both even:
+// t_{i+1} r_i - t_i r_{i+1} = +-l is odd) and the next pair (rejected when it degenerates to t = +-l).
+// =============================================================================
+BJJ_HD bool limbs_lt(const Fr& a, const Fr& b) {  // a < b, both N-form plain integers
+  u32 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) { u32 t = a.v[i] - b.v[i] - borrow; borrow = t >> 31; }
+  return borrow != 0;
+}
+BJJ_HD bool limbs_ge_2p126(const Fr& a) {  // 2^126 = bit 10 of limb 4
+  return (a.v[8] | a.v[7] | a.v[6] | a.v[5] | (a.v[4] >> 10)) != 0;
+}
+BJJ_HD bool limbs_is_zero(const Fr& a) { return fr_is_zero_canon(a); }
+BJJ_HD double limbs_to_double(const Fr& a) {  // rounded to 53 bits
+  double d = (double)a.v[8];
+#pragma unroll
+  for (int i = NL - 2; i >= 0; i--) d = d * 536870912.0 + (double)a.v[i];
+  return d;
+}
+BJJ_HD int limbs_bits(const Fr& a) {  // bit length
+  int bits = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) if (a.v[i]) bits = 29 * i + 32 - __builtin_clz(a.v[i]);
+  return bits;
+}
+BJJ_HD void limbs_submul(Fr& a, u32 q, const Fr& b) {  // a -= q*b  (result >= 0 by the caller's choice of q)
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    c += (int64_t)a.v[i] - (int64_t)((u64)q * b.v[i]);
+    a.v[i] = (i < NL - 1) ? ((u32)c & MASK29) : (u32)c;
+    c >>= 29;
+  }
+}
+BJJ_HD void limbs_addmul(Fr& a, u32 q, const Fr& b) {  // a += q*b
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    c += (u64)a.v[i] + (u64)q * b.v[i];
+    a.v[i] = (i < NL - 1) ? ((u32)c & MASK29) : (u32)c;
+    c >>= 29;
+  }
+}
+BJJ_HD Fr limbs_shift_up(const Fr& a, int k) {  // a * 2^(29 k), k in 0..8 (high limbs fall off: callers keep it in range)
+  Fr r = a;
+#pragma unroll
+  for (int s = 0; s < NL - 1; s++) {
+    if (s < k) {
+#pragma unroll
+      for (int i = NL - 1; i > 0; i--) r.v[i] = r.v[i - 1];
+      r.v[0] = 0;
+    }
+  }
+  return r;
+}
+// one "partial quotient" step of Euclid on (r0 >= r1 > 0): r0 -= q r1, |t0| += q |t1| with
+// 1 <= q <= floor(r0 / r1), where q = m * 2^(29 k) is the leading 29-bit digit of a 53-bit
+// floating-point UNDER-estimate of the quotient (so even a 2^250 quotient takes <= 9 steps)
+BJJ_HD void euclid_partial_step(Fr& r0, const Fr& r1, Fr& t0, const Fr& t1) {
+  double qf = limbs_to_double(r0) / limbs_to_double(r1) * (1.0 - 1.0 / 281474976710656.0);  // * (1 - 2^-48)
+  int k = 0;
+#pragma unroll 1
+  while (qf >= 536870912.0) { qf *= (1.0 / 536870912.0); k++; }                             // qf in [.., 2^29)
+  u32 m = (u32)qf;
+  m = m < 1u ? 1u : m;                                                                      // k == 0 here: q = 1 <= true quotient
+  if (k == 0) {  // the common case: quotient below 2^29
+    limbs_submul(r0, m, r1);
+    limbs_addmul(t0, m, t1);
+  } else {
+    limbs_submul(r0, m, limbs_shift_up(r1, k));
+    limbs_addmul(t0, m, limbs_shift_up(t1, k));
+  }
+}
+// u (>= 0), |v|, sign(v) with u == v*kappa (mod l), v odd and != 0 (mod l); kappa plain canonical < l
+BJJ_HD void lattice_short_pair(const Fr& kappa, Fr& u, Fr& vmag, bool& vneg, const Consts& K) {
+  Fr r0 = K.L, r1 = kappa, t0 = fr_zero(), t1 = fr_one_plain();
+  bool s1 = false;  // sign of t1; t0 has the opposite sign (or is 0)
+  while (limbs_ge_2p126(r1)) {
+    euclid_partial_step(r0, r1, t0, t1);
+    if (limbs_lt(r0, r1)) { Fr x = r0; r0 = r1; r1 = x; x = t0; t0 = t1; t1 = x; s1 = !s1; }
+  }
+  if (t1.v[0] & 1) { u = r1; vmag = t1; vneg = s1; return; }
+  // t1 even (so r1 != 0 and t0 is odd): previous pair P = (r0, t0), next pair N = (r0 mod r1, t0 + q t1)
+  const Fr pr = r0, pt = t0;
+  while (!limbs_lt(r0, r1)) euclid_partial_step(r0, r1, t0, t1);
+  const bool takeN = !limbs_is_zero(r0) && (limbs_bits(t0) < limbs_bits(pr));
+  u = fr_select(takeN, r0, pr);
+  vmag = fr_select(takeN, t0, pt);
+  vneg = !s1;
+}
+// signed 4-bit recoding of a plain N-form scalar < 2^(4*nwin - 2): returns the words of sc + 0x88..8
+BJJ_HD void recode_signed4(const Fr& sc, u32 t[8]) {
+  u32 w[8];
+  fr_to_words(sc, w);
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (u64)w[i] + 0x88888888u; t[i] = (u32)c; c >>= 32; }
+}
+// W = acc0 + u*P1 + |v|*P2 with per-lane tables tbl1 / tbl2 ({0..8}*P in PNiels form)
+BJJ_HD Ext joint_mul_windowed(const u32* tbl1, const u32* tbl2, const Fr& u, const Fr& vmag, int nwin) {
+  u32 tu[8], tv[8];
+  recode_signed4(u, tu);
+  recode_signed4(vmag, tv);
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (int j = nwin - 1; j >= 0; j--) {
+    const int du = (int)((tu[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
+    const int dv = (int)((tv[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
+    PNiels e1 = load_pniels(tbl1 + (u32)(du < 0 ? -du : du) * PNIELS_WORDS);
+    PNiels e2 = load_pniels(tbl2 + (u32)(dv < 0 ? -dv : dv) * PNIELS_WORDS);
+    if (j != nwin - 1) {
+#pragma unroll 1
+      for (int k = 0; k < 3; k++) acc = ext_dbl<false>(acc);
+      acc = ext_dbl<true>(acc);
+    }
+    acc = ext_add_pn(acc, pniels_cneg(e1, du < 0));
+    acc = ext_add_pn(acc, pniels_cneg(e2, dv < 0));
+  }
+  return acc;
+}
+
 // Fast path of verify (src/lib.rs:395-412) and, with SCHNORR, of verify_schnorr (src/lib.rs:375-385:
 // hash input order (pk, R, msg) instead of (R, pk, msg), the hash is NOT multiplied by 8, and msg > Q is
 // an Err -- verdict 2 -- rather than `false`).  Verdict 0 / 1 / 2; need_exact is set when pk or R is off
@@ -375,19 +546,44 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const u32* fb_table, int W, int nwi
   else         { h[0] = rx; h[1] = ry; h[2] = ax; h[3] = ay; }  // :400
   Fr hm = poseidon5(h, K);                                      // :400-404
   Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // canonical integer, :406
-  // EdDSA:   s*B8 == R + 8*hm*A  <=>  8*(hm mod l)*(-A) + s*B8 == R   (group order 8l)
-  // Schnorr: s*B8 == R + hm*A    <=>     hm*(-A)        + s*B8 == R   (hm < r < 8l: no reduction)
-  u32 kw[8], sw[8];
-  fr_to_words(SCHNORR ? hm_plain : plain_mod_l(hm_plain, K), kw);
-  Ext negA = ext_from_ref_affine(fr_neg(ax), ay, K);
-  vb_build_table(negA, vb_tbl, K);
-  Ext q = vb_mul_windowed(vb_tbl, kw, 64);                      // scalar < 2^254
-  if (!SCHNORR) { q = ext_dbl<false>(q); q = ext_dbl<false>(q); q = ext_dbl<true>(q); }
+  u32 sw[8];
   load_w8(in.s, sw);
-  q = fixed_base_accumulate(q, fb_table, W, nwin, sw);          // + s*B8   (:405 / :377)
-  // compare with R on the a'=-1 curve: X == (F Rx) Z, Y == Ry Z
-  Fr fx = fr_mul(rx, K.F);
-  return (fr_eq(q.X, fr_mul(fx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z))) ? 1 : 0;
+  if (SCHNORR) {
+    // s*B8 == R + hm*A  <=>  hm*(-A) + s*B8 == R   (hm < r < 8l: no reduction; A may carry torsion and
+    // hm may be even, so the half-size trick below does not apply)
+    u32 kw[8];
+    fr_to_words(hm_plain, kw);
+    Ext negA = ext_from_ref_affine(fr_neg(ax), ay, K);
+    vb_build_table(negA, vb_tbl, K);
+    Ext q = vb_mul_windowed(vb_tbl, kw, 64);                    // scalar < 2^254
+    q = fixed_base_accumulate(q, fb_table, W, nwin, sw);        // + s*B8   (:377)
+    Fr fx = fr_mul(rx, K.F);                                    // compare with R on the a'=-1 curve
+    return (fr_eq(q.X, fr_mul(fx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z))) ? 1 : 0;
+  }
+  // EdDSA: v*(s*B8 - 8*kappa*A - R) == O  with the short odd pair (u, v), u = v*kappa mod l (see above)
+  Fr u, vmag;
+  bool vneg;
+  lattice_short_pair(plain_mod_l(hm_plain, K), u, vmag, vneg, K);
+  // c = v*s mod l for the fixed-base part (B8 has order l): three Montgomery products mod l
+  Fr sl = fl_mul(fr_from_words(sw), K.L_R1, K);                                  // s mod l (< 2l)
+  Fr c = fl_canon4(fl_mul(vmag, fl_mul(sl, K.L_R2, K), K), K);                   // |v|*s mod l
+  if (vneg && !limbs_is_zero(c)) { Fr t = K.L; limbs_submul(t, 1u, c); c = t; }  // l - c
+  u32 cw[8];
+  fr_to_words(c, cw);
+  // P1 = -8A, P2 = -sign(v) R   (both on the a'=-1 curve)
+  Ext p1 = ext_from_ref_affine(fr_neg(ax), ay, K);
+  p1 = ext_dbl<false>(p1); p1 = ext_dbl<false>(p1); p1 = ext_dbl<true>(p1);
+  Ext p2 = ext_from_ref_affine(vneg ? rx : fr_neg(rx), ry, K);
+  u32* tbl2 = vb_tbl + VB_TABLE_WORDS;
+  vb_build_table(p1, vb_tbl, K);
+  vb_build_table(p2, tbl2, K);
+  const int ub = limbs_bits(u), vb = limbs_bits(vmag);
+  // signed recoding needs top nibble + carry < 8, i.e. scalars < 2^(4*jw - 2): 34 windows cover 134 bits
+  // (all but ~2e-5 of the pairs); the rest -- e.g. kappa = (l+1)/2 gives u of 250 bits -- take 64 windows
+  const int jw = ((ub > vb ? ub : vb) <= 134) ? 34 : 64;
+  Ext q = joint_mul_windowed(vb_tbl, tbl2, u, vmag, jw);
+  q = fixed_base_accumulate(q, fb_table, W, nwin, cw);          // + (v s mod l)*B8
+  return (fr_is_zero(q.X) && fr_eq(q.Y, q.Z)) ? 1 : 0;          // projective identity (0 : z : z)
 }
 // Exact path: replays src/lib.rs:395-412 (or :375-385) operation by operation (any input).
 template <bool SCHNORR>

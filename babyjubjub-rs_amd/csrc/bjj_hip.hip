@@ -262,7 +262,7 @@ __device__ __forceinline__ void verify_kernel_body(const u32* __restrict__ table
                                                    u32* __restrict__ wl) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
+  u32* tbl = vb_tables + tid * VB_VERIFY_WORDS;
   const unsigned long long nexact = wl[0];
 #pragma unroll 1
   for (;;) {  // exact-path groups first
@@ -462,7 +462,7 @@ static int ensure_scratch(bjj_ctx* c, size_t n) {
     HIPCK(hipMalloc((void**)&c->slow, (n + 16) * sizeof(u32)));
     c->slow_items = n;
   }
-  size_t tv = (size_t)c->occ_var * BJJ_EPI_BLOCK, te = (size_t)c->occ_verify * BJJ_BLOCK;
+  size_t tv = (size_t)c->occ_var * BJJ_EPI_BLOCK, te = (size_t)c->occ_verify * BJJ_BLOCK * 2;  // verify: 2 tables per lane
   size_t threads = (size_t)c->cus * (tv > te ? tv : te);
   if (threads > c->vb_threads) {
     if (c->vb_tables) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->vb_tables)); c->vb_tables = nullptr; }

@@ -4,7 +4,6 @@
 // pinned by the digest KAT of src/lib.rs:695-696).
 #pragma once
 #include "bjj_device.hpp"
-#include "bjj_constants.inc"  // BJJ_L_NINV29 (macros only; safe to include repeatedly)
 
 namespace bjj {
 
@@ -73,36 +72,6 @@ BJJ_HD void blake512_words(const u32* w, int nw, u32 dig[16]) {
   for (int i = 0; i < 8; i++) { dig[2 * i] = bswap32((u32)(h[i] >> 32)); dig[2 * i + 1] = bswap32((u32)h[i]); }
 }
 
-// ---------------------------------------------------------------------------
-// arithmetic mod l (the prime subgroup order) in the same 9 x 29-bit limb form, Montgomery
-// radix 2^261.  Only three products per signature, so it is not tuned.
-// ---------------------------------------------------------------------------
-BJJ_HD Fr fl_mul(const Fr& a, const Fr& b, const Consts& K) {  // a*b*2^-261 mod l, needs a*b < l*2^261; result < 2l
-  u32 m[NL];
-  Fr r;
-  u64 acc = 0;
-#pragma unroll
-  for (int k = 0; k < NL; k++) {
-#pragma unroll
-    for (int i = 0; i <= k; i++) acc += (u64)a.v[i] * b.v[k - i];
-#pragma unroll
-    for (int i = 0; i < k; i++) acc += (u64)m[i] * K.L.v[k - i];
-    m[k] = ((u32)acc * BJJ_L_NINV29) & MASK29;
-    acc += (u64)m[k] * K.L.v[0];
-    acc >>= 29;
-  }
-#pragma unroll
-  for (int k = NL; k < 2 * NL - 1; k++) {
-#pragma unroll
-    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)a.v[i] * b.v[k - i];
-#pragma unroll
-    for (int i = k - (NL - 1); i < NL; i++) acc += (u64)m[i] * K.L.v[k - i];
-    r.v[k - NL] = (u32)acc & MASK29;
-    acc >>= 29;
-  }
-  r.v[NL - 1] = (u32)acc;
-  return r;
-}
 // bits [lo, lo+261) of a little-endian word array as 9 x 29-bit limbs
 BJJ_HD Fr limbs_from_bits(const u32* w, int nw, int lo) {
   Fr r;
@@ -116,12 +85,6 @@ BJJ_HD Fr limbs_from_bits(const u32* w, int nw, int lo) {
   }
   return r;
 }
-// canonical value mod l of a plain N-form x < 4l
-BJJ_HD Fr fl_canon4(const Fr& x, const Consts& K) {
-  Fr t = fr_cond_sub_kr(x, K.L2.v);
-  return fr_cond_sub_kr(t, K.L.v);
-}
-
 // ---------------------------------------------------------------------------
 // PrivateKey::scalar_key (src/lib.rs:284-302): Blake-512(key)[..32], pruned, >> 3
 // `pruned` is the value before the shift (== scalar_key << 3, what lib.rs:335 multiplies by);

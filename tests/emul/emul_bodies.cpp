@@ -64,10 +64,19 @@ int emul_sign(const uint8_t* key, const uint8_t* msg, int W, uint8_t* out_r, uin
 }
 int emul_verify_schnorr(const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, int W) {
   ensure_table(W);
-  alignas(16) uint8_t b[192]; alignas(16) static u32 tbl[VB_TABLE_WORDS];
+  alignas(16) uint8_t b[192]; alignas(16) static u32 tbl[VB_VERIFY_WORDS];
   memcpy(b, pk, 64); memcpy(b + 64, r, 64); memcpy(b + 128, s, 32); memcpy(b + 160, msg, 32);
   VerifyIn in = {b, b + 64, b + 128, b + 160};
   return verify_schnorr_item(in, table_ptr(), g_W, g_nwin, tbl, K);
+}
+// (u, |v|, sign) of lattice_short_pair for a canonical kappa < l given as 32 LE bytes
+int emul_short_pair(const uint8_t* kappa, uint8_t* u_out, uint8_t* v_out) {
+  alignas(16) u32 w[8]; memcpy(w, kappa, 32);
+  Fr u, vm; bool neg;
+  lattice_short_pair(fr_from_words(w), u, vm, neg, K);
+  fr_to_words(u, w); memcpy(u_out, w, 32);
+  fr_to_words(vm, w); memcpy(v_out, w, 32);
+  return neg ? 1 : 0;
 }
 int emul_decompress(const uint8_t* in, uint8_t* out) {
   alignas(16) u32 w[8], ox[8], oy[8]; memcpy(w, in, 32);
@@ -81,7 +90,7 @@ void emul_compress(const uint8_t* in, uint8_t* out) {
 }
 int emul_verify(const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, int W) {
   ensure_table(W);
-  alignas(16) uint8_t b[192]; alignas(16) static u32 tbl[VB_TABLE_WORDS];
+  alignas(16) uint8_t b[192]; alignas(16) static u32 tbl[VB_VERIFY_WORDS];
   memcpy(b, pk, 64); memcpy(b + 64, r, 64); memcpy(b + 128, s, 32); memcpy(b + 160, msg, 32);
   VerifyIn in = {b, b + 64, b + 128, b + 160};
   return verify_item(in, table_ptr(), g_W, g_nwin, tbl, K) ? 1 : 0;

@@ -45,3 +45,51 @@ def test_emul_verify_golden(emul, golden):
     v = golden["reference_kats"]["circomlib_testvector"]
     assert emul.emul_verify(pack([tuple(v["pk"])]).tobytes(), pack([tuple(v["r_b8"])]).tobytes(), le32(v["s"]),
                             le32(v["msg"]), 6) == 1
+
+
+def test_emul_verify_half_size_scalar_boundaries(emul, oracle, pyoracle):
+    """The EdDSA fast path multiplies the check by a short odd v (bjj_device.hpp: lattice_short_pair).
+    Properties of the pair on edge / random kappa, and verdicts for signatures whose pair sits at the
+    window-count boundary (>= 131 bits), found by scanning seeded candidates with the oracle's Poseidon."""
+    import numpy as np
+    from babyjubjub_rs_amd import workload as w
+    o = pyoracle
+    L = o.SUBORDER
+    uo, vo = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    ks = [0, 1, 2, 3, L - 1, L - 2, (L + 1) // 2, (L - 1) // 2, 1 << 126, (1 << 126) - 1, (1 << 126) + 1, 1 << 250,
+          L // 3, L - (1 << 126), (1 << 200) + 1] + w.to_ints(w.random_u256(0xABCDEF, 3000))
+    for k in ks:
+        k %= L
+        neg = emul.emul_short_pair(le32(k), uo, vo)
+        u, v = unpack(uo.raw)[0], unpack(vo.raw)[0]
+        v = -v if neg else v
+        assert (u - v * k) % L == 0 and v % 2 == 1 and v % L != 0, k
+
+    def pair_bits(kappa):  # independent restatement of the selection rule
+        r0, t0, r1, t1 = L, 0, kappa, 1
+        while r1 >= (1 << 126):
+            q = r0 // r1
+            r0, r1, t0, t1 = r1, r0 - q * r1, t1, t0 - q * t1
+        if t1 % 2:
+            return max(r1.bit_length(), abs(t1).bit_length())
+        best = max(r0.bit_length(), abs(t0).bit_length())
+        q = r0 // r1
+        r2, t2 = r0 - q * r1, t0 - q * t1
+        if r2:
+            best = min(best, max(r2.bit_length(), abs(t2).bit_length()))
+        return best
+
+    n = 6000
+    kk = [v % L for v in w.to_ints(w.random_u256(w.SEED_KEYS ^ 0xB0, n))]
+    rho = [v % L for v in w.to_ints(w.random_u256(w.SEED_NONCES ^ 0xB0, n))]
+    msg = w.random_u256(w.SEED_MSGS ^ 0xB0, n, 0, 3)
+    A, R = oracle.mul_fixed_base(w.from_ints(kk)), oracle.mul_fixed_base(w.from_ints(rho))
+    hm = w.to_ints(oracle.poseidon5(np.concatenate([R, A, msg], axis=1)))
+    picks = [i for i in range(n) if pair_bits(hm[i] % L) >= 131][:6] + [0, 1]
+    assert len(picks) >= 3
+    for i in picks:
+        S = (rho[i] + 8 * hm[i] * kk[i]) % L
+        for s in (S, S ^ 2):
+            got = emul.emul_verify(A[i].tobytes(), R[i].tobytes(), le32(s), msg[i].tobytes(), 6)
+            want = oracle.verify(A[i], R[i], np.frombuffer(le32(s), np.uint8), msg[i])[0]
+            assert got == want == (1 if s == S else 0), (i, pair_bits(hm[i] % L))
