@@ -252,27 +252,41 @@ BJJ_HD_NOINLINE Fr fr_pow_ts(const Fr& a) {
   }
   return x;
 }
-// Tonelli-Shanks with a data-independent schedule (no lane divergence): invariant x^2 = a*b,
-// ord(b) | 2^(v-1), ord(z) = 2^v.  Returns false for a == 0 (the reference's modsqrt errors on
-// 0, utils.rs:117-119) and for non-residues; root in Montgomery form, < 2r.
+// Square root in F_r (r - 1 = 2^28 s).  With w = a^((s-1)/2): x = a w satisfies x^2 = a b, b = a^s in the
+// subgroup <G> of order 2^28.  The discrete log e of b (four 7-bit digits, Pohlig-Hellman: 21 + 14 + 7
+// squarings and a 128-entry lookup per digit, tables from gen_tables.py) gives the root x G^(-e/2);
+// e is even exactly for residues.  Data-independent schedule (no lane divergence).  Returns false for
+// a == 0 (the reference's modsqrt errors on 0, utils.rs:117-119) and for non-residues; root < 2r.
+BJJ_HD u32 ts_digit(const Fr& c, const Consts& K) {  // c in <H> (order 128) -> its exponent
+  Fr cc = fr_canon(c);
+  return K.TSHASH[(cc.v[0] * BJJ_TS_HASH_MAGIC) >> 21];
+}
 BJJ_HD bool fr_sqrt(const Fr& a, Fr& root, const Consts& K) {
   Fr w = fr_pow_ts(a);
   Fr x = fr_mul(a, w);   // a^((s+1)/2)
   Fr b = fr_mul(x, w);   // a^s
-  Fr z = K.TS_G;
+  Fr c = b;
 #pragma unroll 1
-  for (int v = 28; v >= 2; v--) {
-    Fr t = b;
+  for (int i = 0; i < 21; i++) c = fr_sqr(c);
+  const u32 e0 = ts_digit(c, K);
+  b = fr_mul(b, K.TSN[e0]);
+  c = b;
 #pragma unroll 1
-    for (int k = 0; k < v - 2; k++) t = fr_sqr(t);
-    const bool fix = !fr_eq(t, fr_one());  // t is 1 or -1 for residues
-    Fr z2 = fr_sqr(z);
-    x = fr_select(fix, fr_mul(x, z), x);
-    b = fr_select(fix, fr_mul(b, z2), b);
-    z = z2;
-  }
+  for (int i = 0; i < 14; i++) c = fr_sqr(c);
+  const u32 e1 = ts_digit(c, K);
+  b = fr_mul(b, K.TSN[128 + e1]);
+  c = b;
+#pragma unroll 1
+  for (int i = 0; i < 7; i++) c = fr_sqr(c);
+  const u32 e2 = ts_digit(c, K);
+  b = fr_mul(b, K.TSN[256 + e2]);
+  const u32 e3 = ts_digit(b, K);
+  x = fr_mul(x, K.TSH[e0 >> 1]);
+  x = fr_mul(x, K.TSH[64 + e1]);
+  x = fr_mul(x, K.TSH[192 + e2]);
+  x = fr_mul(x, K.TSH[320 + e3]);
   root = x;
-  return fr_eq(fr_sqr(x), a) && !fr_is_zero(a);
+  return fr_eq(fr_sqr(x), a) && !fr_is_zero(a);   // also rejects odd e0 (non-residues) and garbage digits
 }
 // plain canonical N-form value > (r-1)/2 ?
 BJJ_HD bool plain_gt_halfq(const Fr& v, const Consts& K) {

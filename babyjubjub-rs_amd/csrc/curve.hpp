@@ -39,6 +39,10 @@ struct Consts {
   Fr PSP[660];      // per partial round: m00, v[5], what[5]
   Fr PAL[25];       // 5x5 block applied after the last partial round
   Fr PM[36];        // MDS, row-major
+  // Pohlig-Hellman tables of the square root (gen_tables.py): digit stripping / half-exponent factors / hash
+  Fr TSN[384];
+  Fr TSH[448];
+  unsigned char TSHASH[2048];
 };
 
 struct Ext { Fr X, Y, Z, T; };            // a' = -1 curve, extended

@@ -242,6 +242,39 @@ def main():
         n += 1
     o.append("#define BJJ_K_TS_G     %s  // %d^((r-1)/2^28): order 2^28" % (limbs32(mont(pow(n, ts_s, Q))), n))
     o.append("#define BJJ_K_HALFQ    %s  // PLAIN (r-1)/2" % limbs32((Q - 1) // 2))
+    # Pohlig-Hellman tables for the discrete log in <G> (order 2^28), four 7-bit digits e = sum e_k 2^(7k):
+    #   TSN[k][j] = G^(-j 2^(7k))            (k = 0..2)  strips digit k from b
+    #   TSH[k][j] = G^(-(j 2^(7k)) / 2)      (k = 0: index j/2, j even)  the matching factor of the root
+    #   hash: canonical Montgomery limb 0 of H^j (H = G^(2^21), order 128) -> j
+    G = pow(n, ts_s, Q)
+    Ginv = inv(G)
+    o.append("#define BJJ_K_TS_NEG { \\")
+    for k in range(3):
+        for j in range(128):
+            o.append("  %s, \\" % limbs32(mont(pow(Ginv, j << (7 * k), Q))))
+    o.append("}")
+    o.append("#define BJJ_K_TS_HALF { \\")
+    for j in range(64):
+        o.append("  %s, \\" % limbs32(mont(pow(Ginv, j, Q))))               # e0 = 2j  ->  G^(-j)
+    for k in range(1, 4):
+        for j in range(128):
+            o.append("  %s, \\" % limbs32(mont(pow(Ginv, j << (7 * k - 1), Q))))
+    o.append("}")
+    H = pow(G, 1 << 21, Q)
+    keys = [mont(pow(H, j, Q)) & 0x1FFFFFFF for j in range(128)]
+    assert len(set(keys)) == 128
+    import random as _r
+    rr = _r.Random(7)
+    while True:
+        magic = rr.getrandbits(32) | 1
+        slots = [((kk * magic) & 0xFFFFFFFF) >> 21 for kk in keys]             # 11-bit slot
+        if len(set(slots)) == 128:
+            break
+    table = [0] * 2048
+    for j, sl in enumerate(slots):
+        table[sl] = j
+    o.append("#define BJJ_TS_HASH_MAGIC 0x%08xu" % magic)
+    o.append("#define BJJ_K_TS_HASH { " + ",".join(str(v) for v in table) + " }")
     o.append("#define BJJ_K_FINV     %s  // 1/sqrt(-A), Montgomery" % limbs32(mont(inv(f))))
     # arithmetic mod l (scalar side of sign, lib.rs:328, 335-339): Montgomery radix 2^261 as well
     Lm = SUBORDER
