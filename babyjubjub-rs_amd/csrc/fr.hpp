@@ -181,15 +181,27 @@ inline void fr_check_mul_operands(const Fr& a, const Fr& b) {
 #endif
 
 // One multiply-accumulate step of a limb column: acc += x * y (64-bit, never overflows by
-// the column bound above); hipcc selects v_mad_u64_u32.  (Pinning the chain with one inline
-// asm per multiply-add was measured and rejected: hipcc pads every asm statement with an
-// s_nop -- tools/ubench/fr_bench.hip, profiles/r01_fr_bench_*.txt.)
+// the column bound above); hipcc selects v_mad_u64_u32.  Left to itself hipcc splits the
+// columns into 17 accumulators joined by v_lshl_add_u64 (as expensive as a multiply on gfx950)
+// and 34 extra VGPRs.  On the device fr_mul / fr_sqr therefore come from fr_mul_columns.inc
+// (gen_fr_asm.py): ONE inline-asm statement per column part, a single accumulator chain --
+// 208 instead of 233 VALU instructions and 30 instead of 58 VGPRs per multiply; +4..10 % on
+// every kernel (profiles/r01_ab_column_asm_multiplier.txt).  One statement per multiply-add
+// was measured first and rejected: hipcc pads every asm statement with an s_nop.
+// -DBJJ_NO_ASM_COLUMNS selects this portable form on the device too (A/B, and the host).
 #define BJJ_MAD(acc, x, y) acc += (u64)(x) * (y)
 #define BJJ_MAD_K(acc, x, k) acc += (u64)(x) * (k)
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BJJ_NO_ASM_COLUMNS)
+#include "fr_mul_columns.inc"  // gen_fr_asm.py: one asm statement per limb-column part
+#endif
 
 // Montgomery product a*b*2^-261 mod r, product-scanning, one 64-bit accumulator.
 BJJ_HD Fr fr_mul(const Fr& a, const Fr& b) {
   BJJ_CHECK_MUL(a, b);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BJJ_NO_ASM_COLUMNS)
+  return fr_mul_columns(a, b);
+#endif
   u32 m[NL];
   Fr r;
   u64 acc = 0;
@@ -219,6 +231,9 @@ BJJ_HD Fr fr_mul(const Fr& a, const Fr& b) {
 // Montgomery square: cross terms once, against a pre-doubled copy.
 BJJ_HD Fr fr_sqr(const Fr& a) {
   BJJ_CHECK_MUL(a, a);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BJJ_NO_ASM_COLUMNS)
+  return fr_sqr_columns(a);
+#endif
   u32 m[NL], a2[NL];
 #pragma unroll
   for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;

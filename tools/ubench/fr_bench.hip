@@ -1,6 +1,6 @@
 // Field-operation throughput microbenchmark (developer tool): dependent chains of fr_mul /
 // fr_sqr / ext_madd / ext_dbl per lane, at 1..4 waves per SIMD.  Build twice to A/B the
-// multiplier: default (asm-pinned single accumulator) and -DBJJ_NO_ASM_MAD (compiler form).
+// multiplier: default (one asm statement per column part) and -DBJJ_NO_ASM_COLUMNS (compiler form).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../babyjubjub-rs_amd/csrc/curve.hpp"
@@ -56,10 +56,10 @@ int main() {
     {"fr_mul  (x4 per iter)", k_mul, 4}, {"fr_sqr  (x4 per iter)", k_sqr, 4}, {"add+sub+2 reduce4", k_addsub, 1},
     {"ext_madd (7M)", k_madd, 1}, {"ext_dbl<T> (4M+4S)", k_dbl, 1}};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-#ifdef BJJ_NO_ASM_MAD
+#ifdef BJJ_NO_ASM_COLUMNS
   printf("variant: compiler-scheduled columns\n");
 #else
-  printf("variant: asm-pinned single accumulator\n");
+  printf("variant: one asm statement per column part (BJJ_ASM_COLUMNS)\n");
 #endif
   printf("%-24s %12s %12s %12s %12s   (nominal-clock cycles per op per SIMD; Gops/s chip-wide at 4 w/SIMD)\n", "op", "1w/SIMD", "2w/SIMD", "3w/SIMD", "4w/SIMD");
   const int iters = 2000;
