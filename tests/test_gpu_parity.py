@@ -239,3 +239,19 @@ def test_full_size_verify_1m(gpu_ctx, oracle):
     got = gpu_ctx.eddsa_verify(A, R, S, msg)
     assert (got == (~bad).astype(np.uint8)).all()
     assert (got[idx] == oracle.verify(A[idx], R[idx], S[idx], msg[idx])).all()
+
+
+def test_config0_bench_point_1k_scalars(gpu_ctx, oracle, golden):
+    """BASELINE.json configs[0]: benches/bench_babyjubjub.rs:15-38 -- mul_scalar on the bench point with
+    1 000 random 254-bit scalars (SURVEY.md 8d cfg 1) plus the two literal criterion scalars."""
+    from babyjubjub_rs_amd import workload as w
+    b = golden["reference_kats"]["bench_inputs"]
+    n = 1000
+    sc = w.scalars_254(n)
+    sc = np.concatenate([sc, pack(b["scalars"]).reshape(-1, 32)])
+    pts = np.tile(pack([tuple(b["p"])]), (sc.shape[0], 1))
+    got = gpu_ctx.mul_var_base(pts, sc)
+    assert (got == oracle.mul_var_base(pts, sc)).all()
+    import hashlib
+    # the digest is printed so a maintainer can compare runs / boxes; the byte comparison above is the test
+    print("cfg0 output sha256:", hashlib.sha256(got.tobytes()).hexdigest())
