@@ -433,9 +433,12 @@ struct bjj_ctx {
   uint8_t* codec = nullptr;    // verify_compressed: n * (64 pk + 64 R + 32 s + 2 flags) bytes
   size_t codec_items = 0;
   int occ_decomp = 1, occ_sign = 1;
-  // staging buffers for the host-pointer API
-  uint8_t* stage = nullptr;
-  size_t stage_bytes = 0;
+  // host-pointer API: chunked pipeline  user memory -> pinned[b] -H2D-> dstage[b] -kernel-> dstage[b] -D2H-> pinned[b] -> user
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+  uint8_t* pinned[2] = {nullptr, nullptr};
+  uint8_t* dstage[2] = {nullptr, nullptr};
+  size_t pipe_bytes = 0;
 };
 
 static int grid_for(const bjj_ctx* c, size_t n, int blocks_per_cu, int block = BJJ_BLOCK) {
@@ -472,13 +475,79 @@ static int ensure_scratch(bjj_ctx* c, size_t n) {
   }
   return BJJ_OK;
 }
-static int ensure_stage(bjj_ctx* c, size_t bytes) {
-  if (bytes > c->stage_bytes) {
-    if (c->stage) { HIPCK(hipStreamSynchronize(c->stream)); HIPCK(hipFree(c->stage)); c->stage = nullptr; }
-    HIPCK(hipMalloc((void**)&c->stage, bytes));
-    c->stage_bytes = bytes;
+// ---------------------------------------------------------------------------
+// Host-pointer API plumbing.  Pageable hipMemcpy runs at ~3 GB/s and would dominate every call
+// (29.8 ms of copies around a 1.1 ms kernel for 2^20 fixed-base multiplications), so batches are
+// cut into chunks that flow through two pinned staging buffers: while the kernels of chunk c run
+// on the context's stream, chunk c+1 is copied in (s_in) and chunk c-1 is copied out (s_out).
+// Kernels of different chunks stay on ONE stream, so the context's scratch is never shared.
+// ---------------------------------------------------------------------------
+#define BJJ_PIPE_CHUNK ((size_t)1 << 18)
+struct PipeSpec {
+  int n_in, n_out;
+  const uint8_t* in[4]; size_t in_stride[4];
+  uint8_t* out[4];      size_t out_stride[4];
+};
+static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+static int ensure_pipe(bjj_ctx* c, size_t bytes) {
+  HIPCK(hipSetDevice(c->device));
+  if (!c->s_in) {
+    HIPCK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+    HIPCK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+      HIPCK(hipEventCreateWithFlags(&c->ev_in[b], hipEventDisableTiming));
+      HIPCK(hipEventCreateWithFlags(&c->ev_k[b], hipEventDisableTiming));
+      HIPCK(hipEventCreateWithFlags(&c->ev_out[b], hipEventDisableTiming));
+    }
+  }
+  if (bytes > c->pipe_bytes) {
+    HIPCK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < 2; b++) {
+      if (c->pinned[b]) { HIPCK(hipHostFree(c->pinned[b])); c->pinned[b] = nullptr; }
+      if (c->dstage[b]) { HIPCK(hipFree(c->dstage[b])); c->dstage[b] = nullptr; }
+      HIPCK(hipHostMalloc((void**)&c->pinned[b], bytes, hipHostMallocDefault));
+      HIPCK(hipMalloc((void**)&c->dstage[b], bytes));
+    }
+    c->pipe_bytes = bytes;
   }
   return BJJ_OK;
+}
+// launch(d_in[], d_out[], count, stream) enqueues the kernels of one chunk on `stream`
+template <typename Launch>
+static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch) {
+  const size_t chunk = n < BJJ_PIPE_CHUNK ? n : BJJ_PIPE_CHUNK;
+  size_t off_in[4], off_out[4], tot = 0, in_bytes = 0;
+  for (int i = 0; i < sp.n_in; i++) { off_in[i] = tot; tot += up16(chunk * sp.in_stride[i]); }
+  in_bytes = tot;
+  for (int i = 0; i < sp.n_out; i++) { off_out[i] = tot; tot += up16(chunk * sp.out_stride[i]); }
+  int rc = ensure_pipe(c, tot); if (rc) return rc;
+  const size_t nchunks = (n + chunk - 1) / chunk;
+  auto drain = [&](size_t ch) -> int {  // copy the finished outputs of chunk `ch` to user memory
+    const int b = (int)(ch & 1);
+    const size_t lo = ch * chunk, cnt = (lo + chunk <= n ? chunk : n - lo);
+    HIPCK(hipEventSynchronize(c->ev_out[b]));
+    for (int i = 0; i < sp.n_out; i++) memcpy(sp.out[i] + lo * sp.out_stride[i], c->pinned[b] + off_out[i], cnt * sp.out_stride[i]);
+    return BJJ_OK;
+  };
+  for (size_t ch = 0; ch < nchunks; ch++) {
+    const int b = (int)(ch & 1);
+    const size_t lo = ch * chunk, cnt = (lo + chunk <= n ? chunk : n - lo);
+    if (ch >= 2) { rc = drain(ch - 2); if (rc) return rc; }     // frees pinned[b] and dstage[b]
+    for (int i = 0; i < sp.n_in; i++) memcpy(c->pinned[b] + off_in[i], sp.in[i] + lo * sp.in_stride[i], cnt * sp.in_stride[i]);
+    HIPCK(hipMemcpyAsync(c->dstage[b], c->pinned[b], in_bytes, hipMemcpyHostToDevice, c->s_in));
+    HIPCK(hipEventRecord(c->ev_in[b], c->s_in));
+    HIPCK(hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
+    void* d_in[4]; void* d_out[4];
+    for (int i = 0; i < sp.n_in; i++) d_in[i] = c->dstage[b] + off_in[i];
+    for (int i = 0; i < sp.n_out; i++) d_out[i] = c->dstage[b] + off_out[i];
+    rc = launch(d_in, d_out, cnt, (void*)c->stream); if (rc) return rc;
+    HIPCK(hipEventRecord(c->ev_k[b], c->stream));
+    HIPCK(hipStreamWaitEvent(c->s_out, c->ev_k[b], 0));
+    HIPCK(hipMemcpyAsync(c->pinned[b] + in_bytes, c->dstage[b] + in_bytes, tot - in_bytes, hipMemcpyDeviceToHost, c->s_out));
+    HIPCK(hipEventRecord(c->ev_out[b], c->s_out));
+  }
+  if (nchunks >= 2) { rc = drain(nchunks - 2); if (rc) return rc; }
+  return drain(nchunks - 1);
 }
 static int ensure_codec(bjj_ctx* c, size_t n) {  // 162 bytes per item of intermediate records
   HIPCK(hipSetDevice(c->device));
@@ -551,7 +620,15 @@ void bjj_free(bjj_ctx* c) {
   if (c->vb_tables) hipFree(c->vb_tables);
   if (c->slow) hipFree(c->slow);
   if (c->codec) hipFree(c->codec);
-  if (c->stage) hipFree(c->stage);
+  for (int b = 0; b < 2; b++) {
+    if (c->pinned[b]) hipHostFree(c->pinned[b]);
+    if (c->dstage[b]) hipFree(c->dstage[b]);
+    if (c->ev_in[b]) hipEventDestroy(c->ev_in[b]);
+    if (c->ev_k[b]) hipEventDestroy(c->ev_k[b]);
+    if (c->ev_out[b]) hipEventDestroy(c->ev_out[b]);
+  }
+  if (c->s_in) hipStreamDestroy(c->s_in);
+  if (c->s_out) hipStreamDestroy(c->s_out);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -748,180 +825,74 @@ int bjj_sign_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, v
   return BJJ_OK;
 }
 
-// ---- host-pointer API: stage -> *_dev -> copy back ----------------------------
-static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+// ---- host-pointer API: chunked pinned-staging pipeline around the *_dev entry points ----------
+#define HOST_PROLOGUE(name, cond)                                             \
+  CHECK_CTX(c, name);                                                         \
+  if (n == 0) return BJJ_OK;                                                  \
+  if (cond) return set_err(BJJ_E_INVALID, name ": NULL buffer")
 
 int bjj_mul_fixed_base(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* out) {
-  CHECK_CTX(c, "bjj_mul_fixed_base");
-  if (n == 0) return BJJ_OK;
-  if (!scalars || !out) return set_err(BJJ_E_INVALID, "bjj_mul_fixed_base: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_in = 0, o_out = up16(n * 32);
-  int rc = ensure_stage(c, o_out + n * 64); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage + o_in, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_mul_fixed_base_dev(c, c->stage + o_in, n, c->stage + o_out, nullptr); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_mul_fixed_base", !scalars || !out);
+  PipeSpec sp = {1, 1, {scalars}, {32}, {out}, {64}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_fixed_base_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_mul_var_base(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out) {
-  CHECK_CTX(c, "bjj_mul_var_base");
-  if (n == 0) return BJJ_OK;
-  if (!pts || !scalars || !out) return set_err(BJJ_E_INVALID, "bjj_mul_var_base: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_p = 0, o_s = up16(n * 64), o_out = o_s + up16(n * 32);
-  int rc = ensure_stage(c, o_out + n * 64); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage + o_p, pts, n * 64, hipMemcpyHostToDevice, c->stream));
-  HIPCK(hipMemcpyAsync(c->stage + o_s, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_mul_var_base_dev(c, c->stage + o_p, c->stage + o_s, n, c->stage + o_out, nullptr); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_mul_var_base", !pts || !scalars || !out);
+  PipeSpec sp = {2, 1, {pts, scalars}, {64, 32}, {out}, {64}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_var_base_dev(c, i[0], i[1], cnt, o[0], st); });
 }
 int bjj_poseidon5(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out) {
-  CHECK_CTX(c, "bjj_poseidon5");
-  if (n == 0) return BJJ_OK;
-  if (!in || !out) return set_err(BJJ_E_INVALID, "bjj_poseidon5: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_out = up16(n * 160);
-  int rc = ensure_stage(c, o_out + n * 32); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage, in, n * 160, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_poseidon5_dev(c, c->stage, n, c->stage + o_out, nullptr); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 32, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_poseidon5", !in || !out);
+  PipeSpec sp = {1, 1, {in}, {160}, {out}, {32}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_poseidon5_dev(c, i[0], cnt, o[0], st); });
 }
-static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg,
-                       size_t n, uint8_t* ok);
 int bjj_eddsa_verify(bjj_ctx* c, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n,
                      uint8_t* ok) {
-  return verify_host(c, false, pk, r, s, msg, n, ok);
+  HOST_PROLOGUE("bjj_eddsa_verify", !pk || !r || !s || !msg || !ok);
+  PipeSpec sp = {4, 1, {pk, r, s, msg}, {64, 64, 32, 32}, {ok}, {1}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_eddsa_verify_dev(c, i[0], i[1], i[2], i[3], cnt, o[0], st); });
 }
 int bjj_schnorr_verify(bjj_ctx* c, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n,
                        uint8_t* ok) {
-  return verify_host(c, true, pk, r, s, msg, n, ok);
-}
-static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg,
-                       size_t n, uint8_t* ok) {
-  CHECK_CTX(c, "bjj_eddsa_verify / bjj_schnorr_verify");
-  if (n == 0) return BJJ_OK;
-  if (!pk || !r || !s || !msg || !ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify / bjj_schnorr_verify: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_pk = 0, o_r = up16(n * 64), o_s = o_r + up16(n * 64), o_m = o_s + up16(n * 32), o_ok = o_m + up16(n * 32);
-  int rc = ensure_stage(c, o_ok + n); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage + o_pk, pk, n * 64, hipMemcpyHostToDevice, c->stream));
-  HIPCK(hipMemcpyAsync(c->stage + o_r, r, n * 64, hipMemcpyHostToDevice, c->stream));
-  HIPCK(hipMemcpyAsync(c->stage + o_s, s, n * 32, hipMemcpyHostToDevice, c->stream));
-  HIPCK(hipMemcpyAsync(c->stage + o_m, msg, n * 32, hipMemcpyHostToDevice, c->stream));
-  rc = verify_launch(c, schnorr, c->stage + o_pk, c->stage + o_r, c->stage + o_s, c->stage + o_m, n, c->stage + o_ok, nullptr,
-                     schnorr ? "bjj_schnorr_verify" : "bjj_eddsa_verify");
-  if (rc) return rc;
-  HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_schnorr_verify", !pk || !r || !s || !msg || !ok);
+  PipeSpec sp = {4, 1, {pk, r, s, msg}, {64, 64, 32, 32}, {ok}, {1}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_schnorr_verify_dev(c, i[0], i[1], i[2], i[3], cnt, o[0], st); });
 }
 int bjj_point_add(bjj_ctx* c, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out) {
-  CHECK_CTX(c, "bjj_point_add");
-  if (n == 0) return BJJ_OK;
-  if (!p || !q || !out) return set_err(BJJ_E_INVALID, "bjj_point_add: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_q = up16(n * 64), o_out = o_q + up16(n * 64);
-  int rc = ensure_stage(c, o_out + n * 64); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage, p, n * 64, hipMemcpyHostToDevice, c->stream));
-  HIPCK(hipMemcpyAsync(c->stage + o_q, q, n * 64, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_point_add_dev(c, c->stage, c->stage + o_q, n, c->stage + o_out, nullptr); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_point_add", !p || !q || !out);
+  PipeSpec sp = {2, 1, {p, q}, {64, 64}, {out}, {64}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_point_add_dev(c, i[0], i[1], cnt, o[0], st); });
 }
-
 int bjj_compress_points(bjj_ctx* c, const uint8_t* pts, size_t n, uint8_t* out) {
-  CHECK_CTX(c, "bjj_compress_points");
-  if (n == 0) return BJJ_OK;
-  if (!pts || !out) return set_err(BJJ_E_INVALID, "bjj_compress_points: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_out = up16(n * 64);
-  int rc = ensure_stage(c, o_out + n * 32); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage, pts, n * 64, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_compress_points_dev(c, c->stage, n, c->stage + o_out, nullptr); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 32, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_compress_points", !pts || !out);
+  PipeSpec sp = {1, 1, {pts}, {64}, {out}, {32}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_compress_points_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_decompress_points(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out_xy, uint8_t* ok) {
-  CHECK_CTX(c, "bjj_decompress_points");
-  if (n == 0) return BJJ_OK;
-  if (!in || !out_xy || !ok) return set_err(BJJ_E_INVALID, "bjj_decompress_points: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_out = up16(n * 32), o_ok = o_out + up16(n * 64);
-  int rc = ensure_stage(c, o_ok + n); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage, in, n * 32, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_decompress_points_dev(c, c->stage, n, c->stage + o_out, c->stage + o_ok, nullptr); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(out_xy, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_decompress_points", !in || !out_xy || !ok);
+  PipeSpec sp = {1, 2, {in}, {32}, {out_xy, ok}, {64, 1}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_decompress_points_dev(c, i[0], cnt, o[0], o[1], st); });
 }
 int bjj_eddsa_verify_compressed(bjj_ctx* c, const uint8_t* pk32, const uint8_t* sig64, const uint8_t* msg, size_t n,
                                 uint8_t* ok) {
-  CHECK_CTX(c, "bjj_eddsa_verify_compressed");
-  if (n == 0) return BJJ_OK;
-  if (!pk32 || !sig64 || !msg || !ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_compressed: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_sig = up16(n * 32), o_m = o_sig + up16(n * 64), o_ok = o_m + up16(n * 32);
-  int rc = ensure_stage(c, o_ok + n); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage, pk32, n * 32, hipMemcpyHostToDevice, c->stream));
-  HIPCK(hipMemcpyAsync(c->stage + o_sig, sig64, n * 64, hipMemcpyHostToDevice, c->stream));
-  HIPCK(hipMemcpyAsync(c->stage + o_m, msg, n * 32, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_eddsa_verify_compressed_dev(c, c->stage, c->stage + o_sig, c->stage + o_m, n, c->stage + o_ok, nullptr);
-  if (rc) return rc;
-  HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_eddsa_verify_compressed", !pk32 || !sig64 || !msg || !ok);
+  PipeSpec sp = {3, 1, {pk32, sig64, msg}, {32, 64, 32}, {ok}, {1}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_eddsa_verify_compressed_dev(c, i[0], i[1], i[2], cnt, o[0], st); });
 }
-
 int bjj_scalar_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out) {
-  CHECK_CTX(c, "bjj_scalar_keys");
-  if (n == 0) return BJJ_OK;
-  if (!keys || !out) return set_err(BJJ_E_INVALID, "bjj_scalar_keys: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_out = up16(n * 32);
-  int rc = ensure_stage(c, o_out + n * 32); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage, keys, n * 32, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_scalar_keys_dev(c, c->stage, n, c->stage + o_out, nullptr); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(out, c->stage + o_out, n * 32, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_scalar_keys", !keys || !out);
+  PipeSpec sp = {1, 1, {keys}, {32}, {out}, {32}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_scalar_keys_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_public_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out_xy) {
-  CHECK_CTX(c, "bjj_public_keys");
-  if (n == 0) return BJJ_OK;
-  if (!keys || !out_xy) return set_err(BJJ_E_INVALID, "bjj_public_keys: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_out = up16(n * 32);
-  int rc = ensure_stage(c, o_out + n * 64); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage, keys, n * 32, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_public_keys_dev(c, c->stage, n, c->stage + o_out, nullptr); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(out_xy, c->stage + o_out, n * 64, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_public_keys", !keys || !out_xy);
+  PipeSpec sp = {1, 1, {keys}, {32}, {out_xy}, {64}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_public_keys_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_sign(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
-  CHECK_CTX(c, "bjj_sign");
-  if (n == 0) return BJJ_OK;
-  if (!keys || !msgs || !out_r || !out_s || !ok) return set_err(BJJ_E_INVALID, "bjj_sign: NULL buffer");
-  HIPCK(hipSetDevice(c->device));
-  size_t o_m = up16(n * 32), o_r = o_m + up16(n * 32), o_s = o_r + up16(n * 64), o_ok = o_s + up16(n * 32);
-  int rc = ensure_stage(c, o_ok + n); if (rc) return rc;
-  HIPCK(hipMemcpyAsync(c->stage, keys, n * 32, hipMemcpyHostToDevice, c->stream));
-  HIPCK(hipMemcpyAsync(c->stage + o_m, msgs, n * 32, hipMemcpyHostToDevice, c->stream));
-  rc = bjj_sign_dev(c, c->stage, c->stage + o_m, n, c->stage + o_r, c->stage + o_s, c->stage + o_ok, nullptr);
-  if (rc) return rc;
-  HIPCK(hipMemcpyAsync(out_r, c->stage + o_r, n * 64, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipMemcpyAsync(out_s, c->stage + o_s, n * 32, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipMemcpyAsync(ok, c->stage + o_ok, n, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(hipStreamSynchronize(c->stream));
-  return BJJ_OK;
+  HOST_PROLOGUE("bjj_sign", !keys || !msgs || !out_r || !out_s || !ok);
+  PipeSpec sp = {2, 3, {keys, msgs}, {32, 32}, {out_r, out_s, ok}, {64, 32, 1}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_sign_dev(c, i[0], i[1], cnt, o[0], o[1], o[2], st); });
 }
 
 #pragma GCC visibility pop
