@@ -373,7 +373,7 @@ def main():
             from conftest import Oracle
             orc = Oracle()
         result["parity_sample_ok"] = wl.check_sample(orc)
-        if not args.no_also and not args.scatter:
+        if not args.no_also and not args.scatter and world == 1:  # secondary lines only in the 1-GPU run
             also = {}
             for k2, n2, s2 in (("verify", n, 5), ("var_base", n, 5)):
                 if k2 == kind:
