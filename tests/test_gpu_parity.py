@@ -255,3 +255,34 @@ def test_config0_bench_point_1k_scalars(gpu_ctx, oracle, golden):
     import hashlib
     # the digest is printed so a maintainer can compare runs / boxes; the byte comparison above is the test
     print("cfg0 output sha256:", hashlib.sha256(got.tobytes()).hexdigest())
+
+
+def test_verify_small_order_and_torsion_cases(gpu_ctx, oracle, pyoracle):
+    """verdicts that hinge on the cofactor: pk of small order (8*hm*pk vanishes, so s*B8 == R decides),
+    R or pk shifted by torsion points, s beyond l.  The GPU path multiplies the check by a short ODD v,
+    which must not change any of these verdicts (verify)."""
+    from babyjubjub_rs_amd import workload as w
+    o = pyoracle
+    tors = [o.mul_scalar(o.T8, c) for c in range(8)]          # the 8 points of order dividing 8
+    n = 96
+    s_int = [v % (8 * L) for v in w.to_ints(w.random_u256(0x7075, n))]
+    sB = oracle.mul_fixed_base(w.from_ints(s_int))
+    msg = w.random_u256(0x7076, n, 0, top_bits_cleared=3)
+    pk, R, S, want_true = [], [], [], []
+    for i in range(n):
+        t1, t2 = tors[i % 8], tors[(i // 8) % 8]
+        sb = unpack(sB[i], 2)[0]
+        if i % 3 == 0:      # small-order pk, R = s*B8           -> true
+            pk.append(t1); R.append(sb); want_true.append(True)
+        elif i % 3 == 1:    # small-order pk, R = s*B8 + torsion -> true only if the shift is the identity
+            pk.append(t1); R.append(o.proj_affine(o.proj_add(sb + (1,), t2 + (1,)))); want_true.append(t2 == (0, 1))
+        else:               # random pk: just compare with the oracle
+            pk.append(unpack(sB[(i + 1) % n], 2)[0]); R.append(sb); want_true.append(None)
+        S.append(s_int[i])
+    got = gpu_ctx.eddsa_verify(pack(pk), pack(R), pack(S), msg)
+    want = oracle.verify(pack(pk), pack(R), pack(S), msg)
+    assert (got == want).all()
+    for i, wt in enumerate(want_true):
+        if wt is not None:
+            assert bool(got[i]) == wt, i
+    assert got.sum() >= n // 3
