@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_build_fixed_table(u32* table,
 // ---------------------------------------------------------------------------
 // K1: fixed base
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BJJ_EPI_BLOCK, 4) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
+__global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
                                                                   const uint8_t* __restrict__ scalars, size_t n,
                                                                   uint8_t* __restrict__ out, u32* __restrict__ scratch) {
   __shared__ u32 lds[NL * BJJ_EPI_BLOCK];

@@ -85,3 +85,13 @@ def test_workload_generator_matches_oracle_splitmix(pyoracle):
     assert w.to_ints(w.scalars_254(4, offset=6)) == want[6:]
     assert [w.shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert w.shard_bounds(2, 4, 3) == (2, 2)
+
+
+def test_library_is_not_older_than_its_sources():
+    """a stale libbjj_hip.so (sources edited, library not rebuilt) invalidates every GPU measurement"""
+    d = os.path.join(ROOT, "babyjubjub-rs_amd", "csrc")
+    so = os.path.join(d, "libbjj_hip.so")
+    srcs = ["bjj_hip.hip", "fr.hpp", "fr_mul_columns.inc", "curve.hpp", "poseidon.hpp", "bjj_device.hpp", "sign.hpp",
+            "bjj_constants.inc", os.path.join("..", "..", "include", "bjj_hip.h")]
+    newest = max(os.path.getmtime(os.path.join(d, s)) for s in srcs)
+    assert os.path.getmtime(so) >= newest, "rebuild: python -c 'import __graft_entry__ as g; g.build()'"
