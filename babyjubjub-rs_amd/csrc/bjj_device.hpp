@@ -1,6 +1,6 @@
 // Per-item bodies of the hot path (one item per lane).  __host__ __device__ so
 // that tests/emul can run exactly this code on the CPU with bound assertions; the
-// shipped library only instantiates them inside HIP kernels (bjj_kernels.hip).
+// shipped library only instantiates them inside HIP kernels (bjj_hip.hip).
 #pragma once
 #include "poseidon.hpp"
 #include "bjj_constants.inc"  // BJJ_L_NINV29 (macros only; safe to include repeatedly)
@@ -20,20 +20,6 @@ BJJ_HD void store_w8(void* p, const u32 w[8]) {
   U4 a = {w[0], w[1], w[2], w[3]}, b = {w[4], w[5], w[6], w[7]};
   q[0] = a; q[1] = b;
 }
-// raw 9-limb field element <-> 48-byte slot (3 x 16 B; 3 words of padding)
-constexpr int FR_SLOT_WORDS = 12;
-BJJ_HD Fr load_fr_slot(const u32* p) {
-  const U4* q = (const U4*)p;
-  U4 a = q[0], b = q[1], c = q[2];
-  Fr r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x}};
-  return r;
-}
-BJJ_HD void store_fr_slot(u32* p, const Fr& f) {
-  U4* q = (U4*)p;
-  U4 a = {f.v[0], f.v[1], f.v[2], f.v[3]}, b = {f.v[4], f.v[5], f.v[6], f.v[7]}, c = {f.v[8], 0, 0, 0};
-  q[0] = a; q[1] = b; q[2] = c;
-}
-
 // ---- fixed-base table: entry = Niels in 32 words (128 B = one cache line) ----
 constexpr int NIELS_WORDS = 32;  // 27 used
 BJJ_HD Niels load_niels(const u32* p) {

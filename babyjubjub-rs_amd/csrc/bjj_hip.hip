@@ -2,16 +2,21 @@
 // include/bjj_hip.h.  There is no CPU fallback anywhere in this file: every entry
 // point launches device code or returns an error.
 //
-// Kernel map (SURVEY.md section 2 "kernel inventory"):
-//   bjj_k_build_fixed_table  init-time: window table of B8 multiples (Niels form)
-//   bjj_k_mul_fixed_base     K1  B8.mul_scalar(n)              src/lib.rs:149-164, 37-46
-//   bjj_k_mul_var_base       K2  P.mul_scalar(n) (+K6 exact path for off-curve P)
-//   bjj_k_poseidon5          K3  POSEIDON.hash([a,b,c,d,e])    src/lib.rs:400-404
-//   bjj_k_eddsa_verify       K4  verify(pk, sig, msg)          src/lib.rs:395-412
-//   bjj_k_point_add              PointProjective::add + affine src/lib.rs:88-131, 70-85
-// K5 (batched affine conversion) is the epilogue of K1/K2: Montgomery's trick per
-// lane over its items, then across the workgroup through LDS scans, so that ONE
-// Fermat inversion serves blockDim * items_per_lane points.
+// Kernel map (SURVEY.md section 2 "kernel inventory"; bodies in bjj_device.hpp / sign.hpp):
+//   bjj_k_build_fixed_table   init-time: window table of B8 multiples (affine Niels form)
+//   bjj_k_mul_fixed_base      K1  B8.mul_scalar(n)               src/lib.rs:149-164, 37-46
+//   bjj_k_mul_var_base        K2  P.mul_scalar(n), on-curve P    src/lib.rs:149-164
+//   bjj_k_mul_var_base_exact  K6  the reference's exact op sequence for off-curve P
+//   bjj_k_poseidon5           K3  POSEIDON.hash([a,b,c,d,e])     src/lib.rs:400-404
+//   bjj_k_eddsa_verify_scan / bjj_k_eddsa_verify / bjj_k_schnorr_verify
+//                             K4  verify / verify_schnorr        src/lib.rs:395-412, 375-385
+//   bjj_k_point_add               PointProjective::add + affine  src/lib.rs:88-131, 70-85
+//   bjj_k_compress_points / bjj_k_decompress_points / bjj_k_merge_codec_flags
+//                                 wire format                    src/lib.rs:166-224, 260-268
+//   bjj_k_scalar_keys / bjj_k_sign  signer side                  src/lib.rs:284-342
+// K5 (batched affine conversion) is the epilogue of K1/K2: Montgomery's trick per lane over its
+// items, then across the 512-lane workgroup through two LDS product scans, so that ONE
+// (binary-GCD) inversion serves blockDim * items_per_lane points.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,8 +32,8 @@ using namespace bjj;
 
 #define BJJ_VERSION_STRING "bjj-hip 0.1.0 gfx950"
 #define BJJ_BLOCK 256
-// Workgroup size of the kernels that end in the shared-inversion epilogue: one Fermat
-// inversion (381 multiplications on one wave) is amortised over the whole workgroup.
+// Workgroup size of the kernels that end in the shared-inversion epilogue: one binary-GCD
+// inversion (executed by one wave) is amortised over the whole workgroup.
 #define BJJ_EPI_BLOCK 512
 
 __constant__ Consts c_K = {
@@ -39,7 +44,7 @@ __constant__ Consts c_K = {
 
 // ---------------------------------------------------------------------------
 // workgroup-wide simultaneous inversion: every thread passes x (Montgomery, != 0,
-// < 2r) and receives 1/x.  Two LDS scans (prefix / suffix products) + one Fermat
+// < 2r) and receives 1/x.  Two LDS scans (prefix / suffix products) + one binary-GCD
 // inversion executed by wave 0.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void lds_put(u32* lds, int t, const Fr& f) {

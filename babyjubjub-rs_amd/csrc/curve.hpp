@@ -53,7 +53,6 @@ struct RefProj { Fr x, y, z; };           // reference PointProjective, src/lib.
 BJJ_HD Ext ext_identity() {
   Ext e; e.X = fr_zero(); e.Y = fr_one(); e.Z = fr_one(); e.T = fr_zero(); return e;
 }
-BJJ_HD Niels niels_identity() { Niels n; n.ymx = fr_one(); n.ypx = fr_one(); n.t2d = fr_zero(); return n; }
 
 // Limb discipline inside the formulas below: products of fr_mul/fr_sqr are N-form
 // (limbs < 2^29); sums/differences that feed exactly one multiplication stay carry-less
@@ -116,13 +115,6 @@ BJJ_HD PNiels pniels_cneg(const PNiels& n, bool neg) {
   r.ypx = fr_select(neg, n.ymx, n.ypx);
   r.t2d = fr_select(neg, fr_neg(n.t2d), n.t2d);
   r.z2 = n.z2;
-  return r;
-}
-BJJ_HD Niels niels_cneg(const Niels& n, bool neg) {
-  Niels r;
-  r.ymx = fr_select(neg, n.ypx, n.ymx);
-  r.ypx = fr_select(neg, n.ymx, n.ypx);
-  r.t2d = fr_select(neg, fr_neg(n.t2d), n.t2d);
   return r;
 }
 // affine point of the REFERENCE curve (Montgomery x, y) -> extended point on the a'=-1 curve

@@ -278,7 +278,6 @@ BJJ_HD Fr fr_reduce_weak(const Fr& x) {
   }
   return r;
 }
-BJJ_HD Fr fr_reduce4(const Fr& x) { return fr_reduce_weak(x); }
 
 // ---- constants in Montgomery form (R = 2^261) ----------------------------
 BJJ_HD Fr fr_one() {  // 2^261 mod r
