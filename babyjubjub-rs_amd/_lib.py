@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = (
     "bjj_version", "bjj_last_error", "bjj_init", "bjj_free", "bjj_sync", "bjj_stream",
     "bjj_mul_fixed_base", "bjj_mul_var_base", "bjj_poseidon5", "bjj_eddsa_verify", "bjj_point_add",
     "bjj_mul_fixed_base_dev", "bjj_mul_var_base_dev", "bjj_poseidon5_dev", "bjj_eddsa_verify_dev",
-    "bjj_point_add_dev", "bjj_reserve", "bjj_get_info",
+    "bjj_point_add_dev", "bjj_reserve", "bjj_get_info", "bjj_check_table",
     "bjj_compress_points", "bjj_decompress_points", "bjj_eddsa_verify_compressed",
     "bjj_schnorr_verify", "bjj_schnorr_verify_dev",
     "bjj_scalar_keys", "bjj_public_keys", "bjj_sign", "bjj_scalar_keys_dev", "bjj_public_keys_dev", "bjj_sign_dev",
@@ -69,6 +69,7 @@ def load():
     lib.bjj_stream.restype = vp
     lib.bjj_reserve.argtypes = [vp, sz]
     lib.bjj_get_info.argtypes = [vp, ctypes.POINTER(BjjInfo)]
+    lib.bjj_check_table.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.bjj_mul_fixed_base.argtypes = [vp, vp, sz, vp]
     lib.bjj_mul_var_base.argtypes = [vp, vp, vp, sz, vp]
     lib.bjj_poseidon5.argtypes = [vp, vp, sz, vp]

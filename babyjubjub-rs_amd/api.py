@@ -92,6 +92,12 @@ class Context:
         self._ck(self.lib.bjj_get_info(self.handle, ctypes.byref(i)), "bjj_get_info")
         return i
 
+    def check_table(self):
+        """number of violated link conditions of the fixed-base table (0 = sound), checked on the device"""
+        bad = ctypes.c_uint64(0)
+        self._ck(self.lib.bjj_check_table(self.handle, ctypes.byref(bad)), "bjj_check_table")
+        return bad.value
+
     def sync(self):
         self._ck(self.lib.bjj_sync(self.handle), "bjj_sync")
 

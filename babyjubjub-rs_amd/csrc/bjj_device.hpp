@@ -68,31 +68,70 @@ BJJ_HD void store_pniels(u32* p, const PNiels& n) {
 }
 
 // =============================================================================
-// fixed base:  acc + n * B8   with the precomputed window table
-//   table[j][k] = Niels( k * 2^(W j) * B8 ),  j < nwin, k < 2^W
+// fixed base:  acc + n * B8   with the precomputed signed-window table
+//   n is first reduced mod l (B8 has order l, so this is exact) and recoded into nwin = ceil(252 / W)
+//   signed digits d_j in [-2^(W-1), 2^(W-1)];  table[j][k] = Niels( k * 2^(W j) * B8 ), k = 0 .. 2^(W-1)
+//   (k = 0 is the identity entry), -k*P by swapping y-x / y+x and negating 2D'xy.
 // =============================================================================
+BJJ_HD int fixed_nwin(int W) { return (252 + W - 1) / W; }            // l < 2^251: the top digit absorbs the last carry
+BJJ_HD size_t fixed_stride(int W) { return ((size_t)1 << (W - 1)) + 1; }  // entries per window
+// 256-bit integer mod l (8 words in, 8 words out, < l)
+BJJ_HD void scalar_mod_l(const u32 w[8], u32 out[8], const Consts& K) {
+  Fr s = fr_from_words(w);  // < 2^256 < 64 l
+  s = fr_cond_sub_kr(s, K.ORDER4.v);
+  s = fr_cond_sub_kr(s, K.ORDER2.v);
+  s = fr_cond_sub_kr(s, K.ORDER.v);
+  s = fr_cond_sub_kr(s, K.L4.v);
+  s = fr_cond_sub_kr(s, K.L2.v);
+  s = fr_cond_sub_kr(s, K.L.v);
+  fr_to_words(s, out);
+}
+// signed digit j of sc (< l): returns the table slot, sets neg; carry threads through the windows LSB-first
+BJJ_HD size_t fixed_digit_slot(const u32 sc[8], int j, int W, u32& carry, bool& neg) {
+  const u32 u = scalar_window(sc, j, W) + carry;
+  neg = u > (1u << (W - 1));
+  carry = neg ? 1u : 0u;
+  const u32 d = neg ? (1u << W) - u : u;
+  return (size_t)j * fixed_stride(W) + d;
+}
+// -(x', y) = (-x', y): swap y-x' / y+x', negate 2D'x'y.  The negation stays carry-less (limbs < 2^30): the entry
+// only ever feeds one multiplication whose other operand is N-form.
+BJJ_HD Niels niels_cneg_lazy(const Niels& n, bool neg) {
+  Niels r;
+  r.ymx = fr_select(neg, n.ypx, n.ymx);
+  r.ypx = fr_select(neg, n.ymx, n.ypx);
+  r.t2d = fr_select(neg, fr_sub_lazy(fr_zero(), n.t2d), n.t2d);
+  return r;
+}
+BJJ_HD Niels fixed_load_signed(const u32* table, const u32 sc[8], int j, int W, u32& carry) {
+  bool neg;
+  const size_t slot = fixed_digit_slot(sc, j, W, carry, neg);
+  return niels_cneg_lazy(load_niels(table + slot * NIELS_WORDS), neg);
+}
+// acc + sc * B8, sc < l
 BJJ_HD Ext fixed_base_accumulate(Ext acc, const u32* table, int W, int nwin, const u32 sc[8]) {
-  Niels cur = load_niels(table + (size_t)scalar_window(sc, 0, W) * NIELS_WORDS);
+  u32 carry = 0;
+  Niels cur = fixed_load_signed(table, sc, 0, W, carry);
 #pragma unroll 1
   for (int j = 0; j < nwin; j++) {
     Niels nxt = cur;
-    if (j + 1 < nwin) {  // issue the next gather before the 7 multiplications of this window
-      size_t idx = ((size_t)(j + 1) << W) | scalar_window(sc, j + 1, W);
-      nxt = load_niels(table + idx * NIELS_WORDS);
-    }
+    if (j + 1 < nwin) nxt = fixed_load_signed(table, sc, j + 1, W, carry);  // next gather before this window's 7 multiplications
     acc = ext_madd(acc, cur);
     cur = nxt;
   }
   return acc;
 }
 
-// n * B8 from scratch: window 0's entry is lifted directly to extended coordinates
+// n * B8 from scratch (n any 256-bit integer): window 0's entry is lifted directly to extended coordinates
 // (X:Y:Z:T) = (2x' : 2y : 2 : 2x'y), T recovered from the stored 2D'x'y with one
 // multiplication by 1/D', instead of a 7M addition to the identity.
-BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 sc[8], const Consts& K) {
-  Niels n0 = load_niels(table + (size_t)scalar_window(sc, 0, W) * NIELS_WORDS);
+BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 raw[8], const Consts& K) {
+  u32 sc[8];
+  scalar_mod_l(raw, sc, K);
+  u32 carry = 0;
+  Niels n0 = fixed_load_signed(table, sc, 0, W, carry);
   Niels cur = n0;
-  if (nwin > 1) cur = load_niels(table + ((((size_t)1) << W) | scalar_window(sc, 1, W)) * NIELS_WORDS);
+  if (nwin > 1) cur = fixed_load_signed(table, sc, 1, W, carry);
   Ext acc;
   acc.X = fr_reduce_weak(fr_sub(n0.ypx, n0.ymx));  // ext_madd wants coordinates < 2r
   acc.Y = fr_add(n0.ypx, n0.ymx);
@@ -100,10 +139,7 @@ BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 sc[8], co
 #pragma unroll 1
   for (int j = 1; j < nwin; j++) {
     Niels nxt = cur;
-    if (j + 1 < nwin) {
-      size_t idx = ((size_t)(j + 1) << W) | scalar_window(sc, j + 1, W);
-      nxt = load_niels(table + idx * NIELS_WORDS);
-    }
+    if (j + 1 < nwin) nxt = fixed_load_signed(table, sc, j + 1, W, carry);
     acc = ext_madd(acc, cur);
     cur = nxt;
   }
@@ -194,6 +230,102 @@ BJJ_HD Niels fixed_table_entry(u32 k, int j, int W, const Consts& K) {
   Niels n;
   n.ymx = fr_canon(fr_sub(y, x)); n.ypx = fr_canon(fr_add(y, x)); n.t2d = fr_canon(fr_mul(fr_mul(x, y), K.D2P));
   return n;
+}
+
+// ---- table construction in chains ------------------------------------------------------------------
+// One thread owns `cnt` consecutive digits k0 .. k0+cnt-1 of window j (slots slot0 ..): it walks
+// k*P_j by repeated mixed addition of P_j, parks (X, Y, Z, running product of Z) of every step in the entry's
+// own 128-byte slot (4 x 8 words), inverts the final product once and walks back (Montgomery's trick),
+// overwriting each slot with the affine Niels form.  ~14 multiplications per entry instead of a
+// W(j+1)-step ladder and an inversion per entry (fixed_table_entry, kept as the independent definition).
+BJJ_HD void store_chain_slot(u32* p, const Fr& x, const Fr& y, const Fr& z, const Fr& pre) {
+  u32 w[8];
+  fr_to_words(x, w);   store_w8(p, w);        // N-form values < 2r < 2^256: 8 words hold them exactly
+  fr_to_words(y, w);   store_w8(p + 8, w);
+  fr_to_words(z, w);   store_w8(p + 16, w);
+  fr_to_words(pre, w); store_w8(p + 24, w);
+}
+BJJ_HD Fr load_chain_word(const u32* p) {
+  u32 w[8];
+  load_w8(p, w);
+  return fr_from_words(w);
+}
+BJJ_HD Niels niels_from_affine(const Fr& x, const Fr& y, const Consts& K) {
+  Niels n;
+  n.ymx = fr_canon(fr_sub(y, x)); n.ypx = fr_canon(fr_add(y, x)); n.t2d = fr_canon(fr_mul(fr_mul(x, y), K.D2P));
+  return n;
+}
+BJJ_HD void fixed_table_chain(u32* table, const Niels& base, size_t slot0, u32 k0, u32 cnt, int W, const Consts& K) {
+  // k0 * P_j, MSB first; the addition is computed unconditionally and selected (uniform control flow)
+  Ext acc = ext_identity();
+#pragma unroll 1
+  for (int b = W - 1; b >= 0; b--) {
+    acc = ext_dbl<true>(acc);
+    Ext sum = ext_madd(acc, base);
+    const bool bit = (k0 >> b) & 1;
+    acc.X = fr_select(bit, sum.X, acc.X); acc.Y = fr_select(bit, sum.Y, acc.Y);
+    acc.Z = fr_select(bit, sum.Z, acc.Z); acc.T = fr_select(bit, sum.T, acc.T);
+  }
+  Fr pre = fr_one();
+#pragma unroll 1
+  for (u32 i = 0; i < cnt; i++) {
+    pre = fr_mul(pre, acc.Z);
+    store_chain_slot(table + (slot0 + i) * NIELS_WORDS, acc.X, acc.Y, acc.Z, pre);
+    acc = ext_madd(acc, base);
+  }
+  Fr inv = fr_inv(pre);
+#pragma unroll 1
+  for (u32 i = cnt; i-- > 0;) {
+    u32* slot = table + (slot0 + i) * NIELS_WORDS;
+    Fr X = load_chain_word(slot), Y = load_chain_word(slot + 8), Z = load_chain_word(slot + 16);
+    Fr prev = i > 0 ? load_chain_word(slot - NIELS_WORDS + 24) : fr_one();
+    Fr zi = fr_mul(inv, prev);
+    inv = fr_mul(inv, Z);
+    store_niels(slot, niels_from_affine(fr_mul(X, zi), fr_mul(Y, zi), K));
+  }
+}
+// Link check of the finished table (proof by induction that every entry is k * 2^(W j) * B8):
+//   T[j][0] = identity, T[j][1] = P_j, T[j][k] + P_j = T[j][k+1], P_{j+1} = 2 * T[j][2^(W-1)], P_0 = B8,
+//   every entry canonical with 2D'x'y consistent.  Returns the number of violated conditions for slot (j, k).
+BJJ_HD Ext niels_lift(const Niels& n, const Consts& K) {  // (2x' : 2y : 2 : 2x'y)
+  Ext e;
+  e.X = fr_reduce_weak(fr_sub(n.ypx, n.ymx)); e.Y = fr_add(n.ypx, n.ymx);
+  e.Z = fr_add(fr_one(), fr_one()); e.T = fr_mul(n.t2d, K.DPINV);
+  return e;
+}
+BJJ_HD bool ext_equals_niels(const Ext& p, const Niels& n) {  // p == (x', y) of n, projectively
+  Fr two_x = fr_sub(n.ypx, n.ymx), two_y = fr_add(n.ypx, n.ymx);
+  return fr_eq(fr_mul(two_x, p.Z), fr_dbl(p.X)) && fr_eq(fr_mul(two_y, p.Z), fr_dbl(p.Y));
+}
+BJJ_HD bool niels_limbs_equal(const Niels& a, const Niels& b) {
+  bool eq = true;
+  for (int i = 0; i < NL; i++) eq = eq && a.ymx.v[i] == b.ymx.v[i] && a.ypx.v[i] == b.ypx.v[i] && a.t2d.v[i] == b.t2d.v[i];
+  return eq;
+}
+BJJ_HD int fixed_table_check_slot(const u32* table, const u32* bases, int j, u32 k, int W, int nwin, const Consts& K) {
+  const size_t stride = fixed_stride(W);
+  const Niels e = load_niels(table + ((size_t)j * stride + k) * NIELS_WORDS);
+  const Niels base = load_niels(bases + (size_t)j * NIELS_WORDS);
+  int bad = 0;
+  // canonical limbs and values
+  for (int i = 0; i < NL; i++) bad += (e.ymx.v[i] >> 29) != 0 || (e.ypx.v[i] >> 29) != 0 || (e.t2d.v[i] >> 29) != 0;
+  bad += !niels_limbs_equal(e, Niels{fr_canon(e.ymx), fr_canon(e.ypx), fr_canon(e.t2d)});
+  // 2 * t2d == D' * (ypx^2 - ymx^2)      (4x'y = (y+x')^2 - (y-x')^2)
+  bad += !fr_eq(fr_mul(fr_sub(fr_sqr(e.ypx), fr_sqr(e.ymx)), K.DP), fr_dbl(e.t2d));
+  if (k == 0) bad += !niels_limbs_equal(e, Niels{fr_one(), fr_one(), fr_zero()});
+  if (k == 1) bad += !niels_limbs_equal(e, base);
+  if (k + 1 < stride) {
+    const Niels nx = load_niels(table + ((size_t)j * stride + k + 1) * NIELS_WORDS);
+    bad += !ext_equals_niels(ext_madd(niels_lift(e, K), base), nx);
+  } else if (j + 1 < nwin) {
+    const Niels nb = load_niels(bases + (size_t)(j + 1) * NIELS_WORDS);
+    bad += !ext_equals_niels(ext_dbl<false>(niels_lift(e, K)), nb);
+  }
+  if (j == 0 && k == 1) {
+    Ext g = ext_from_ref_affine(K.B8X, K.B8Y, K);
+    bad += !ext_equals_niels(g, e);
+  }
+  return bad;
 }
 
 // one variable-base item: (x, y) Montgomery on the reference curve, raw 256-bit scalar.
@@ -556,7 +688,9 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const u32* fb_table, int W, int nwi
     Ext negA = ext_from_ref_affine(fr_neg(ax), ay, K);
     vb_build_table(negA, vb_tbl, K);
     Ext q = vb_mul_windowed(vb_tbl, kw, 64);                    // scalar < 2^254
-    q = fixed_base_accumulate(q, fb_table, W, nwin, sw);        // + s*B8   (:377)
+    u32 sl[8];
+    scalar_mod_l(sw, sl, K);                                    // B8 has order l
+    q = fixed_base_accumulate(q, fb_table, W, nwin, sl);        // + s*B8   (:377)
     Fr fx = fr_mul(rx, K.F);                                    // compare with R on the a'=-1 curve
     return (fr_eq(q.X, fr_mul(fx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z))) ? 1 : 0;
   }

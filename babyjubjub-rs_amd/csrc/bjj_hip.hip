@@ -32,6 +32,10 @@ using namespace bjj;
 
 #define BJJ_VERSION_STRING "bjj-hip 0.1.0 gfx950"
 #define BJJ_BLOCK 256
+// Fixed-base window width when bjj_init is given 0: 11 signed 23-bit digits, 11 x (2^22 + 1) entries = 5.9 GB
+// of the 288 GB of HBM.  Measured on MI355X (profiles/r01_ablation_signed_windows.txt): 16 bits (67 MB) 1.12 ms,
+// 18 (235 MB) 1.03, 21 (1.6 GB) 0.96, 23 (5.9 GB) 0.91, 26 (43 GB, 10 digits) 1.00 ms per 2^20 multiplications.
+#define BJJ_DEFAULT_WINDOW_BITS 23
 // Workgroup size of the kernels that end in the shared-inversion epilogue: one binary-GCD
 // inversion (executed by one wave) is amortised over the whole workgroup.
 #define BJJ_EPI_BLOCK 512
@@ -137,16 +141,36 @@ __device__ __forceinline__ void epilogue_run(Fr run, size_t n, size_t tid, size_
 }
 
 // ---------------------------------------------------------------------------
-// init: fixed-base table.  One thread per entry (j, k): k * 2^(W j) * B8.
+// init: fixed-base table (layout and recoding: bjj_device.hpp "fixed base").
+//   bases:  one thread per window j -> P_j = 2^(W j) * B8 (ladder + inversion; nwin threads)
+//   build:  one thread per chain of `chain` consecutive digits of one window (fixed_table_chain)
+//   check:  one thread per entry, link conditions of fixed_table_check_slot (bjj_check_table)
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_build_fixed_table(u32* table, int W, int nwin) {
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)nwin << W;
-  if (e >= total) return;
-  const u32 k = (u32)(e & (((size_t)1 << W) - 1));
-  const int j = (int)(e >> W);
-  Niels n = fixed_table_entry(k, j, W, c_K);
-  store_niels(table + e * NIELS_WORDS, n);
+__global__ void __launch_bounds__(64) bjj_k_fixed_window_bases(u32* bases, int W, int nwin) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nwin) return;
+  store_niels(bases + (size_t)j * NIELS_WORDS, fixed_table_entry(1u, j, W, c_K));
+}
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_build_fixed_table(u32* table, const u32* __restrict__ bases, int W, int nwin,
+                                                                 u32 chain) {
+  const size_t stride = fixed_stride(W);
+  const size_t cpw = (stride + chain - 1) / chain;  // chains per window
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cpw * (size_t)nwin) return;
+  const int j = (int)(t / cpw);
+  const size_t k0 = (t % cpw) * chain;
+  const u32 cnt = (u32)(stride - k0 < chain ? stride - k0 : chain);
+  fixed_table_chain(table, load_niels(bases + (size_t)j * NIELS_WORDS), (size_t)j * stride + k0, (u32)k0, cnt, W, c_K);
+}
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_check_fixed_table(const u32* __restrict__ table, const u32* __restrict__ bases,
+                                                                 int W, int nwin, unsigned long long* bad) {
+  const size_t stride = fixed_stride(W);
+  const size_t total = stride * (size_t)nwin, nthreads = (size_t)gridDim.x * blockDim.x;
+  unsigned long long mine = 0;
+#pragma unroll 1
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += nthreads)
+    mine += (unsigned long long)fixed_table_check_slot(table, bases, (int)(e / stride), (u32)(e % stride), W, nwin, c_K);
+  if (mine) atomicAdd(bad, mine);
 }
 
 // ---------------------------------------------------------------------------
@@ -427,7 +451,8 @@ struct bjj_ctx {
   // grids are sized to exactly one resident wave of workgroups, items are grid-strided
   int occ_fixed = 1, occ_var = 1, occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
   hipStream_t stream = nullptr;
-  u32* table = nullptr;
+  u32* table = nullptr;      // [window][digit 0 .. 2^(W-1)] x 128 B
+  u32* bases = nullptr;      // P_j = 2^(W j) * B8, one Niels entry per window
   size_t table_bytes = 0;
   u32* scratch = nullptr;      // n * 64 B (Z, prefix)
   size_t scratch_items = 0;
@@ -574,8 +599,8 @@ const char* bjj_last_error(void) { return g_err.c_str(); }
 int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   if (!out_ctx) return set_err(BJJ_E_INVALID, "bjj_init: out_ctx is NULL");
   *out_ctx = nullptr;
-  int W = window_bits == 0 ? 16 : window_bits;
-  if (W < 4 || W > 18) return set_err(BJJ_E_INVALID, "bjj_init: window_bits must be 0 or 4..18");
+  int W = window_bits == 0 ? BJJ_DEFAULT_WINDOW_BITS : window_bits;
+  if (W < 4 || W > 26) return set_err(BJJ_E_INVALID, "bjj_init: window_bits must be 0 or 4..26");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)
@@ -589,7 +614,7 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->device = device;
   c->cus = prop.multiProcessorCount;
   c->W = W;
-  c->nwin = (256 + W - 1) / W;
+  c->nwin = fixed_nwin(W);
   c->occ_fixed = occupancy_of(bjj_k_mul_fixed_base, BJJ_EPI_BLOCK);
   c->occ_var = occupancy_of(bjj_k_mul_var_base, BJJ_EPI_BLOCK);
   c->occ_poseidon = occupancy_of(bjj_k_poseidon5, BJJ_BLOCK);
@@ -600,16 +625,26 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->occ_sign = occupancy_of(bjj_k_sign, BJJ_BLOCK);
   hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (se != hipSuccess) { delete c; return set_err(BJJ_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
-  size_t entries = (size_t)c->nwin << W;
+  const size_t entries = fixed_stride(W) * (size_t)c->nwin;
   c->table_bytes = entries * NIELS_WORDS * sizeof(u32);
   se = hipMalloc((void**)&c->table, c->table_bytes);
-  if (se != hipSuccess) { hipStreamDestroy(c->stream); delete c; return set_err(BJJ_E_NOMEM, "bjj_init: cannot allocate the fixed-base table"); }
-  int blocks = (int)((entries + BJJ_BLOCK - 1) / BJJ_BLOCK);
-  hipLaunchKernelGGL(bjj_k_build_fixed_table, dim3(blocks), dim3(BJJ_BLOCK), 0, c->stream, c->table, c->W, c->nwin);
+  if (se == hipSuccess) se = hipMalloc((void**)&c->bases, (size_t)c->nwin * NIELS_WORDS * sizeof(u32));
+  if (se != hipSuccess) {
+    if (c->table) hipFree(c->table);
+    hipStreamDestroy(c->stream); delete c;
+    return set_err(BJJ_E_NOMEM, "bjj_init: cannot allocate the fixed-base table");
+  }
+  // chain length: long enough to amortise the start ladder and the inversion, short enough to fill the GPU
+  size_t chain = entries >> 18;
+  chain = chain < 4 ? 4 : (chain > 256 ? 256 : chain);
+  const size_t chains = ((fixed_stride(W) + chain - 1) / chain) * (size_t)c->nwin;
+  hipLaunchKernelGGL(bjj_k_fixed_window_bases, dim3((c->nwin + 63) / 64), dim3(64), 0, c->stream, c->bases, c->W, c->nwin);
+  hipLaunchKernelGGL(bjj_k_build_fixed_table, dim3((unsigned)((chains + BJJ_BLOCK - 1) / BJJ_BLOCK)), dim3(BJJ_BLOCK), 0, c->stream,
+                     c->table, c->bases, c->W, c->nwin, (u32)chain);
   se = hipGetLastError();
   if (se == hipSuccess) se = hipStreamSynchronize(c->stream);
   if (se != hipSuccess) {
-    hipFree(c->table); hipStreamDestroy(c->stream); delete c;
+    hipFree(c->table); hipFree(c->bases); hipStreamDestroy(c->stream); delete c;
     return set_err(BJJ_E_HIP, std::string("bjj_init: table build failed: ") + hipGetErrorString(se));
   }
   *out_ctx = c;
@@ -621,6 +656,7 @@ void bjj_free(bjj_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->table) hipFree(c->table);
+  if (c->bases) hipFree(c->bases);
   if (c->scratch) hipFree(c->scratch);
   if (c->vb_tables) hipFree(c->vb_tables);
   if (c->slow) hipFree(c->slow);
@@ -662,6 +698,26 @@ int bjj_get_info(bjj_ctx* c, bjj_info* info) {
   info->kernel_var_base = "bjj_k_mul_var_base";
   info->kernel_poseidon5 = "bjj_k_poseidon5";
   info->kernel_verify = "bjj_k_eddsa_verify";
+  return BJJ_OK;
+}
+
+int bjj_check_table(bjj_ctx* c, uint64_t* n_bad) {
+  if (!c || !n_bad) return set_err(BJJ_E_INVALID, "bjj_check_table: NULL argument");
+  HIPCK(hipSetDevice(c->device));
+  unsigned long long* d_bad = nullptr;
+  HIPCK(hipMalloc((void**)&d_bad, sizeof(unsigned long long)));
+  hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(bjj_k_check_fixed_table, dim3((unsigned)(c->cus * 8)), dim3(BJJ_BLOCK), 0, c->stream, c->table, c->bases, c->W,
+                       c->nwin, d_bad);
+    e = hipGetLastError();
+  }
+  unsigned long long h = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d_bad, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_bad);
+  if (e != hipSuccess) return set_err(BJJ_E_HIP, std::string("bjj_check_table: ") + hipGetErrorString(e));
+  *n_bad = (uint64_t)h;
   return BJJ_OK;
 }
 

@@ -78,8 +78,10 @@ const char* bjj_last_error(void);
 
 /* Creates a context on HIP device `device`: stream, scratch, and the fixed-base
  * window table of B8 multiples (built on the GPU).  `window_bits` selects the
- * fixed-base window width W (table = ceil(256/W) * 2^W entries of 128 bytes, kept
- * in HBM); 0 picks the default (16). Valid: 4..18. */
+ * fixed-base window width W: scalars are reduced mod l and recoded into
+ * ceil(252/W) signed digits, the table holds (2^(W-1) + 1) entries of 128 bytes per
+ * window, resident in HBM (W = 16: 67 MB, 21: 1.6 GB, 23: 5.9 GB, 26: 43 GB).
+ * 0 picks the default. Valid: 4..26. */
 int bjj_init(int device, int window_bits, bjj_ctx** out_ctx);
 void bjj_free(bjj_ctx* ctx);
 /* Blocks until everything enqueued on the context's stream has finished. */
@@ -146,12 +148,17 @@ int bjj_eddsa_verify_compressed_dev(bjj_ctx* ctx, const void* d_pk, const void* 
  * later *_dev calls do not allocate (call once before timing). */
 int bjj_reserve(bjj_ctx* ctx, size_t n);
 
+/* Verifies the whole fixed-base table on the device by induction over its entries
+ * (T[j][0] = O, T[j][k] + P_j = T[j][k+1], P_j+1 = 2 T[j][2^(W-1)], P_0 = B8, canonical
+ * limbs): *n_bad = number of violated conditions (0 for a sound table). */
+int bjj_check_table(bjj_ctx* ctx, uint64_t* n_bad);
+
 /* Introspection for benchmarks / profiling reports. */
 typedef struct {
   int device;
   int compute_units;
   int window_bits;          /* fixed-base W */
-  int n_windows;            /* ceil(256 / W) */
+  int n_windows;            /* ceil(252 / W) */
   uint64_t table_bytes;     /* fixed-base table size in HBM */
   uint64_t scratch_bytes;   /* current scratch allocation */
   const char* kernel_fixed_base; /* kernel symbol names, for matching rocprofv3 rows */

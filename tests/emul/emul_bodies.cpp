@@ -14,16 +14,27 @@ static const Consts K = {
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
     BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M,
     BJJ_K_TS_NEG, BJJ_K_TS_HALF, BJJ_K_TS_HASH};
-static std::vector<u32> g_table; static int g_W = 0, g_nwin = 0;
+static std::vector<u32> g_table, g_bases; static int g_W = 0, g_nwin = 0;
+static u32* aligned16(std::vector<u32>& v) { return (u32*)(((uintptr_t)v.data() + 15) & ~(uintptr_t)15); }
+// the table is built by the product's chain builder (what bjj_k_build_fixed_table runs per thread)
+static void build_table(int W, u32 chain) {
+  g_W = W; g_nwin = fixed_nwin(W);
+  const size_t stride = fixed_stride(W), entries = stride * g_nwin;
+  g_table.assign(entries * NIELS_WORDS + 4, 0);
+  g_bases.assign((size_t)g_nwin * NIELS_WORDS + 4, 0);
+  u32* t = aligned16(g_table); u32* bs = aligned16(g_bases);
+  for (int j = 0; j < g_nwin; j++) store_niels(bs + (size_t)j * NIELS_WORDS, fixed_table_entry(1u, j, W, K));
+  for (int j = 0; j < g_nwin; j++)
+    for (size_t k0 = 0; k0 < stride; k0 += chain) {
+      u32 cnt = (u32)(stride - k0 < chain ? stride - k0 : chain);
+      fixed_table_chain(t, load_niels(bs + (size_t)j * NIELS_WORDS), (size_t)j * stride + k0, (u32)k0, cnt, W, K);
+    }
+}
 static void ensure_table(int W) {
   if (g_W == W) return;
-  g_W = W; g_nwin = (256 + W - 1) / W;
-  size_t entries = (size_t)g_nwin << W;
-  g_table.assign(entries * NIELS_WORDS + 4, 0);
-  u32* t = (u32*)(((uintptr_t)g_table.data() + 15) & ~(uintptr_t)15);
-  for (size_t e = 0; e < entries; e++) store_niels(t + e * NIELS_WORDS, fixed_table_entry((u32)(e & ((1u << W) - 1)), (int)(e >> W), W, K));
+  build_table(W, 8);
 }
-static const u32* table_ptr() { return (const u32*)(((uintptr_t)g_table.data() + 15) & ~(uintptr_t)15); }
+static const u32* table_ptr() { return aligned16(g_table); }
 static void ext_out(const Ext& p, uint8_t* out) {  // single-item affine epilogue
   alignas(16) u32 w[8];
   Fr zi = fr_inv(p.Z);
@@ -33,6 +44,24 @@ static void ext_out(const Ext& p, uint8_t* out) {  // single-item affine epilogu
   fr_to_words(fr_cond_sub_kr(fr_mul(p.Y, c1), R1), w); memcpy(out + 32, w, 32);
 }
 extern "C" {
+// builds the table with the chain builder, then (i) compares every entry with the independent per-entry ladder
+// (fixed_table_entry) and (ii) runs the induction check the GPU runs; `corrupt` >= 0 flips one bit of that
+// slot first so the test can see the check fire.  Returns mismatches in the high half, check failures in the low.
+unsigned long long emul_table_selfcheck(int W, unsigned chain, long long corrupt_slot) {
+  build_table(W, chain);
+  g_W = 0;  // force a rebuild for later callers
+  u32* t = aligned16(g_table); const u32* bs = aligned16(g_bases);
+  const int nwin = fixed_nwin(W);
+  const size_t stride = fixed_stride(W);
+  unsigned long long mism = 0, bad = 0;
+  for (int j = 0; j < nwin; j++)
+    for (size_t k = 0; k < stride; k++)
+      mism += !niels_limbs_equal(load_niels(t + ((size_t)j * stride + k) * NIELS_WORDS), fixed_table_entry((u32)k, j, W, K));
+  if (corrupt_slot >= 0) t[(size_t)corrupt_slot * NIELS_WORDS + 11] ^= 4u;
+  for (int j = 0; j < nwin; j++)
+    for (size_t k = 0; k < stride; k++) bad += fixed_table_check_slot(t, bs, j, (u32)k, W, nwin, K);
+  return (mism << 32) | bad;
+}
 void emul_fixed_base(const uint8_t* scalar, int W, uint8_t* out) {
   ensure_table(W);
   alignas(16) u32 sc[8]; memcpy(sc, scalar, 32);

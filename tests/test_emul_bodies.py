@@ -19,6 +19,35 @@ def test_emul_fixed_base_golden(emul, golden):
             assert unpack(out.raw, 2)[0] == tuple(hexint(v) for v in c["out"]), (W, c["n"])
 
 
+def test_emul_fixed_table_chain_builder(emul):
+    """The chain builder (what bjj_k_build_fixed_table runs per thread) reproduces the independent per-entry
+    ladder for every entry, for chain lengths that do and do not divide the window, and the induction check the
+    GPU runs (bjj_check_table) accepts the table and fires on a single flipped bit."""
+    emul.emul_table_selfcheck.restype = ctypes.c_ulonglong
+    emul.emul_table_selfcheck.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_longlong]
+    for W, chain in ((4, 4), (5, 7), (6, 64)):
+        r = emul.emul_table_selfcheck(W, chain, -1)
+        assert r == 0, (W, chain, r >> 32, r & 0xFFFFFFFF)
+    r = emul.emul_table_selfcheck(5, 7, 40)
+    assert (r >> 32) == 0 and (r & 0xFFFFFFFF) > 0
+
+
+def test_emul_fixed_base_signed_digit_edges(emul, pyoracle):
+    """Scalars that stress the signed recoding: digits exactly 2^(W-1), 2^(W-1)+1, all-ones runs (carry chains),
+    l-1, l, l+1, 2^256-1 (reduced mod l first)."""
+    o = pyoracle
+    out = ctypes.create_string_buffer(64)
+    l = o.SUBORDER
+    for W in (4, 7):
+        half = 1 << (W - 1)
+        cases = [0, 1, half, half + 1, (1 << W) - 1, 1 << W, l - 1, l, l + 1, (1 << 256) - 1, (1 << 251) - 1,
+                 sum(half << (W * j) for j in range(252 // W)) % l, sum((half + 1) << (W * j) for j in range(252 // W)),
+                 sum(((1 << W) - 1) << (W * j) for j in range(0, 252 // W, 2))]
+        for n in cases:
+            emul.emul_fixed_base(le32(n % (1 << 256)), W, out)
+            assert unpack(out.raw, 2)[0] == o.mul_scalar(o.B8, n % (1 << 256)), (W, hex(n))
+
+
 def test_emul_var_base_golden(emul, golden):
     out = ctypes.create_string_buffer(64)
     for c in golden["oracle_vectors"]["var_base"]:

@@ -155,7 +155,7 @@ def test_verify_msg_range_rule(gpu_ctx, oracle):
     assert list(oracle.verify(pack([A] * n), pack([R] * n), pack([S] * n), pack(msgs))) == [1, 1, 0, 0, 0]
 
 
-@pytest.mark.parametrize("window_bits", [4, 8, 13])
+@pytest.mark.parametrize("window_bits", [4, 8, 13, 19])
 def test_fixed_base_other_window_widths(oracle, window_bits):
     """the table geometry is a tuning knob; results must not depend on it (13 does not divide 256)."""
     import babyjubjub_rs_amd as bjj
@@ -163,7 +163,9 @@ def test_fixed_base_other_window_widths(oracle, window_bits):
     ctx = bjj.Context(0, window_bits)
     try:
         info = ctx.info()
-        assert info.window_bits == window_bits and info.n_windows == -(-256 // window_bits)
+        assert info.window_bits == window_bits and info.n_windows == -(-252 // window_bits)
+        assert info.table_bytes == info.n_windows * ((1 << (window_bits - 1)) + 1) * 128
+        assert ctx.check_table() == 0   # every entry, by induction from B8, on the device
         sc = workload.random_u256(workload.SEED_SCALARS, 777, offset=5)
         sc[0] = 255
         assert (ctx.mul_fixed_base(sc) == oracle.mul_fixed_base(sc)).all()
@@ -172,6 +174,22 @@ def test_fixed_base_other_window_widths(oracle, window_bits):
         assert (ctx.eddsa_verify(A, R, S, msg) == oracle.verify(A, R, S, msg)).all()
     finally:
         ctx.close()
+
+
+def test_fixed_base_table_is_sound_and_signed_digit_edges(gpu_ctx, oracle, pyoracle):
+    """default-width table verified entry by entry on the device; scalars that stress the signed recoding
+    (digits at +-2^(W-1), carry runs, values around l and 2^256) against the oracle."""
+    assert gpu_ctx.check_table() == 0
+    W = gpu_ctx.info().window_bits
+    l, half = pyoracle.SUBORDER, 1 << (W - 1)
+    nw = 252 // W
+    cases = [0, 1, half, half + 1, (1 << W) - 1, 1 << W, l - 1, l, l + 1, 2 * l - 1, 8 * l, (1 << 256) - 1, (1 << 251) - 1,
+             (1 << 251), sum(half << (W * j) for j in range(nw)) % l, sum((half + 1) << (W * j) for j in range(nw)),
+             sum(((1 << W) - 1) << (W * j) for j in range(0, nw, 2)), l - half, l + half]
+    sc = pack([c % (1 << 256) for c in cases])
+    got = gpu_ctx.mul_fixed_base(sc)
+    assert (got == oracle.mul_fixed_base(sc)).all()
+    assert unpack(got[0].tobytes(), 2)[0] == (0, 1) and unpack(got[7].tobytes(), 2)[0] == (0, 1)
 
 
 # ---------------------------------------------------------------- device-pointer API

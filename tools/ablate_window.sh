@@ -2,12 +2,12 @@
 # Developer tool: fixed-base throughput vs window width W (table size / gather traffic trade-off),
 # plus the PCIe-inclusive rate of the host-pointer API.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-for W in 8 10 12 14 15 16 17 18; do
+for W in ${WIDTHS:-12 14 16 17 18 20 21 23 26}; do
   python3 bench.py --workload fixed_base --window-bits $W --steps 10 --warmup 2 --no-cpu-baseline --no-also 2>/dev/null | python3 -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
-        d=json.loads(line); c=d['config']; print('W=%2d  windows=%2d  table %8.1f MB  %8.2f M/s  kernel %.3f ms  parity %s' % (c['window_bits'], -(-256//c['window_bits']), c['fixed_base_table_mb'], d['value']/1e6, d['roofline']['kernel_ms_avg'], d['parity_sample_ok']))
+        d=json.loads(line); c=d['config']; print('W=%2d  windows=%2d  table %8.1f MB  %8.2f M/s  kernel %.3f ms  parity %s' % (c['window_bits'], -(-252//c['window_bits']), c['fixed_base_table_mb'], d['value']/1e6, d['roofline']['kernel_ms_avg'], d['parity_sample_ok']))
 "
 done
 python3 - <<'PY'
