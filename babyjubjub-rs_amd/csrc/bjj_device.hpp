@@ -75,14 +75,18 @@ BJJ_HD void store_pniels(u32* p, const PNiels& n) {
 // =============================================================================
 BJJ_HD int fixed_nwin(int W) { return (252 + W - 1) / W; }            // l < 2^251: the top digit absorbs the last carry
 BJJ_HD size_t fixed_stride(int W) { return ((size_t)1 << (W - 1)) + 1; }  // entries per window
-// 256-bit integer mod l (8 words in, 8 words out, < l)
+// 256-bit integer mod l (8 words in, 8 words out, < l).  Quotient estimate from the top byte:
+// floor(2^264 / l) = 10834, so q = (top byte * 10834) >> 16 satisfies q*l <= s < (q + 1.17) l.
 BJJ_HD void scalar_mod_l(const u32 w[8], u32 out[8], const Consts& K) {
-  Fr s = fr_from_words(w);  // < 2^256 < 64 l
-  s = fr_cond_sub_kr(s, K.ORDER4.v);
-  s = fr_cond_sub_kr(s, K.ORDER2.v);
-  s = fr_cond_sub_kr(s, K.ORDER.v);
-  s = fr_cond_sub_kr(s, K.L4.v);
-  s = fr_cond_sub_kr(s, K.L2.v);
+  Fr s = fr_from_words(w);
+  const u32 q = ((w[7] >> 24) * 10834u) >> 16;  // <= 42
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    c += (int64_t)s.v[i] - (int64_t)((u64)q * K.L.v[i]);
+    s.v[i] = (i < NL - 1) ? ((u32)c & MASK29) : (u32)c;
+    c >>= 29;
+  }
   s = fr_cond_sub_kr(s, K.L.v);
   fr_to_words(s, out);
 }
@@ -108,18 +112,17 @@ BJJ_HD Niels fixed_load_signed(const u32* table, const u32 sc[8], int j, int W, 
   const size_t slot = fixed_digit_slot(sc, j, W, carry, neg);
   return niels_cneg_lazy(load_niels(table + slot * NIELS_WORDS), neg);
 }
-// acc + sc * B8, sc < l
+// acc + sc * B8, sc < l.  The result's T is not computed (callers only compare or convert X, Y, Z).
 BJJ_HD Ext fixed_base_accumulate(Ext acc, const u32* table, int W, int nwin, const u32 sc[8]) {
   u32 carry = 0;
   Niels cur = fixed_load_signed(table, sc, 0, W, carry);
 #pragma unroll 1
-  for (int j = 0; j < nwin; j++) {
-    Niels nxt = cur;
-    if (j + 1 < nwin) nxt = fixed_load_signed(table, sc, j + 1, W, carry);  // next gather before this window's 7 multiplications
+  for (int j = 0; j + 1 < nwin; j++) {
+    Niels nxt = fixed_load_signed(table, sc, j + 1, W, carry);  // next gather before this window's 7 multiplications
     acc = ext_madd(acc, cur);
     cur = nxt;
   }
-  return acc;
+  return ext_madd<false>(acc, cur);
 }
 
 // n * B8 from scratch (n any 256-bit integer): window 0's entry is lifted directly to extended coordinates
@@ -130,20 +133,18 @@ BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 raw[8], c
   scalar_mod_l(raw, sc, K);
   u32 carry = 0;
   Niels n0 = fixed_load_signed(table, sc, 0, W, carry);
-  Niels cur = n0;
-  if (nwin > 1) cur = fixed_load_signed(table, sc, 1, W, carry);
+  Niels cur = fixed_load_signed(table, sc, 1, W, carry);
   Ext acc;
   acc.X = fr_reduce_weak(fr_sub(n0.ypx, n0.ymx));  // ext_madd wants coordinates < 2r
   acc.Y = fr_add(n0.ypx, n0.ymx);
   acc.Z = fr_add(fr_one(), fr_one()); acc.T = fr_mul(n0.t2d, K.DPINV);
 #pragma unroll 1
-  for (int j = 1; j < nwin; j++) {
-    Niels nxt = cur;
-    if (j + 1 < nwin) nxt = fixed_load_signed(table, sc, j + 1, W, carry);
+  for (int j = 1; j + 1 < nwin; j++) {
+    Niels nxt = fixed_load_signed(table, sc, j + 1, W, carry);
     acc = ext_madd(acc, cur);
     cur = nxt;
   }
-  return acc;
+  return ext_madd<false>(acc, cur);  // nwin >= 10: the last window's addition, T not needed by the epilogue
 }
 
 // =============================================================================

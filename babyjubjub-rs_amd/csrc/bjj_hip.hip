@@ -48,56 +48,57 @@ __constant__ Consts c_K = {
 
 // ---------------------------------------------------------------------------
 // workgroup-wide simultaneous inversion: every thread passes x (Montgomery, != 0,
-// < 2r) and receives 1/x.  Two LDS scans (prefix / suffix products) + one binary-GCD
-// inversion executed by wave 0.
+// < 2r) and receives 1/x.  The workgroup is cut into 64 groups of G = BJJ_EPI_BLOCK/64
+// consecutive lanes: prefix and suffix products inside a group by cross-lane shuffles
+// (log2 G steps each, no barrier), the 64 group products go through LDS to ONE wave
+// whose 64 lanes invert one group product each (binary GCD), and every thread
+// finishes with 1/x = (1/group product) * (product of the lanes before it) * (after it).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void lds_put(u32* lds, int t, const Fr& f) {
+#define BJJ_EPI_GROUP (BJJ_EPI_BLOCK / 64)
+__device__ __forceinline__ Fr fr_shfl_up(const Fr& f, int d) {
+  Fr r;
 #pragma unroll
-  for (int i = 0; i < NL; i++) lds[i * BJJ_EPI_BLOCK + t] = f.v[i];  // limb-major: conflict-free
+  for (int i = 0; i < NL; i++) r.v[i] = __shfl_up(f.v[i], d, BJJ_EPI_GROUP);
+  return r;
 }
-__device__ __forceinline__ Fr lds_get(const u32* lds, int t) {
-  Fr f;
+__device__ __forceinline__ Fr fr_shfl_down(const Fr& f, int d) {
+  Fr r;
 #pragma unroll
-  for (int i = 0; i < NL; i++) f.v[i] = lds[i * BJJ_EPI_BLOCK + t];
-  return f;
+  for (int i = 0; i < NL; i++) r.v[i] = __shfl_down(f.v[i], d, BJJ_EPI_GROUP);
+  return r;
 }
-__device__ Fr block_invert(const Fr& x, u32* lds /* NL * BJJ_EPI_BLOCK words */) {
-  const int t = threadIdx.x;
+__device__ Fr block_invert(const Fr& x, u32* lds /* NL * 64 words */) {
+  const int t = threadIdx.x, gl = t & (BJJ_EPI_GROUP - 1), grp = t / BJJ_EPI_GROUP;
   Fr pre = x, suf = x;
 #pragma unroll 1
-  for (int d = 1; d < BJJ_EPI_BLOCK; d <<= 1) {  // inclusive prefix products
-    lds_put(lds, t, pre);
-    __syncthreads();
-    Fr y = (t >= d) ? lds_get(lds, t - d) : fr_one();
-    __syncthreads();
-    pre = fr_mul(pre, y);
+  for (int d = 1; d < BJJ_EPI_GROUP; d <<= 1) {  // inclusive prefix / suffix products inside the group
+    Fr yp = fr_shfl_up(pre, d), ys = fr_shfl_down(suf, d);
+    pre = fr_mul(pre, fr_select(gl >= d, yp, fr_one()));
+    suf = fr_mul(suf, fr_select(gl + d < BJJ_EPI_GROUP, ys, fr_one()));
   }
-#pragma unroll 1
-  for (int d = 1; d < BJJ_EPI_BLOCK; d <<= 1) {  // inclusive suffix products
-    lds_put(lds, t, suf);
-    __syncthreads();
-    Fr y = (t + d < BJJ_EPI_BLOCK) ? lds_get(lds, t + d) : fr_one();
-    __syncthreads();
-    suf = fr_mul(suf, y);
-  }
-  // exclusive versions
-  lds_put(lds, t, pre);
-  __syncthreads();
-  Fr epre = (t > 0) ? lds_get(lds, t - 1) : fr_one();
-  Fr total = lds_get(lds, BJJ_EPI_BLOCK - 1);
-  __syncthreads();
-  lds_put(lds, t, suf);
-  __syncthreads();
-  Fr esuf = (t + 1 < BJJ_EPI_BLOCK) ? lds_get(lds, t + 1) : fr_one();
-  __syncthreads();
-  if (t < 64) {  // one wave inverts the workgroup product
-    Fr inv = fr_inv(total);
-    if (t == 0) lds_put(lds, 0, inv);
+  Fr epre = fr_select(gl > 0, fr_shfl_up(pre, 1), fr_one());                    // exclusive versions
+  Fr esuf = fr_select(gl + 1 < BJJ_EPI_GROUP, fr_shfl_down(suf, 1), fr_one());
+  if (gl == BJJ_EPI_GROUP - 1) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) lds[i * 64 + grp] = pre.v[i];  // limb-major: conflict-free
   }
   __syncthreads();
-  Fr inv = lds_get(lds, 0);
+  // the inverting wave rotates with the workgroup index so that co-resident workgroups do not queue on one SIMD
+  if ((t >> 6) == (int)((blockIdx.x + (blockIdx.x >> 8)) % (BJJ_EPI_BLOCK / 64))) {
+    const int l = t & 63;
+    Fr tot;
+#pragma unroll
+    for (int i = 0; i < NL; i++) tot.v[i] = lds[i * 64 + l];
+    Fr inv = fr_inv(tot);
+#pragma unroll
+    for (int i = 0; i < NL; i++) lds[i * 64 + l] = inv.v[i];
+  }
   __syncthreads();
-  return fr_mul(fr_mul(inv, epre), esuf);
+  Fr ginv;
+#pragma unroll
+  for (int i = 0; i < NL; i++) ginv.v[i] = lds[i * 64 + grp];
+  __syncthreads();
+  return fr_mul(fr_mul(ginv, epre), esuf);
 }
 
 // Phase-1 record for the affine epilogue: X, Y (as 2 x 32-byte integers) go to the
@@ -110,8 +111,9 @@ __device__ __forceinline__ void epilogue_stash(const Ext& p, Fr& run, uint8_t* o
   fr_to_words(run, w); store_w8(scr_item + 8, w);
   run = fr_mul(run, p.Z);
 }
-// Phase-2: given inv = 1 / (product of this lane's Z_0..Z_i), finish item i and
-// step inv down to 1 / (Z_0..Z_{i-1}).  Output: canonical reference-curve (x, y).
+// Phase-2: given inv = 1 / (product of this lane's Z_0..Z_i) as a PLAIN (non-Montgomery) integer, finish item i
+// and step inv down to 1 / (Z_0..Z_{i-1}).  A Montgomery product of a plain and a Montgomery operand is the plain
+// product, so Y * (1/Z) lands directly on the canonical output integer.  Output: reference-curve (x, y).
 __device__ __forceinline__ void epilogue_finish(Fr& inv, uint8_t* out_item, const u32* scr_item) {
   constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
   u32 w[8];
@@ -119,18 +121,17 @@ __device__ __forceinline__ void epilogue_finish(Fr& inv, uint8_t* out_item, cons
   load_w8(scr_item + 8, w); Fr P = fr_from_words(w);
   load_w8(out_item, w);     Fr X = fr_from_words(w);
   load_w8(out_item + 32, w); Fr Y = fr_from_words(w);
-  Fr zinv = fr_mul(inv, P);
+  Fr zinv = fr_mul(inv, P);               // plain 1/Z
   inv = fr_mul(inv, Z);
-  Fr c1 = fr_mul(zinv, fr_one_plain());   // plain 1/Z
-  Fr c2 = fr_mul(zinv, c_K.FINV_PLAIN);   // plain 1/(Z F): maps x' back to the reference curve
+  Fr c2 = fr_mul(zinv, c_K.FINV);         // plain 1/(Z F): maps x' back to the reference curve
   Fr x = fr_cond_sub_kr(fr_mul(X, c2), R1);
-  Fr y = fr_cond_sub_kr(fr_mul(Y, c1), R1);
+  Fr y = fr_cond_sub_kr(fr_mul(Y, zinv), R1);
   fr_to_words(x, w); store_w8(out_item, w);
   fr_to_words(y, w); store_w8(out_item + 32, w);
 }
 __device__ __forceinline__ void epilogue_run(Fr run, size_t n, size_t tid, size_t nthreads, uint8_t* out, u32* scratch,
                                              u32* lds) {
-  Fr inv = block_invert(run, lds);
+  Fr inv = fr_mul(block_invert(run, lds), fr_one_plain());  // out of Montgomery form once per lane
   if (tid >= n) return;
   size_t cnt = (n - tid + nthreads - 1) / nthreads;
 #pragma unroll 1
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_check_fixed_table(const u32* 
 __global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
                                                                   const uint8_t* __restrict__ scalars, size_t n,
                                                                   uint8_t* __restrict__ out, u32* __restrict__ scratch) {
-  __shared__ u32 lds[NL * BJJ_EPI_BLOCK];
+  __shared__ u32 lds[NL * 64];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   Fr run = fr_one();
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_var_base(const uint8_
                                                                 const uint8_t* __restrict__ scalars, size_t n,
                                                                 uint8_t* __restrict__ out, u32* __restrict__ scratch,
                                                                 u32* __restrict__ vb_tables, u32* __restrict__ slow) {
-  __shared__ u32 lds[NL * BJJ_EPI_BLOCK];
+  __shared__ u32 lds[NL * 64];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   u32* tbl = vb_tables + tid * VB_TABLE_WORDS;

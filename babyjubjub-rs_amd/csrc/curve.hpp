@@ -59,7 +59,9 @@ BJJ_HD Ext ext_identity() {
 // ("lazy", limbs < 2^30 for a sum, < 1.5*2^30 for a difference) and only the one operand per
 // formula that would break the 64-bit column bound is carried.  Value bounds in comments.
 
-// P + Q, Q affine-precomputed (entries N-form, < 2r).  P coords N-form < 2r.  7M.
+// P + Q, Q affine-precomputed (entries N-form, < 2r).  P coords N-form < 2r.  7M (6M when the caller
+// does not need T: the last addition of a chain).
+template <bool NEED_T = true>
 BJJ_HD Ext ext_madd(const Ext& p, const Niels& q) {
   Fr a = fr_mul(fr_sub_lazy(p.Y, p.X), q.ymx);   // (Y-X) < 6r
   Fr b = fr_mul(fr_add_lazy(p.Y, p.X), q.ypx);   // (Y+X) < 4r
@@ -70,7 +72,8 @@ BJJ_HD Ext ext_madd(const Ext& p, const Niels& q) {
   Fr g = fr_add_lazy(d, c);                      // < 6r,  limbs < 1.5*2^30
   Fr h = fr_add_lazy(b, a);                      // < 4r,  limbs < 2^30
   Ext r;
-  r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.T = fr_mul(e, h); r.Z = fr_mul(f, g);
+  r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.Z = fr_mul(f, g);
+  if (NEED_T) r.T = fr_mul(e, h); else r.T = fr_zero();
   return r;
 }
 // P + Q, Q projective-precomputed (entries carried).  8M.
