@@ -723,12 +723,15 @@ int bjj_check_table(bjj_ctx* c, uint64_t* n_bad) {
 }
 
 // ---- device-pointer API ------------------------------------------------------
+// item indices travel as 32-bit words in the work lists and cursors
+#define CHECK_N(n) if ((n) >> 32) return set_err(BJJ_E_INVALID, "batches are limited to 2^32 - 1 items per call")
 #define CHECK_CTX(c, name) if (!(c)) return set_err(BJJ_E_INVALID, name ": ctx is NULL")
 #define CHECK_PTR(p, name) if (!(p) || !aligned16(p)) return set_err(BJJ_E_INVALID, name ": NULL or not 16-byte aligned device pointer")
 
 int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_out, void* stream) {
   CHECK_CTX(c, "bjj_mul_fixed_base_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_scalars, "bjj_mul_fixed_base_dev"); CHECK_PTR(d_out, "bjj_mul_fixed_base_dev");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
@@ -740,6 +743,7 @@ int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_
 int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* stream) {
   CHECK_CTX(c, "bjj_mul_var_base_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_pts, "bjj_mul_var_base_dev"); CHECK_PTR(d_scalars, "bjj_mul_var_base_dev"); CHECK_PTR(d_out, "bjj_mul_var_base_dev");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
@@ -755,6 +759,7 @@ int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, s
 int bjj_poseidon5_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out, void* stream) {
   CHECK_CTX(c, "bjj_poseidon5_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_in, "bjj_poseidon5_dev"); CHECK_PTR(d_out, "bjj_poseidon5_dev");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   hipLaunchKernelGGL(bjj_k_poseidon5, dim3(grid_for(c, n, c->occ_poseidon)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_in, n,
@@ -766,12 +771,12 @@ static int verify_launch(bjj_ctx* c, bool schnorr, const void* d_pk, const void*
                          size_t n, void* d_ok, void* stream, const char* who) {
   if (!c) return set_err(BJJ_E_INVALID, std::string(who) + ": ctx is NULL");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   if (!d_pk || !d_r || !d_s || !d_msg || !aligned16(d_pk) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_msg))
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   if (!d_ok) return set_err(BJJ_E_INVALID, std::string(who) + ": d_ok is NULL");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  if (n >> 32) return set_err(BJJ_E_INVALID, std::string(who) + ": batches are limited to 2^32 - 1 items");
   HIPCK(hipMemsetAsync(c->slow, 0, WL_HDR * sizeof(u32), st));
   hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_for(c, n, c->occ_scan)), dim3(BJJ_BLOCK), 0, st,
                      (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_msg, n, c->slow);
@@ -798,6 +803,7 @@ int bjj_schnorr_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const 
 int bjj_point_add_dev(bjj_ctx* c, const void* d_p, const void* d_q, size_t n, void* d_out, void* stream) {
   CHECK_CTX(c, "bjj_point_add_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_p, "bjj_point_add_dev"); CHECK_PTR(d_q, "bjj_point_add_dev"); CHECK_PTR(d_out, "bjj_point_add_dev");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   hipLaunchKernelGGL(bjj_k_point_add, dim3(grid_for(c, n, c->occ_add)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_p,
@@ -809,6 +815,7 @@ int bjj_point_add_dev(bjj_ctx* c, const void* d_p, const void* d_q, size_t n, vo
 int bjj_compress_points_dev(bjj_ctx* c, const void* d_pts, size_t n, void* d_out, void* stream) {
   CHECK_CTX(c, "bjj_compress_points_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_pts, "bjj_compress_points_dev"); CHECK_PTR(d_out, "bjj_compress_points_dev");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   hipLaunchKernelGGL(bjj_k_compress_points, dim3(grid_for(c, n, 8)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_pts, n,
@@ -819,6 +826,7 @@ int bjj_compress_points_dev(bjj_ctx* c, const void* d_pts, size_t n, void* d_out
 int bjj_decompress_points_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out_xy, void* d_ok, void* stream) {
   CHECK_CTX(c, "bjj_decompress_points_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_in, "bjj_decompress_points_dev"); CHECK_PTR(d_out_xy, "bjj_decompress_points_dev");
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_decompress_points_dev: d_ok is NULL");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
@@ -831,6 +839,7 @@ int bjj_eddsa_verify_compressed_dev(bjj_ctx* c, const void* d_pk32, const void* 
                                     void* d_ok, void* stream) {
   CHECK_CTX(c, "bjj_eddsa_verify_compressed_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_pk32, "bjj_eddsa_verify_compressed_dev"); CHECK_PTR(d_sig64, "bjj_eddsa_verify_compressed_dev");
   CHECK_PTR(d_msg, "bjj_eddsa_verify_compressed_dev");
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_compressed_dev: d_ok is NULL");
@@ -857,6 +866,7 @@ int bjj_eddsa_verify_compressed_dev(bjj_ctx* c, const void* d_pk32, const void* 
 int bjj_scalar_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out, void* stream) {
   CHECK_CTX(c, "bjj_scalar_keys_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_keys, "bjj_scalar_keys_dev"); CHECK_PTR(d_out, "bjj_scalar_keys_dev");
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   hipLaunchKernelGGL(bjj_k_scalar_keys, dim3(grid_for(c, n, 4)), dim3(BJJ_BLOCK), 0, st, (const uint8_t*)d_keys, n,
@@ -867,6 +877,7 @@ int bjj_scalar_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out, v
 int bjj_public_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy, void* stream) {
   CHECK_CTX(c, "bjj_public_keys_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_keys, "bjj_public_keys_dev"); CHECK_PTR(d_out_xy, "bjj_public_keys_dev");
   int rc = ensure_codec(c, n); if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
@@ -877,6 +888,7 @@ int bjj_sign_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, v
                  void* stream) {
   CHECK_CTX(c, "bjj_sign_dev");
   if (n == 0) return BJJ_OK;
+  CHECK_N(n);
   CHECK_PTR(d_keys, "bjj_sign_dev"); CHECK_PTR(d_msgs, "bjj_sign_dev"); CHECK_PTR(d_out_r, "bjj_sign_dev");
   CHECK_PTR(d_out_s, "bjj_sign_dev");
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_sign_dev: d_ok is NULL");

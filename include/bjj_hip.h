@@ -42,6 +42,8 @@
  * API misuse / HIP runtime errors.  0 = success; negative = BJJ_E_*; see
  * bjj_last_error().
  *
+ * Batch size: any n < 2^32 per call (byte offsets are 64-bit; item indices travel as 32-bit words).
+ *
  * Threading: a context is bound to one device and one internal stream; calls on
  * the same context are serialised by the caller; different contexts are
  * independent.  The library keeps no pointer past return.
