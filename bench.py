@@ -240,15 +240,21 @@ def cpu_baseline(kind, wl, budget_cpu_s=25.0):
             "single_thread_value": rate1}, orc
 
 
-def load_traffic(kind):
-    """per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json), or None"""
+def load_traffic(kind, field="bytes_per_launch"):
+    """per-launch HBM bytes (or VALU wave-instructions) from the committed rocprofv3 PMC passes
+    (profiles/hbm_traffic.json, written by tools/summarize_profile.py), or None"""
     p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get(kind, {}).get("bytes_per_launch")
+            return json.load(open(p)).get(kind, {}).get(field)
         except Exception:
             return None
     return None
+
+
+# the unit that actually bounds this path: VALU issue.  Peak = 1024 SIMDs x 2.4 GHz / 4.54 cycles per
+# v_mad_u64_u32 wave-instruction (tools/ubench, profiles/r01_ubench_valu_rates.txt).
+VALU_PEAK_GINST = 1024 * 2.4 / 4.54
 
 
 def main():
@@ -357,13 +363,20 @@ def main():
             algo = ALGO_BYTES[kind] * n
             ach = algo / (kernel_ms * 1e-3) / 1e9
             result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": ach / HBM_PEAK_GBPS, "traffic": load_traffic(kind),
+                                  "frac": ach / HBM_PEAK_GBPS,
+                                  "traffic": load_traffic(kind) if (n == (1 << 20) and not args.window_bits) else None,
                                   "kernel": {"fixed_base": info.kernel_fixed_base, "var_base": info.kernel_var_base,
                                              "verify": info.kernel_verify, "poseidon5": info.kernel_poseidon5,
                                              "verify_compressed": info.kernel_verify,
                                              "decompress": b"bjj_k_decompress_points", "sign": b"bjj_k_sign"}[kind].decode(),
                                   "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": algo,
                                   "note": "integer-ALU bound path (see DESIGN.md): HBM fraction is reported as measured"}
+            vi = load_traffic(kind, "valu_insts_per_launch")
+            if vi and n == (1 << 20) and not args.window_bits:
+                va = vi / (kernel_ms * 1e-3) / 1e9
+                result["valu"] = {"insts_per_launch": vi, "achieved": va, "peak": VALU_PEAK_GINST, "frac": va / VALU_PEAK_GINST,
+                                  "unit": "G wave-instructions/s",
+                                  "note": "SQ_INSTS_VALU of the rocprofv3 PMC pass / live kernel time; peak = measured v_mad_u64_u32 issue rate"}
         orc = None
         if not args.no_cpu_baseline and world == 1:
             cb, orc = cpu_baseline(kind, wl)

@@ -61,6 +61,8 @@ tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 d = json.load(open(tj)) if os.path.exists(tj) else {}
 if traffic:
     d[wl] = {"bytes_per_launch": traffic, "source": "profiles/%s_%s_summary.md" % (tag, wl), "batch": int(meta.get("Grid_Size", 0)) and 1 << 20}
+    if "SQ_INSTS_VALU" in counters:
+        d[wl]["valu_insts_per_launch"] = counters["SQ_INSTS_VALU"][0]
     json.dump(d, open(tj, "w"), indent=1)
 bj = os.path.join(src, "bench_%s.json" % wl)
 if os.path.exists(bj) and os.path.getsize(bj):
