@@ -9,6 +9,6 @@ product is csrc/libbjj_hip.so.
 from .api import (  # noqa: F401
     Q, B8, SUBORDER, BjjError, Context, Point, PointProjective, Signature, default_context,
     mul_scalar_batch, mul_fixed_base_batch, poseidon5_batch, verify_batch, verify, point_add_batch,
-    decompress_point, decompress_signature, PrivateKey, verify_schnorr,
+    decompress_point, decompress_signature, PrivateKey, verify_schnorr, new_key,
 )
 from ._lib import LIB_PATH, EXPORTED_SYMBOLS  # noqa: F401

@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = (
     "bjj_compress_points", "bjj_decompress_points", "bjj_eddsa_verify_compressed",
     "bjj_schnorr_verify", "bjj_schnorr_verify_dev",
     "bjj_scalar_keys", "bjj_public_keys", "bjj_sign", "bjj_scalar_keys_dev", "bjj_public_keys_dev", "bjj_sign_dev",
+    "bjj_sign_schnorr", "bjj_sign_schnorr_dev",
     "bjj_compress_points_dev", "bjj_decompress_points_dev", "bjj_eddsa_verify_compressed_dev",
 )
 
@@ -89,6 +90,8 @@ def load():
     lib.bjj_scalar_keys_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.bjj_public_keys_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.bjj_sign_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
+    lib.bjj_sign_schnorr.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
+    lib.bjj_sign_schnorr_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp]
     lib.bjj_decompress_points.argtypes = [vp, vp, sz, vp, vp]
     lib.bjj_eddsa_verify_compressed.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.bjj_compress_points_dev.argtypes = [vp, vp, sz, vp, vp]

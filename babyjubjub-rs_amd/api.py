@@ -195,6 +195,26 @@ class Context:
                                    ok.ctypes.data), "bjj_sign")
         return r.reshape(n, 64), s.reshape(n, 32), ok
 
+    def sign_schnorr(self, keys, msgs, nonces):
+        """PrivateKey::sign_schnorr in bulk with caller-supplied 1024-bit nonces (n x 128 bytes, little-endian).
+        -> (r (n, 64), s (n, 160): the reference's unreduced k + scalar_key*h, ok (n,): 0 = Err (msg > Q))"""
+        a = _as_u8(keys, 32, "keys")
+        m = _as_u8(msgs, 32, "msgs")
+        k = np.ascontiguousarray(np.asarray(nonces, dtype=np.uint8)).reshape(-1)
+        n = a.size // 32
+        if m.size != a.size or k.size != n * 128:
+            raise BjjError("sign_schnorr: array lengths disagree (nonces are 128 bytes each)")
+        r = np.empty(n * 64, dtype=np.uint8)
+        s = np.empty(n * 160, dtype=np.uint8)
+        ok = np.empty(n, dtype=np.uint8)
+        self._ck(self.lib.bjj_sign_schnorr(self.handle, a.ctypes.data, m.ctypes.data, k.ctypes.data, n, r.ctypes.data,
+                                           s.ctypes.data, ok.ctypes.data), "bjj_sign_schnorr")
+        return r.reshape(n, 64), s.reshape(n, 160), ok
+
+    def sign_schnorr_dev(self, d_keys, d_msgs, d_nonces, n, d_r, d_s, d_ok, stream=0):
+        self._ck(self.lib.bjj_sign_schnorr_dev(self.handle, d_keys, d_msgs, d_nonces, n, d_r, d_s, d_ok, stream),
+                 "bjj_sign_schnorr_dev")
+
     def sign_dev(self, d_keys, d_msgs, n, d_r, d_s, d_ok, stream=0):
         self._ck(self.lib.bjj_sign_dev(self.handle, d_keys, d_msgs, n, d_r, d_s, d_ok, stream), "bjj_sign_dev")
 
@@ -374,6 +394,27 @@ class PrivateKey:
         x, y = _ints(r, 2)[0]
         return Signature(Point(x, y), _ints(s, 1)[0])
 
+    def sign_schnorr(self, m, k=None, ctx=None):  # lib.rs:344-361 -> (Point, BigInt); ValueError for Err
+        """k: the 1024-bit nonce; None draws it from the OS generator as the reference does from
+        rand::thread_rng (lib.rs:347-348).  s is the reference's unreduced integer k + scalar_key*h."""
+        m = int(m)
+        if m < 0:
+            raise BjjError("sign_schnorr: negative msg")
+        if m > Q:
+            raise ValueError("msg outside the Finite Field")
+        if k is None:
+            import secrets
+            k = secrets.randbits(1024)
+        k = int(k)
+        if k < 0 or k >> 1024:
+            raise BjjError("sign_schnorr: nonce outside the 1024-bit record of the C ABI")
+        r, s, ok = (ctx or default_context()).sign_schnorr(np.frombuffer(self.key, np.uint8), [m],
+                                                           np.frombuffer(k.to_bytes(128, "little"), np.uint8))
+        if not ok[0]:
+            raise ValueError("msg outside the Finite Field")
+        x, y = _ints(r, 2)[0]
+        return Point(x, y), int.from_bytes(s[0].tobytes(), "little")
+
 
 def decompress_point(bb, ctx=None):
     """decompress_point(bb: [u8; 32]) -> Result<Point, String>  (lib.rs:192-224); raises ValueError for Err"""
@@ -391,6 +432,15 @@ def decompress_signature(b, ctx=None):
     if len(b) != 64:
         raise BjjError("decompress_signature: need exactly 64 bytes")
     return Signature(decompress_point(bytes(b[:32]), ctx), int.from_bytes(bytes(b[32:]), "little"))
+
+
+def new_key():
+    """new_key() -> PrivateKey (lib.rs:387-393): 1024 random bits, the first 32 big-endian bytes kept."""
+    import secrets
+    raw = secrets.randbits(1024).to_bytes(128, "big").lstrip(b"\x00")
+    while len(raw) < 32:  # probability 2^-768; the reference would panic on the slice here
+        raw = secrets.randbits(1024).to_bytes(128, "big").lstrip(b"\x00")
+    return PrivateKey.import_(raw[:32])
 
 
 def verify(pk, sig, msg, ctx=None):

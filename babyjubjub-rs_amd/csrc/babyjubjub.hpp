@@ -23,6 +23,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/bjj_hip.h"
@@ -118,6 +119,10 @@ struct PrivateKey {  // lib.rs:270-342
   U256 scalar_key() const;               // lib.rs:284-302
   Point public_key() const;              // lib.rs:304-306 (`public` is a C++ keyword)
   Signature sign(const U256& msg) const; // lib.rs:308-342; throws std::invalid_argument where the crate returns Err
+  // lib.rs:344-361 with the 1024-bit nonce k (128 little-endian bytes) supplied by the caller -- the crate draws it from
+  // rand::thread_rng (:347-348).  Returns (r, s) with s the crate's UNREDUCED integer k + scalar_key*h, 160 bytes LE.
+  std::pair<Point, std::array<uint8_t, BJJ_SCHNORR_S_BYTES>> sign_schnorr(const U256& m,
+                                                                         const std::array<uint8_t, BJJ_SCHNORR_NONCE_BYTES>& k) const;
 };
 
 inline const Point& B8() {  // lib.rs:37-46
@@ -199,6 +204,18 @@ inline std::vector<Signature> sign_batch(const std::vector<PrivateKey>& k, const
   return out;
 }
 
+// Schnorr signer, batch (lib.rs:344-361): ok[i] == 0 where sign_schnorr returns Err (msg > Q)
+inline std::vector<Point> sign_schnorr_batch(const std::vector<PrivateKey>& k, const std::vector<U256>& msg,
+                                             const std::vector<std::array<uint8_t, BJJ_SCHNORR_NONCE_BYTES>>& nonces,
+                                             std::vector<std::array<uint8_t, BJJ_SCHNORR_S_BYTES>>& s, std::vector<uint8_t>& ok,
+                                             Context& c = Context::global()) {
+  if (k.size() != msg.size() || k.size() != nonces.size()) throw std::runtime_error("sign_schnorr_batch: length mismatch");
+  std::vector<Point> r(k.size()); s.resize(k.size()); ok.assign(k.size(), 0);
+  check(bjj_sign_schnorr(c.handle(), (const uint8_t*)k.data(), (const uint8_t*)msg.data(), (const uint8_t*)nonces.data(), k.size(),
+                         (uint8_t*)r.data(), (uint8_t*)s.data(), ok.data()), "bjj_sign_schnorr");
+  return r;
+}
+
 // ---- scalar (single-item) forms, same signatures as the crate ------------------------------
 inline U256 PrivateKey::scalar_key() const {
   U256 out; check(bjj_scalar_keys(Context::global().handle(), key.data(), 1, out.le.data()), "bjj_scalar_keys"); return out;
@@ -208,6 +225,13 @@ inline Signature PrivateKey::sign(const U256& msg) const {
   std::vector<uint8_t> ok; Signature s = sign_batch({*this}, {msg}, ok)[0];
   if (!ok[0]) throw std::invalid_argument("msg outside the Finite Field");
   return s;
+}
+inline std::pair<Point, std::array<uint8_t, BJJ_SCHNORR_S_BYTES>> PrivateKey::sign_schnorr(
+    const U256& m, const std::array<uint8_t, BJJ_SCHNORR_NONCE_BYTES>& k) const {
+  std::vector<std::array<uint8_t, BJJ_SCHNORR_S_BYTES>> s; std::vector<uint8_t> ok;
+  Point r = sign_schnorr_batch({*this}, {m}, {k}, s, ok)[0];
+  if (!ok[0]) throw std::invalid_argument("msg outside the Finite Field");
+  return {r, s[0]};
 }
 inline std::array<uint8_t, 32> Point::compress() const { return compress_batch({*this})[0]; }
 // decompress_point(bb) -> Result<Point, String>: throws std::invalid_argument for Err (lib.rs:192-224)
@@ -234,6 +258,30 @@ inline Point PointProjective::affine() const {
   if (z == Fr(0)) return Point{Fr(0), Fr(0)};  // lib.rs:71-76
   if (z != Fr(1)) throw std::runtime_error("PointProjective::affine: boundary holds z in {0, 1}");
   return Point{x, y};
+}
+// little-endian integer of any width mod ORDER = 8l (the group order): bit-serial shift-and-subtract on the host.
+// Exact for the scalar of B8.mul_scalar (lib.rs:377) because B8 lies on the curve.
+inline U256 reduce_mod_order(const uint8_t* le, size_t nbytes) {
+  static const U256 order = U256::from_str("21888242871839275222246405745257275088614511777268538073601725287587578984328");
+  uint8_t acc[33] = {0};  // < 2 * ORDER < 2^256, plus the shifted-in bit
+  for (size_t bit = nbytes * 8; bit-- > 0;) {
+    unsigned carry = (le[bit >> 3] >> (bit & 7)) & 1u;
+    for (int i = 0; i < 33; i++) { unsigned v = ((unsigned)acc[i] << 1) | carry; acc[i] = (uint8_t)v; carry = v >> 8; }
+    bool ge = acc[32] != 0;
+    if (!ge) { ge = true; for (int i = 31; i >= 0; i--) if (acc[i] != order.le[i]) { ge = acc[i] > order.le[i]; break; } }
+    if (ge) { int borrow = 0; for (int i = 0; i < 33; i++) { int v = (int)acc[i] - (i < 32 ? order.le[i] : 0) - borrow; borrow = v < 0; acc[i] = (uint8_t)(v + (borrow << 8)); } }
+  }
+  U256 r; std::memcpy(r.le.data(), acc, 32); return r;
+}
+// verify_schnorr(pk, m, r, s) -> Result<bool, String> (lib.rs:375-385); s: the signer's integer, any width (little-endian);
+// throws std::invalid_argument where the crate returns Err (msg > Q)
+inline bool verify_schnorr(const Point& pk, const U256& m, const Point& r, const uint8_t* s_le, size_t s_bytes) {
+  U256 s = reduce_mod_order(s_le, s_bytes);
+  uint8_t ok = 0;
+  check(bjj_schnorr_verify(Context::global().handle(), (const uint8_t*)&pk, (const uint8_t*)&r, s.le.data(), m.le.data(), 1, &ok),
+        "bjj_schnorr_verify");
+  if (ok == 2) throw std::invalid_argument("msg outside the Finite Field");
+  return ok == 1;
 }
 inline bool verify(const Point& pk, const Signature& sig, const U256& msg) {  // lib.rs:395-412
   return verify_batch({pk}, {sig}, {msg})[0] != 0;

@@ -13,7 +13,7 @@
 //   bjj_k_point_add               PointProjective::add + affine  src/lib.rs:88-131, 70-85
 //   bjj_k_compress_points / bjj_k_decompress_points / bjj_k_merge_codec_flags
 //                                 wire format                    src/lib.rs:166-224, 260-268
-//   bjj_k_scalar_keys / bjj_k_sign  signer side                  src/lib.rs:284-342
+//   bjj_k_scalar_keys / bjj_k_sign / bjj_k_sign_schnorr  signer side   src/lib.rs:284-361
 // K5 (batched affine conversion) is the epilogue of K1/K2: Montgomery's trick per lane over its
 // items, then across the 512-lane workgroup through two LDS product scans, so that ONE
 // (binary-GCD) inversion serves blockDim * items_per_lane points.
@@ -432,6 +432,33 @@ __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign(const u32* __restrict
   }
 }
 
+// PrivateKey::sign_schnorr (src/lib.rs:344-361) with caller-supplied 1024-bit nonces (128 B each); s is the
+// reference's unreduced integer k + scalar_key*h in a 160-byte little-endian record.
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign_schnorr(const u32* __restrict__ table, int W, int nwin,
+                                                                   const uint8_t* __restrict__ keys,
+                                                                   const uint8_t* __restrict__ msgs,
+                                                                   const uint8_t* __restrict__ nonces, size_t n,
+                                                                   uint8_t* __restrict__ out_r, uint8_t* __restrict__ out_s,
+                                                                   uint8_t* __restrict__ ok) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    u32 k[8], m[8], rx[8], ry[8], kn[SCHNORR_K_WORDS], s[SCHNORR_S_WORDS];
+    load_w8(keys + i * 32, k); load_w8(msgs + i * 32, m);
+#pragma unroll
+    for (int j = 0; j < SCHNORR_K_WORDS / 8; j++) load_w8(nonces + i * (SCHNORR_K_WORDS * 4) + j * 32, kn + 8 * j);
+    const bool good = sign_schnorr_item(k, m, kn, table, W, nwin, rx, ry, s, c_K);
+#pragma unroll
+    for (int j = 0; j < 8; j++) { rx[j] = good ? rx[j] : 0u; ry[j] = good ? ry[j] : 0u; }
+#pragma unroll
+    for (int j = 0; j < SCHNORR_S_WORDS; j++) s[j] = good ? s[j] : 0u;
+    store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry);
+#pragma unroll
+    for (int j = 0; j < SCHNORR_S_WORDS / 8; j++) store_w8(out_s + i * (SCHNORR_S_WORDS * 4) + j * 32, s + 8 * j);
+    ok[i] = good ? 1 : 0;
+  }
+}
+
 // ===========================================================================
 // host side: context + extern "C" boundary
 // ===========================================================================
@@ -463,7 +490,7 @@ struct bjj_ctx {
   size_t slow_items = 0;
   uint8_t* codec = nullptr;    // verify_compressed: n * (64 pk + 64 R + 32 s + 2 flags) bytes
   size_t codec_items = 0;
-  int occ_decomp = 1, occ_sign = 1;
+  int occ_decomp = 1, occ_sign = 1, occ_sign_schnorr = 1;
   // host-pointer API: chunked pipeline  user memory -> pinned[b] -H2D-> dstage[b] -kernel-> dstage[b] -D2H-> pinned[b] -> user
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
@@ -624,6 +651,7 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->occ_add = occupancy_of(bjj_k_point_add, BJJ_BLOCK);
   c->occ_decomp = occupancy_of(bjj_k_decompress_points, BJJ_BLOCK);
   c->occ_sign = occupancy_of(bjj_k_sign, BJJ_BLOCK);
+  c->occ_sign_schnorr = occupancy_of(bjj_k_sign_schnorr, BJJ_BLOCK);
   hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (se != hipSuccess) { delete c; return set_err(BJJ_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
   const size_t entries = fixed_stride(W) * (size_t)c->nwin;
@@ -899,6 +927,22 @@ int bjj_sign_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, v
   return BJJ_OK;
 }
 
+int bjj_sign_schnorr_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, const void* d_nonces, size_t n, void* d_out_r,
+                         void* d_out_s, void* d_ok, void* stream) {
+  CHECK_CTX(c, "bjj_sign_schnorr_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_N(n);
+  CHECK_PTR(d_keys, "bjj_sign_schnorr_dev"); CHECK_PTR(d_msgs, "bjj_sign_schnorr_dev"); CHECK_PTR(d_nonces, "bjj_sign_schnorr_dev");
+  CHECK_PTR(d_out_r, "bjj_sign_schnorr_dev"); CHECK_PTR(d_out_s, "bjj_sign_schnorr_dev");
+  if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_sign_schnorr_dev: d_ok is NULL");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipLaunchKernelGGL(bjj_k_sign_schnorr, dim3(grid_for(c, n, c->occ_sign_schnorr)), dim3(BJJ_BLOCK), 0, st, c->table, c->W, c->nwin,
+                     (const uint8_t*)d_keys, (const uint8_t*)d_msgs, (const uint8_t*)d_nonces, n, (uint8_t*)d_out_r,
+                     (uint8_t*)d_out_s, (uint8_t*)d_ok);
+  HIPCK(hipGetLastError());
+  return BJJ_OK;
+}
+
 // ---- host-pointer API: chunked pinned-staging pipeline around the *_dev entry points ----------
 #define HOST_PROLOGUE(name, cond)                                             \
   CHECK_CTX(c, name);                                                         \
@@ -967,6 +1011,12 @@ int bjj_sign(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uin
   HOST_PROLOGUE("bjj_sign", !keys || !msgs || !out_r || !out_s || !ok);
   PipeSpec sp = {2, 3, {keys, msgs}, {32, 32}, {out_r, out_s, ok}, {64, 32, 1}};
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_sign_dev(c, i[0], i[1], cnt, o[0], o[1], o[2], st); });
+}
+int bjj_sign_schnorr(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, const uint8_t* nonces, size_t n, uint8_t* out_r,
+                     uint8_t* out_s, uint8_t* ok) {
+  HOST_PROLOGUE("bjj_sign_schnorr", !keys || !msgs || !nonces || !out_r || !out_s || !ok);
+  PipeSpec sp = {3, 3, {keys, msgs, nonces}, {32, 32, BJJ_SCHNORR_NONCE_BYTES}, {out_r, out_s, ok}, {64, BJJ_SCHNORR_S_BYTES, 1}};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_sign_schnorr_dev(c, i[0], i[1], i[2], cnt, o[0], o[1], o[2], st); });
 }
 
 #pragma GCC visibility pop

@@ -134,4 +134,57 @@ BJJ_HD bool sign_item(const u32 key[8], const u32 msg[8], const u32* fb_table, i
   return true;
 }
 
+// PrivateKey::sign_schnorr (src/lib.rs:344-361) with the 1024-bit nonce k supplied by the caller (the
+// reference draws it from rand::thread_rng, :347-348; randomness stays on the host).  r = k*B8 (:351),
+// h = schnorr_hash(pk, m, r) (:355, hash input order (pk, r, m), :369), s = k + scalar_key*h as a PLAIN
+// integer -- the reference never reduces it (:359) -- written as 40 little-endian words (< 2^1025).
+// Returns false where the reference returns Err (msg > Q, :365-367).
+constexpr int SCHNORR_K_WORDS = 32;   // 1024-bit nonce
+constexpr int SCHNORR_S_WORDS = 40;   // 160-byte record of s
+BJJ_HD bool sign_schnorr_item(const u32 key[8], const u32 msg[8], const u32 k[SCHNORR_K_WORDS], const u32* fb_table, int W,
+                              int nwin, u32 out_rx[8], u32 out_ry[8], u32 out_s[SCHNORR_S_WORDS], const Consts& K) {
+  if (words_gt_modulus(msg)) return false;
+  u32 sk[8], pruned[8], hi[8];
+  scalar_key_words(key, sk, pruned, hi);                         // :358 (and :354 through public())
+  // k mod l for the fixed-base engine (B8 has order l):  k = X0 + 2^261 X1 + 2^522 X2 + 2^783 X3
+  Fr t1 = fl_mul(limbs_from_bits(k, SCHNORR_K_WORDS, 261), K.L_R2, K);
+  Fr t2 = fl_mul(fl_mul(limbs_from_bits(k, SCHNORR_K_WORDS, 522), K.L_R2, K), K.L_R2, K);
+  Fr t3 = fl_mul(fl_mul(fl_mul(limbs_from_bits(k, SCHNORR_K_WORDS, 783), K.L_R2, K), K.L_R2, K), K.L_R2, K);
+  Fr t0 = fl_mul(limbs_from_bits(k, SCHNORR_K_WORDS, 0), K.L_R1, K);
+  Fr kr = fl_canon4(fr_add(fl_canon4(fr_add(t0, t1), K), fl_canon4(fr_add(t2, t3), K)), K);  // each term < 2l
+  u32 kw[8];
+  fr_to_words(kr, kw);
+  Ext Rp = fixed_base_mul(fb_table, W, nwin, kw, K);             // :351
+  Ext Ap = fixed_base_mul(fb_table, W, nwin, sk, K);             // :354
+  Fr zi = fr_inv(fr_mul(Rp.Z, Ap.Z));
+  Fr zr = fr_mul(zi, Ap.Z), za = fr_mul(zi, Rp.Z);
+  Fr h[5];
+  h[0] = fr_mul(fr_mul(Ap.X, za), K.FINV); h[1] = fr_mul(Ap.Y, za);   // pk first, :369
+  h[2] = fr_mul(fr_mul(Rp.X, zr), K.FINV); h[3] = fr_mul(Rp.Y, zr);
+  h[4] = fr_to_mont_words(msg);                                  // :368
+  Fr hm = poseidon5(h, K);
+  u32 hw[8];
+  fr_from_mont_words(hm, hw);                                    // canonical integer, :371
+  // s = k + sk * h over the integers (:359): 8 x 8 word product accumulated onto k
+  u64 acc = 0;
+#pragma unroll
+  for (int c = 0; c < SCHNORR_S_WORDS; c++) {
+    u64 carry = 0;
+    if (c < SCHNORR_K_WORDS) acc += k[c];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int j = c - i;
+      if (j >= 0 && j < 8) {
+        const u64 p = (u64)sk[i] * hw[j];
+        acc += (u32)p;
+        carry += p >> 32;
+      }
+    }
+    out_s[c] = (u32)acc;
+    acc = (acc >> 32) + carry;
+  }
+  fr_from_mont_words(h[2], out_rx); fr_from_mont_words(h[3], out_ry);
+  return true;
+}
+
 }  // namespace bjj

@@ -22,6 +22,7 @@
  *   bjj_scalar_keys      PrivateKey::scalar_key()    src/lib.rs:284-302 (Blake-512, prune, >> 3)
  *   bjj_public_keys      PrivateKey::public()        src/lib.rs:304-306
  *   bjj_sign             PrivateKey::sign(msg)       src/lib.rs:308-342
+ *   bjj_sign_schnorr     PrivateKey::sign_schnorr(m) src/lib.rs:344-361 (caller-supplied nonce)
  *   bjj_eddsa_verify_compressed  decompress_point(pk), decompress_signature(sig)
  *                        (src/lib.rs:260-268), then verify -- the wire-format ingest path
  *
@@ -125,6 +126,16 @@ int bjj_scalar_keys(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, size_t n, uint
 int bjj_public_keys(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, size_t n, uint8_t* out_xy /* n*64 */);
 int bjj_sign(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, const uint8_t* msgs /* n*32 */, size_t n,
              uint8_t* out_r_xy /* n*64 */, uint8_t* out_s /* n*32 */, uint8_t* ok /* n */);
+/* PrivateKey::sign_schnorr(m) -> Result<(Point, BigInt), String> (src/lib.rs:344-361) with the nonce supplied by
+ * the caller: the reference draws k = rng.gen_biguint(1024) (:347-348) -- randomness stays on the host, so the
+ * call is deterministic.  nonces: 128-byte little-endian integers.  out_r = k*B8; out_s = k + scalar_key*h as
+ * the reference's UNREDUCED integer (:359, < 2^1025) in a 160-byte little-endian record (reduce it mod 8l
+ * before bjj_schnorr_verify).  ok[i] = 0 where the reference returns Err (msg > Q, :365-367; outputs zeroed). */
+#define BJJ_SCHNORR_NONCE_BYTES 128
+#define BJJ_SCHNORR_S_BYTES 160
+int bjj_sign_schnorr(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, const uint8_t* msgs /* n*32 */,
+                     const uint8_t* nonces /* n*128 */, size_t n, uint8_t* out_r_xy /* n*64 */,
+                     uint8_t* out_s /* n*160 */, uint8_t* ok /* n */);
 
 /* ---- device-pointer batch API (asynchronous on `stream`) -------------------- */
 int bjj_mul_fixed_base_dev(bjj_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* stream);
@@ -141,6 +152,8 @@ int bjj_scalar_keys_dev(bjj_ctx* ctx, const void* d_keys, size_t n, void* d_out,
 int bjj_public_keys_dev(bjj_ctx* ctx, const void* d_keys, size_t n, void* d_out_xy, void* stream);
 int bjj_sign_dev(bjj_ctx* ctx, const void* d_keys, const void* d_msgs, size_t n, void* d_out_r_xy, void* d_out_s,
                  void* d_ok, void* stream);
+int bjj_sign_schnorr_dev(bjj_ctx* ctx, const void* d_keys, const void* d_msgs, const void* d_nonces, size_t n,
+                         void* d_out_r_xy, void* d_out_s, void* d_ok, void* stream);
 int bjj_compress_points_dev(bjj_ctx* ctx, const void* d_pts_xy, size_t n, void* d_out, void* stream);
 int bjj_decompress_points_dev(bjj_ctx* ctx, const void* d_in, size_t n, void* d_out_xy, void* d_ok, void* stream);
 int bjj_eddsa_verify_compressed_dev(bjj_ctx* ctx, const void* d_pk, const void* d_sig, const void* d_msg, size_t n,

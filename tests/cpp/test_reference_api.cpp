@@ -79,6 +79,22 @@ static void test_point_compress_decompress() {  // lib.rs:575-594
   try { std::array<uint8_t, 32> bad; bad.fill(0xff); decompress_point(bad); } catch (const std::invalid_argument&) { threw = true; }
   ASSERT_TRUE(threw);
 }
+static void test_schnorr_signature() {  // lib.rs:678-686: sign_schnorr -> verify_schnorr == true
+  std::vector<uint8_t> kb(32); for (int i = 0; i < 32; i++) kb[i] = (uint8_t)(7 * i + 1);
+  PrivateKey sk = PrivateKey::import(kb);
+  Point pk = sk.public_key();
+  U256 msg = U256::from_str("123456789012345678901234567890");
+  std::array<uint8_t, BJJ_SCHNORR_NONCE_BYTES> k; for (size_t i = 0; i < k.size(); i++) k[i] = (uint8_t)(251 * i + 17);
+  auto rs = sk.sign_schnorr(msg, k);
+  ASSERT_TRUE(verify_schnorr(pk, msg, rs.first, rs.second.data(), rs.second.size()));
+  auto tampered = rs.second; tampered[0] ^= 1;
+  ASSERT_TRUE(!verify_schnorr(pk, msg, rs.first, tampered.data(), tampered.size()));
+  ASSERT_TRUE(rs.first.equals(B8().mul_scalar(reduce_mod_order(k.data(), k.size()))));  // r = k*B8, lib.rs:351
+  bool threw = false;
+  U256 big = U256::from_str("21888242871839275222246405745257275088548364400416034343698204186575808495618");  // Q + 1
+  try { sk.sign_schnorr(big, k); } catch (const std::invalid_argument&) { threw = true; }
+  ASSERT_TRUE(threw);
+}
 static void test_batch() {
   std::vector<U256> n; for (uint64_t i = 0; i < 1000; i++) n.push_back(U256(i * 0x9E3779B97F4A7C15ULL + 1));
   std::vector<Point> a = mul_fixed_base_batch(n);
@@ -88,7 +104,7 @@ static void test_batch() {
 }
 int main() {
   try {
-    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_point_compress_decompress(); test_batch();
+    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_point_compress_decompress(); test_schnorr_signature(); test_batch();
   } catch (const std::exception& e) { printf("EXCEPTION %s\n", e.what()); return 2; }
   printf(failures ? "FAILED %d\n" : "ok (reference tests re-stated in C++)\n", failures);
   return failures ? 1 : 0;

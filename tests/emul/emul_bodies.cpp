@@ -92,6 +92,14 @@ int emul_sign(const uint8_t* key, const uint8_t* msg, int W, uint8_t* out_r, uin
   if (!ok) { memset(out_r, 0, 64); memset(out_s, 0, 32); return 0; }
   memcpy(out_r, rx, 32); memcpy(out_r + 32, ry, 32); memcpy(out_s, s, 32); return 1;
 }
+int emul_sign_schnorr(const uint8_t* key, const uint8_t* msg, const uint8_t* nonce, int W, uint8_t* out_r, uint8_t* out_s) {
+  ensure_table(W);
+  alignas(16) u32 k[8], m[8], kn[SCHNORR_K_WORDS], rx[8], ry[8], s[SCHNORR_S_WORDS];
+  memcpy(k, key, 32); memcpy(m, msg, 32); memcpy(kn, nonce, SCHNORR_K_WORDS * 4);
+  bool ok = sign_schnorr_item(k, m, kn, table_ptr(), g_W, g_nwin, rx, ry, s, K);
+  if (!ok) { memset(out_r, 0, 64); memset(out_s, 0, SCHNORR_S_WORDS * 4); return 0; }
+  memcpy(out_r, rx, 32); memcpy(out_r + 32, ry, 32); memcpy(out_s, s, SCHNORR_S_WORDS * 4); return 1;
+}
 int emul_verify_schnorr(const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, int W) {
   ensure_table(W);
   alignas(16) uint8_t b[192]; alignas(16) static u32 tbl[VB_VERIFY_WORDS];

@@ -4,7 +4,7 @@ nonce drawn from a seeded stream."""
 import numpy as np
 import pytest
 
-from conftest import pack
+from conftest import pack, unpack
 
 Q = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 L = 2736030358979909402780800718157159386076813972158567259200215660948447373041
@@ -67,3 +67,103 @@ def test_gpu_reference_api_schnorr(gpu_ctx, pyoracle):
     assert bjj.verify_schnorr(pk, msg + 1, bjj.Point(*r), s) is False
     with pytest.raises(ValueError):
         bjj.verify_schnorr(pk, Q + 1, bjj.Point(*r), s)
+
+
+# ---- sign_schnorr (src/lib.rs:344-361) with caller-supplied nonces -------------------------------------
+ORDER8 = 8 * 2736030358979909402780800718157159386076813972158567259200215660948447373041
+
+
+def _schnorr_sign_cases():
+    """(key, msg, nonce): edge nonces (0, 1, l, 2^1024 - 1, top bit only) and msgs (0, Q, Q + 1 = Err) + seeded random"""
+    rng = np.random.default_rng(0x5C4E)
+    rb = lambda n: int.from_bytes(rng.bytes(n), "little")  # noqa: E731
+    L = ORDER8 // 8
+    cases = [(bytes(range(32)), 0, 0), (bytes(range(32)), 1, 1), (b"\xff" * 32, Q, L), (b"\x00" * 32, Q + 1, 5),
+             (bytes(rng.bytes(32)), rb(31), (1 << 1024) - 1), (bytes(rng.bytes(32)), Q - 1, 1 << 1023),
+             (bytes(rng.bytes(32)), rb(31), L - 1), (bytes(rng.bytes(32)), rb(31), (1 << 261) - 1)]
+    cases += [(bytes(rng.bytes(32)), rb(32) % Q, rb(128)) for _ in range(10)]
+    return cases
+
+
+def _schnorr_expect(pyoracle, cases):
+    out = []
+    for key, m, k in cases:
+        res = pyoracle.sign_schnorr_with_nonce(key, m, k)
+        out.append(None if res is None else (tuple(res[0]), res[1]))
+    return out
+
+
+def test_oracle_sign_schnorr_roundtrip(pyoracle):
+    """the reference's own (and only) Schnorr test is sign -> verify == true, src/lib.rs:678-686"""
+    for key, m, k in _schnorr_sign_cases()[:6]:
+        res = pyoracle.sign_schnorr_with_nonce(key, m, k)
+        if m > Q:
+            assert res is None
+            continue
+        r, s = res
+        assert s == k + pyoracle.scalar_key(key) * pyoracle.schnorr_hash(pyoracle.public(key), m, r)
+        assert pyoracle.verify_schnorr(pyoracle.public(key), m, r, s) is True
+
+
+def test_emul_sign_schnorr(emul, pyoracle):
+    import ctypes
+    cases = _schnorr_sign_cases()[:10]
+    r, s = ctypes.create_string_buffer(64), ctypes.create_string_buffer(160)
+    for (key, m, k), want in zip(cases, _schnorr_expect(pyoracle, cases)):
+        ok = emul.emul_sign_schnorr(key, (m % (1 << 256)).to_bytes(32, "little"), k.to_bytes(128, "little"), 6, r, s)
+        assert bool(ok) == (want is not None)
+        if want is not None:
+            assert unpack(r.raw, 2)[0] == want[0] and int.from_bytes(s.raw, "little") == want[1]
+        else:
+            assert r.raw == b"\x00" * 64 and s.raw == b"\x00" * 160
+
+
+@pytest.mark.gpu
+def test_gpu_sign_schnorr_vs_oracle_and_roundtrip(gpu_ctx, pyoracle, oracle):
+    cases = _schnorr_sign_cases()
+    want = _schnorr_expect(pyoracle, cases)
+    keys = np.frombuffer(b"".join(c[0] for c in cases), np.uint8).reshape(-1, 32)
+    msgs = pack([c[1] for c in cases]).reshape(-1, 32)
+    nonces = np.frombuffer(b"".join(c[2].to_bytes(128, "little") for c in cases), np.uint8).reshape(-1, 128)
+    r, s, ok = gpu_ctx.sign_schnorr(keys, msgs, nonces)
+    assert [bool(v) for v in ok] == [w is not None for w in want]
+    for i, w in enumerate(want):
+        if w is None:
+            assert not r[i].any() and not s[i].any()
+        else:
+            assert unpack(r[i], 2)[0] == w[0] and int.from_bytes(s[i].tobytes(), "little") == w[1]
+    # sign -> verify on the GPU (src/lib.rs:678-686), s reduced mod 8l for the 32-byte record
+    good = [i for i, w in enumerate(want) if w is not None]
+    sv = pack([want[i][1] % ORDER8 for i in good]).reshape(-1, 32)
+    pk = gpu_ctx.public_keys(keys[good])
+    assert (gpu_ctx.schnorr_verify(pk, r[good], sv, msgs[good]) == 1).all()
+    assert (oracle.verify_schnorr(pk, r[good], sv, msgs[good]) == 1).all()
+    # a 3 000-item seeded batch through the pipelined host API: every signature must verify
+    rng = np.random.default_rng(77)
+    n = 3000
+    keys = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8); msgs[:, 31] &= 0x1f
+    nonces = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+    r, s, ok = gpu_ctx.sign_schnorr(keys, msgs, nonces)
+    assert ok.all()
+    sv = pack([int.from_bytes(s[i].tobytes(), "little") % ORDER8 for i in range(n)]).reshape(-1, 32)
+    pk = gpu_ctx.public_keys(keys)
+    assert (gpu_ctx.schnorr_verify(pk, r, sv, msgs) == 1).all()
+    sv[::7, 0] ^= 1
+    got = gpu_ctx.schnorr_verify(pk, r, sv, msgs)
+    assert (got[::7] == 0).all() and (np.delete(got, np.arange(0, n, 7)) == 1).all()
+
+
+@pytest.mark.gpu
+def test_gpu_reference_api_sign_schnorr(gpu_ctx, pyoracle):
+    import babyjubjub_rs_amd as bjj
+    sk = bjj.new_key()                                                           # lib.rs:387-393
+    assert len(sk.key) == 32
+    msg = 123456789012345678901234567890
+    r, s = sk.sign_schnorr(msg)                                                  # random nonce, lib.rs:347-348
+    assert bjj.verify_schnorr(sk.public(), msg, r, s) is True                    # lib.rs:678-686
+    r2, s2 = sk.sign_schnorr(msg, k=(1 << 1000) + 99)
+    want = pyoracle.sign_schnorr_with_nonce(sk.key, msg, (1 << 1000) + 99)
+    assert (r2.x, r2.y) == tuple(want[0]) and s2 == want[1]
+    with pytest.raises(ValueError):
+        sk.sign_schnorr(Q + 1)
