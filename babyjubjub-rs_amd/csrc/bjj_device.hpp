@@ -107,44 +107,82 @@ BJJ_HD Niels niels_cneg_lazy(const Niels& n, bool neg) {
   r.t2d = fr_select(neg, fr_sub_lazy(fr_zero(), n.t2d), n.t2d);
   return r;
 }
-BJJ_HD Niels fixed_load_signed(const u32* table, const u32 sc[8], int j, int W, u32& carry) {
-  bool neg;
-  const size_t slot = fixed_digit_slot(sc, j, W, carry, neg);
-  return niels_cneg_lazy(load_niels(table + slot * NIELS_WORDS), neg);
-}
+// ---- gather policies ---------------------------------------------------------------------------------
+// How a lane obtains table entry `slot`.  A policy has a `Pending` handle type and
+//     void  issue(size_t slot, Pending& p, int buf);   // start the gather (buf: staging buffer 0 / 1)
+//     Niels finish(Pending& p, int buf);               // complete it, return the entry
+// The loops below issue gather j+1, run the 7 multiplications of addition j, and only then finish.
+//  * GatherPerLane (here): every lane reads its own 128-byte entry (7 x dwordx4).  Works in divergent code and
+//    on the host (tests/emul).  hipcc sinks the loads to their first use, so nothing overlaps, and each of
+//    the 7 load instructions touches 64 different lines/pages: fine for cache- or TLB-resident tables.
+//  * GatherCoopLds (bjj_hip.hip, device only): the 64 lanes of a wave fetch their 64 entries together, 8 full
+//    lines per instruction, straight into LDS -- what makes the 43 / 155 GB tables pay off.
+struct GatherPerLane {
+  struct Pending { Niels e; };
+  static constexpr int kBuffers = 2;   // gathers that may be in flight at once
+  const u32* table;
+  BJJ_HD void issue(size_t slot, Pending& p, int) const { p.e = load_niels(table + slot * NIELS_WORDS); }
+  BJJ_HD Niels finish(Pending& p, int) const { return p.e; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BJJ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // nothing is scheduled across: keeps `finish` behind the addition
+#else
+#define BJJ_SCHED_FENCE() ((void)0)
+#endif
+
 // acc + sc * B8, sc < l.  The result's T is not computed (callers only compare or convert X, Y, Z).
-BJJ_HD Ext fixed_base_accumulate(Ext acc, const u32* table, int W, int nwin, const u32 sc[8]) {
+template <class G>
+BJJ_HD Ext fixed_base_accumulate(Ext acc, const G& g, int W, int nwin, const u32 sc[8]) {
   u32 carry = 0;
-  Niels cur = fixed_load_signed(table, sc, 0, W, carry);
+  bool neg;
+  typename G::Pending p;
+  g.issue(fixed_digit_slot(sc, 0, W, carry, neg), p, 0);
+  Niels cur = niels_cneg_lazy(g.finish(p, 0), neg);
 #pragma unroll 1
   for (int j = 0; j + 1 < nwin; j++) {
-    Niels nxt = fixed_load_signed(table, sc, j + 1, W, carry);  // next gather before this window's 7 multiplications
+    g.issue(fixed_digit_slot(sc, j + 1, W, carry, neg), p, (j + 1) & 1);  // in flight during this window's 7 multiplications
     acc = ext_madd(acc, cur);
-    cur = nxt;
+    BJJ_SCHED_FENCE();
+    cur = niels_cneg_lazy(g.finish(p, (j + 1) & 1), neg);
   }
   return ext_madd<false>(acc, cur);
+}
+BJJ_HD Ext fixed_base_accumulate(Ext acc, const u32* table, int W, int nwin, const u32 sc[8]) {
+  return fixed_base_accumulate(acc, GatherPerLane{table}, W, nwin, sc);
 }
 
 // n * B8 from scratch (n any 256-bit integer): window 0's entry is lifted directly to extended coordinates
 // (X:Y:Z:T) = (2x' : 2y : 2 : 2x'y), T recovered from the stored 2D'x'y with one
 // multiplication by 1/D', instead of a 7M addition to the identity.
-BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 raw[8], const Consts& K) {
+template <class G>
+BJJ_HD Ext fixed_base_mul(const G& g, int W, int nwin, const u32 raw[8], const Consts& K) {
   u32 sc[8];
   scalar_mod_l(raw, sc, K);
   u32 carry = 0;
-  Niels n0 = fixed_load_signed(table, sc, 0, W, carry);
-  Niels cur = fixed_load_signed(table, sc, 1, W, carry);
+  bool neg0, neg;
+  typename G::Pending p0, p;
+  g.issue(fixed_digit_slot(sc, 0, W, carry, neg0), p0, 0);
+  const size_t slot1 = fixed_digit_slot(sc, 1, W, carry, neg);
+  if (G::kBuffers >= 2) g.issue(slot1, p, 1);
+  const Niels n0 = niels_cneg_lazy(g.finish(p0, 0), neg0);
+  if (G::kBuffers < 2) g.issue(slot1, p, 1);
   Ext acc;
   acc.X = fr_reduce_weak(fr_sub(n0.ypx, n0.ymx));  // ext_madd wants coordinates < 2r
   acc.Y = fr_add(n0.ypx, n0.ymx);
   acc.Z = fr_add(fr_one(), fr_one()); acc.T = fr_mul(n0.t2d, K.DPINV);
+  BJJ_SCHED_FENCE();
+  Niels cur = niels_cneg_lazy(g.finish(p, 1), neg);
 #pragma unroll 1
   for (int j = 1; j + 1 < nwin; j++) {
-    Niels nxt = fixed_load_signed(table, sc, j + 1, W, carry);
+    g.issue(fixed_digit_slot(sc, j + 1, W, carry, neg), p, (j + 1) & 1);
     acc = ext_madd(acc, cur);
-    cur = nxt;
+    BJJ_SCHED_FENCE();
+    cur = niels_cneg_lazy(g.finish(p, (j + 1) & 1), neg);
   }
-  return ext_madd<false>(acc, cur);  // nwin >= 10: the last window's addition, T not needed by the epilogue
+  return ext_madd<false>(acc, cur);  // nwin >= 9: the last window's addition, T not needed by the epilogue
+}
+BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 raw[8], const Consts& K) {
+  return fixed_base_mul(GatherPerLane{table}, W, nwin, raw, K);
 }
 
 // =============================================================================
@@ -660,13 +698,16 @@ BJJ_HD Ext joint_mul_windowed(const u32* tbl1, const u32* tbl2, const Fr& u, con
 // hash input order (pk, R, msg) instead of (R, pk, msg), the hash is NOT multiplied by 8, and msg > Q is
 // an Err -- verdict 2 -- rather than `false`).  Verdict 0 / 1 / 2; need_exact is set when pk or R is off
 // the curve (the item then belongs to the exact path and the verdict returned here is meaningless).
-template <bool SCHNORR>
-BJJ_HD int verify_fast_t(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K,
+// Straight-line on purpose: items whose verdict is already known (msg > Q, off-curve) run through the same
+// arithmetic on their meaningless data instead of leaving early, so that all lanes of a wave reach the
+// fixed-base part together -- the cooperative gather policy needs the whole wave, and a wave executes the
+// instructions of its slowest lane anyway.
+template <bool SCHNORR, class G>
+BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* vb_tbl, const Consts& K,
                          bool& need_exact) {
   u32 w[8];
-  need_exact = false;
   load_w8(in.msg, w);
-  if (words_gt_modulus(w)) return SCHNORR ? 2 : 0;              // :396-398 / :365-367
+  const bool msg_gt = words_gt_modulus(w);                      // :396-398 / :365-367
   Fr h[5];
   h[4] = fr_to_mont_words(w);                                   // :399
   Fr rx, ry, ax, ay;
@@ -674,13 +715,14 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const u32* fb_table, int W, int nwi
   load_w8((const char*)in.r + 32, w);  ry = fr_to_mont_words(w);
   load_w8(in.pk, w);                   ax = fr_to_mont_words(w);
   load_w8((const char*)in.pk + 32, w); ay = fr_to_mont_words(w);
-  if (!(ref_on_curve(rx, ry, K) && ref_on_curve(ax, ay, K))) { need_exact = true; return 0; }
+  need_exact = !msg_gt && !(ref_on_curve(rx, ry, K) && ref_on_curve(ax, ay, K));
   if (SCHNORR) { h[0] = ax; h[1] = ay; h[2] = rx; h[3] = ry; }  // :369
   else         { h[0] = rx; h[1] = ry; h[2] = ax; h[3] = ay; }  // :400
   Fr hm = poseidon5(h, K);                                      // :400-404
   Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // canonical integer, :406
   u32 sw[8];
   load_w8(in.s, sw);
+  int verdict;
   if (SCHNORR) {
     // s*B8 == R + hm*A  <=>  hm*(-A) + s*B8 == R   (hm < r < 8l: no reduction; A may carry torsion and
     // hm may be even, so the half-size trick below does not apply)
@@ -691,9 +733,10 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const u32* fb_table, int W, int nwi
     Ext q = vb_mul_windowed(vb_tbl, kw, 64);                    // scalar < 2^254
     u32 sl[8];
     scalar_mod_l(sw, sl, K);                                    // B8 has order l
-    q = fixed_base_accumulate(q, fb_table, W, nwin, sl);        // + s*B8   (:377)
+    q = fixed_base_accumulate(q, fb, W, nwin, sl);              // + s*B8   (:377)
     Fr fx = fr_mul(rx, K.F);                                    // compare with R on the a'=-1 curve
-    return (fr_eq(q.X, fr_mul(fx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z))) ? 1 : 0;
+    verdict = (fr_eq(q.X, fr_mul(fx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z))) ? 1 : 0;
+    return msg_gt ? 2 : verdict;
   }
   // EdDSA: v*(s*B8 - 8*kappa*A - R) == O  with the short odd pair (u, v), u = v*kappa mod l (see above)
   Fr u, vmag;
@@ -717,8 +760,9 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const u32* fb_table, int W, int nwi
   // (all but ~2e-5 of the pairs); the rest -- e.g. kappa = (l+1)/2 gives u of 250 bits -- take 64 windows
   const int jw = ((ub > vb ? ub : vb) <= 134) ? 34 : 64;
   Ext q = joint_mul_windowed(vb_tbl, tbl2, u, vmag, jw);
-  q = fixed_base_accumulate(q, fb_table, W, nwin, cw);          // + (v s mod l)*B8
-  return (fr_is_zero(q.X) && fr_eq(q.Y, q.Z)) ? 1 : 0;          // projective identity (0 : z : z)
+  q = fixed_base_accumulate(q, fb, W, nwin, cw);                // + (v s mod l)*B8
+  verdict = (fr_is_zero(q.X) && fr_eq(q.Y, q.Z)) ? 1 : 0;       // projective identity (0 : z : z)
+  return msg_gt ? 0 : verdict;
 }
 // Exact path: replays src/lib.rs:395-412 (or :375-385) operation by operation (any input).
 template <bool SCHNORR>
@@ -764,7 +808,7 @@ BJJ_HD int verify_exact_t(const VerifyIn& in, const Consts& K) {
 }
 BJJ_HD bool verify_fast(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K,
                         bool& need_exact) {
-  return verify_fast_t<false>(in, fb_table, W, nwin, vb_tbl, K, need_exact) == 1;
+  return verify_fast_t<false>(in, GatherPerLane{fb_table}, W, nwin, vb_tbl, K, need_exact) == 1;
 }
 BJJ_HD bool verify_exact(const VerifyIn& in, const Consts& K) { return verify_exact_t<false>(in, K) == 1; }
 BJJ_HD bool verify_item(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K) {
@@ -774,7 +818,7 @@ BJJ_HD bool verify_item(const VerifyIn& in, const u32* fb_table, int W, int nwin
 }
 BJJ_HD int verify_schnorr_item(const VerifyIn& in, const u32* fb_table, int W, int nwin, u32* vb_tbl, const Consts& K) {
   bool need_exact;
-  int v = verify_fast_t<true>(in, fb_table, W, nwin, vb_tbl, K, need_exact);
+  int v = verify_fast_t<true>(in, GatherPerLane{fb_table}, W, nwin, vb_tbl, K, need_exact);
   return need_exact ? verify_exact_t<true>(in, K) : v;
 }
 

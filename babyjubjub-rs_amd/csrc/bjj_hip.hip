@@ -32,10 +32,13 @@ using namespace bjj;
 
 #define BJJ_VERSION_STRING "bjj-hip 0.1.0 gfx950"
 #define BJJ_BLOCK 256
-// Fixed-base window width when bjj_init is given 0: 11 signed 23-bit digits, 11 x (2^22 + 1) entries = 5.9 GB
-// of the 288 GB of HBM.  Measured on MI355X (profiles/r01_ablation_signed_windows.txt): 16 bits (67 MB) 1.12 ms,
-// 18 (235 MB) 1.03, 21 (1.6 GB) 0.96, 23 (5.9 GB) 0.91, 26 (43 GB, 10 digits) 1.00 ms per 2^20 multiplications.
-#define BJJ_DEFAULT_WINDOW_BITS 23
+// Fixed-base window width when bjj_init is given 0: the widest of these whose table fits in 60 % of the device's
+// free memory -- 28 bits = 9 signed digits, 9 x (2^27 + 1) entries = 154.6 GB of the 288 GB of HBM; 26 = 10 digits,
+// 42.9 GB; 23 = 11 digits, 5.9 GB; 21 = 12 digits, 1.6 GB; 16 = 16 digits, 67 MB.  One addition less per step:
+// the kernel is VALU-bound and the cooperative gathers keep the table reads off the critical path at any size
+// (profiles/r01_ablation_signed_windows.txt for the earlier lane-private gathers; r01i_* for these).
+static const int kAutoWindowBits[] = {28, 26, 23, 21, 16};
+#define BJJ_MAX_WINDOW_BITS 28
 // Workgroup size of the kernels that end in the shared-inversion epilogue: one binary-GCD
 // inversion (executed by one wave) is amortised over the whole workgroup.
 #define BJJ_EPI_BLOCK 512
@@ -177,19 +180,67 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_check_fixed_table(const u32* 
 // ---------------------------------------------------------------------------
 // K1: fixed base
 // ---------------------------------------------------------------------------
+// Wave-cooperative gather straight into LDS (policy interface: bjj_device.hpp "gather policies").
+// A lane-private gather costs 7 load instructions x 64 lanes, every lane in its own 128-byte line and, for tables beyond
+// the TLB reach, its own page: measured alone (tools/ubench/gather_bench.hip) that pattern sustains 12.7 G gathers/s on a
+// 5.9 GB table and 10.8 G/s on 155 GB, the one used here 48 and 46 G/s.  Load instruction k of a wave fetches the 8 FULL
+// lines of the entries owned by lanes 8k .. 8k+7: lane L moves one 16-byte chunk of the entry of lane e = 8k + L/8, whose slot
+// number it obtains by a cross-lane read, with global_load_lds_dwordx4 (no VGPR staging; LDS address = M0 + 16 L), so an
+// instruction touches 8 lines, each exactly once.  Chunk c of entry e lands at position c ^ ((e >> 1) & 7) of the entry's
+// 128-byte LDS row, which makes the read-back of one's own entry (7 x ds_read_b128, lane stride 128 B) bank-conflict free.
+// hipcc does not track LDS-DMA completion, hence the explicit s_waitcnt.  ALL 64 lanes of the wave must call issue/finish
+// together (cross-lane reads).  NBUF = 2 staging areas per wave let two gathers be in flight (the start of a fresh
+// multiplication in K1); with NBUF = 1 the loops still overlap gather j+1 with addition j, whose entry is in registers by then.
+#define FB_STAGE_WORDS (64 * NIELS_WORDS)   // 8 KB: one staged entry per lane
+template <int NBUF>
+struct GatherCoopLds {
+  struct Pending {};
+  static constexpr int kBuffers = NBUF;
+  const u32* table;
+  u32* wlds;   // this wave's staging area
+  int lane;
+  __device__ __forceinline__ void issue(size_t slot, Pending&, int buf) const {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int e = 8 * k + (lane >> 3);
+      const u32 s = (u32)__shfl((int)(u32)slot, e, 64);
+      const int c = (lane & 7) ^ ((e >> 1) & 7);
+      __builtin_amdgcn_global_load_lds(table + (size_t)s * NIELS_WORDS + c * 4,
+                                       (__attribute__((address_space(3))) void*)(wlds + (NBUF > 1 ? buf : 0) * FB_STAGE_WORDS + k * (8 * NIELS_WORDS)),
+                                       16, 0, 0);
+    }
+  }
+  __device__ __forceinline__ Niels finish(Pending&, int buf) const {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const U4* q = (const U4*)(wlds + (NBUF > 1 ? buf : 0) * FB_STAGE_WORDS + lane * NIELS_WORDS);
+    const int x = (lane >> 1) & 7;
+    const U4 a = q[0 ^ x], b = q[1 ^ x], c = q[2 ^ x], d = q[3 ^ x], e = q[4 ^ x], f = q[5 ^ x], h = q[6 ^ x];
+    Niels n;
+    n.ymx = Fr{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x}};
+    n.ypx = Fr{{c.y, c.z, c.w, d.x, d.y, d.z, d.w, e.x, e.y}};
+    n.t2d = Fr{{e.z, e.w, f.x, f.y, f.z, f.w, h.x, h.y, h.z}};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are free again before the next issue overwrites them
+    return n;
+  }
+};
+
 __global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
                                                                   const uint8_t* __restrict__ scalars, size_t n,
                                                                   uint8_t* __restrict__ out, u32* __restrict__ scratch) {
   __shared__ u32 lds[NL * 64];
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_EPI_BLOCK / 64) * 2 * FB_STAGE_WORDS];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const GatherCoopLds<2> fb = {table, stage + (threadIdx.x >> 6) * 2 * FB_STAGE_WORDS, lane};
   Fr run = fr_one();
 #pragma unroll 1
-  for (size_t i = tid; i < n; i += nthreads) {
+  for (size_t i = tid; i - lane < n; i += nthreads) {  // wave-uniform trip count: the gathers are cooperative
+    const bool valid = i < n;
     u32 sc[8];
-    load_w8(scalars + i * 32, sc);
-    Ext p = fixed_base_mul(table, W, nwin, sc, c_K);
-    epilogue_stash(p, run, out + i * 64, scratch + i * 16);
+    load_w8(scalars + (valid ? i : n - 1) * 32, sc);
+    Ext p = fixed_base_mul(fb, W, nwin, sc, c_K);
+    if (valid) epilogue_stash(p, run, out + i * 64, scratch + i * 16);
   }
   epilogue_run(run, n, tid, nthreads, out, scratch, lds);
 }
@@ -291,8 +342,10 @@ __device__ __forceinline__ void verify_kernel_body(const u32* __restrict__ table
                                                    const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg, size_t n,
                                                    uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
                                                    u32* __restrict__ wl) {
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_BLOCK / 64) * FB_STAGE_WORDS];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
+  const GatherCoopLds<1> fb = {table, stage + (threadIdx.x >> 6) * FB_STAGE_WORDS, lane};
   u32* tbl = vb_tables + tid * VB_VERIFY_WORDS;
   const unsigned long long nexact = wl[0];
 #pragma unroll 1
@@ -309,13 +362,11 @@ __device__ __forceinline__ void verify_kernel_body(const u32* __restrict__ table
   for (;;) {  // then the bulk
     const unsigned long long c = wave_grab(wl + 4, lane);
     if (c >= n) break;
-    const size_t i = c + lane;
-    if (i < n) {
-      VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
-      bool need_exact;
-      const int v = verify_fast_t<SCHNORR>(in, table, W, nwin, tbl, c_K, need_exact);
-      if (!need_exact) ok[i] = (uint8_t)v;  // exact items were written by the first loop
-    }
+    const size_t i = c + lane, ic = i < n ? i : n - 1;  // every lane runs (cooperative gathers); the tail repeats the last item
+    VerifyIn in = {pk + ic * 64, rb8 + ic * 64, s + ic * 32, msg + ic * 32};
+    bool need_exact;
+    const int v = verify_fast_t<SCHNORR>(in, fb, W, nwin, tbl, c_K, need_exact);
+    if (i < n && !need_exact) ok[i] = (uint8_t)v;  // exact items were written by the first loop
   }
 }
 // verify_schnorr (src/lib.rs:375-385): same structure, verdict 2 = Err (msg > Q)
@@ -419,16 +470,22 @@ __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign(const u32* __restrict
                                                            const uint8_t* __restrict__ msgs, size_t n,
                                                            uint8_t* __restrict__ out_r, uint8_t* __restrict__ out_s,
                                                            uint8_t* __restrict__ ok) {
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_BLOCK / 64) * FB_STAGE_WORDS];
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const GatherCoopLds<1> fb = {table, stage + (threadIdx.x >> 6) * FB_STAGE_WORDS, lane};
 #pragma unroll 1
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i - lane < n; i += nthreads) {  // wave-uniform trip count
+    const size_t ic = i < n ? i : n - 1;
     u32 k[8], m[8], rx[8], ry[8], s[8];
-    load_w8(keys + i * 32, k); load_w8(msgs + i * 32, m);
-    const bool good = sign_item(k, m, table, W, nwin, rx, ry, s, c_K);
+    load_w8(keys + ic * 32, k); load_w8(msgs + ic * 32, m);
+    const bool good = sign_item(k, m, fb, W, nwin, rx, ry, s, c_K);
+    if (i < n) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) { rx[j] = good ? rx[j] : 0u; ry[j] = good ? ry[j] : 0u; s[j] = good ? s[j] : 0u; }
-    store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry); store_w8(out_s + i * 32, s);
-    ok[i] = good ? 1 : 0;
+      for (int j = 0; j < 8; j++) { rx[j] = good ? rx[j] : 0u; ry[j] = good ? ry[j] : 0u; s[j] = good ? s[j] : 0u; }
+      store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry); store_w8(out_s + i * 32, s);
+      ok[i] = good ? 1 : 0;
+    }
   }
 }
 
@@ -440,22 +497,28 @@ __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign_schnorr(const u32* __
                                                                    const uint8_t* __restrict__ nonces, size_t n,
                                                                    uint8_t* __restrict__ out_r, uint8_t* __restrict__ out_s,
                                                                    uint8_t* __restrict__ ok) {
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_BLOCK / 64) * FB_STAGE_WORDS];
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const GatherCoopLds<1> fb = {table, stage + (threadIdx.x >> 6) * FB_STAGE_WORDS, lane};
 #pragma unroll 1
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i - lane < n; i += nthreads) {  // wave-uniform trip count
+    const size_t ic = i < n ? i : n - 1;
     u32 k[8], m[8], rx[8], ry[8], kn[SCHNORR_K_WORDS], s[SCHNORR_S_WORDS];
-    load_w8(keys + i * 32, k); load_w8(msgs + i * 32, m);
+    load_w8(keys + ic * 32, k); load_w8(msgs + ic * 32, m);
 #pragma unroll
-    for (int j = 0; j < SCHNORR_K_WORDS / 8; j++) load_w8(nonces + i * (SCHNORR_K_WORDS * 4) + j * 32, kn + 8 * j);
-    const bool good = sign_schnorr_item(k, m, kn, table, W, nwin, rx, ry, s, c_K);
+    for (int j = 0; j < SCHNORR_K_WORDS / 8; j++) load_w8(nonces + ic * (SCHNORR_K_WORDS * 4) + j * 32, kn + 8 * j);
+    const bool good = sign_schnorr_item(k, m, kn, fb, W, nwin, rx, ry, s, c_K);
+    if (i < n) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) { rx[j] = good ? rx[j] : 0u; ry[j] = good ? ry[j] : 0u; }
+      for (int j = 0; j < 8; j++) { rx[j] = good ? rx[j] : 0u; ry[j] = good ? ry[j] : 0u; }
 #pragma unroll
-    for (int j = 0; j < SCHNORR_S_WORDS; j++) s[j] = good ? s[j] : 0u;
-    store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry);
+      for (int j = 0; j < SCHNORR_S_WORDS; j++) s[j] = good ? s[j] : 0u;
+      store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry);
 #pragma unroll
-    for (int j = 0; j < SCHNORR_S_WORDS / 8; j++) store_w8(out_s + i * (SCHNORR_S_WORDS * 4) + j * 32, s + 8 * j);
-    ok[i] = good ? 1 : 0;
+      for (int j = 0; j < SCHNORR_S_WORDS / 8; j++) store_w8(out_s + i * (SCHNORR_S_WORDS * 4) + j * 32, s + 8 * j);
+      ok[i] = good ? 1 : 0;
+    }
   }
 }
 
@@ -627,8 +690,8 @@ const char* bjj_last_error(void) { return g_err.c_str(); }
 int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   if (!out_ctx) return set_err(BJJ_E_INVALID, "bjj_init: out_ctx is NULL");
   *out_ctx = nullptr;
-  int W = window_bits == 0 ? BJJ_DEFAULT_WINDOW_BITS : window_bits;
-  if (W < 4 || W > 26) return set_err(BJJ_E_INVALID, "bjj_init: window_bits must be 0 or 4..26");
+  if (window_bits != 0 && (window_bits < 4 || window_bits > BJJ_MAX_WINDOW_BITS))
+    return set_err(BJJ_E_INVALID, "bjj_init: window_bits must be 0 (auto) or 4..28");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)
@@ -641,6 +704,16 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   if (!c) return set_err(BJJ_E_NOMEM, "bjj_init: out of host memory");
   c->device = device;
   c->cus = prop.multiProcessorCount;
+  int W = window_bits;
+  if (W == 0) {  // auto: widest table that leaves 40 % of the free memory to the caller (a second context gets 26 bits)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    W = kAutoWindowBits[sizeof(kAutoWindowBits) / sizeof(int) - 1];
+    for (int cand : kAutoWindowBits) {
+      const size_t need = fixed_stride(cand) * (size_t)fixed_nwin(cand) * NIELS_WORDS * sizeof(u32);
+      if (need <= free_b / 5 * 3) { W = cand; break; }
+    }
+  }
   c->W = W;
   c->nwin = fixed_nwin(W);
   c->occ_fixed = occupancy_of(bjj_k_mul_fixed_base, BJJ_EPI_BLOCK);
@@ -654,9 +727,20 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->occ_sign_schnorr = occupancy_of(bjj_k_sign_schnorr, BJJ_BLOCK);
   hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (se != hipSuccess) { delete c; return set_err(BJJ_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
-  const size_t entries = fixed_stride(W) * (size_t)c->nwin;
-  c->table_bytes = entries * NIELS_WORDS * sizeof(u32);
-  se = hipMalloc((void**)&c->table, c->table_bytes);
+  size_t entries = 0;
+  for (;;) {
+    entries = fixed_stride(c->W) * (size_t)c->nwin;
+    c->table_bytes = entries * NIELS_WORDS * sizeof(u32);
+    se = hipMalloc((void**)&c->table, c->table_bytes);
+    if (se == hipSuccess || window_bits != 0) break;
+    (void)hipGetLastError();   // auto mode: the free-memory estimate was too optimistic, take the next narrower table
+    int next = 0;
+    for (int cand : kAutoWindowBits) if (cand < c->W) { next = cand; break; }
+    if (!next) break;
+    c->W = W = next;
+    c->nwin = fixed_nwin(W);
+    c->table = nullptr;
+  }
   if (se == hipSuccess) se = hipMalloc((void**)&c->bases, (size_t)c->nwin * NIELS_WORDS * sizeof(u32));
   if (se != hipSuccess) {
     if (c->table) hipFree(c->table);

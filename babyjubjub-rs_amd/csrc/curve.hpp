@@ -169,7 +169,7 @@ BJJ_HD Fr plain_mod_l(const Fr& v, const Consts& K) {
   s = fr_cond_sub_kr(s, K.L.v);
   return s;
 }
-// W-bit window j of a 256-bit little-endian integer (W <= 25); bits past 255 read as 0
+// W-bit window j of a 256-bit little-endian integer (W <= 32); bits past 255 read as 0
 BJJ_HD u32 scalar_window(const u32 w[8], int j, int W) {
   const int bit = j * W, wi = bit >> 5, sh = bit & 31;
   if (wi >= 8) return 0;

@@ -102,10 +102,12 @@ BJJ_HD void scalar_key_words(const u32 key[8], u32 sk[8], u32 pruned[8], u32 hi[
 }
 
 // PrivateKey::sign (src/lib.rs:308-342).  Returns false where the reference returns Err
-// (msg > Q, :309-311).  R comes out as canonical words, s as a canonical integer mod l.
-BJJ_HD bool sign_item(const u32 key[8], const u32 msg[8], const u32* fb_table, int W, int nwin, u32 out_rx[8],
+// (msg > Q, :309-311; the outputs are then meaningless -- straight-line like verify_fast_t, so that the
+// whole wave reaches the fixed-base gathers).  R comes out as canonical words, s as a canonical integer mod l.
+template <class G>
+BJJ_HD bool sign_item(const u32 key[8], const u32 msg[8], const G& fb_table, int W, int nwin, u32 out_rx[8],
                       u32 out_ry[8], u32 out_s[8], const Consts& K) {
-  if (words_gt_modulus(msg)) return false;
+  const bool good = !words_gt_modulus(msg);
   u32 sk[8], pruned[8], buf[16], dig[16];
   scalar_key_words(key, sk, pruned, buf);                        // :316 (h), buf[0..8) = h[32..64]
 #pragma unroll
@@ -131,7 +133,11 @@ BJJ_HD bool sign_item(const u32 key[8], const u32 msg[8], const u32* fb_table, i
   Fr s = fl_canon4(fr_add(fl_mul(hm_plain, t, K), r), K);
   fr_from_mont_words(h[0], out_rx); fr_from_mont_words(h[1], out_ry);
   fr_to_words(s, out_s);
-  return true;
+  return good;
+}
+BJJ_HD bool sign_item(const u32 key[8], const u32 msg[8], const u32* fb_table, int W, int nwin, u32 out_rx[8],
+                      u32 out_ry[8], u32 out_s[8], const Consts& K) {
+  return sign_item(key, msg, GatherPerLane{fb_table}, W, nwin, out_rx, out_ry, out_s, K);
 }
 
 // PrivateKey::sign_schnorr (src/lib.rs:344-361) with the 1024-bit nonce k supplied by the caller (the
@@ -141,9 +147,10 @@ BJJ_HD bool sign_item(const u32 key[8], const u32 msg[8], const u32* fb_table, i
 // Returns false where the reference returns Err (msg > Q, :365-367).
 constexpr int SCHNORR_K_WORDS = 32;   // 1024-bit nonce
 constexpr int SCHNORR_S_WORDS = 40;   // 160-byte record of s
-BJJ_HD bool sign_schnorr_item(const u32 key[8], const u32 msg[8], const u32 k[SCHNORR_K_WORDS], const u32* fb_table, int W,
+template <class G>
+BJJ_HD bool sign_schnorr_item(const u32 key[8], const u32 msg[8], const u32 k[SCHNORR_K_WORDS], const G& fb_table, int W,
                               int nwin, u32 out_rx[8], u32 out_ry[8], u32 out_s[SCHNORR_S_WORDS], const Consts& K) {
-  if (words_gt_modulus(msg)) return false;
+  const bool good = !words_gt_modulus(msg);                      // straight-line: see sign_item
   u32 sk[8], pruned[8], hi[8];
   scalar_key_words(key, sk, pruned, hi);                         // :358 (and :354 through public())
   // k mod l for the fixed-base engine (B8 has order l):  k = X0 + 2^261 X1 + 2^522 X2 + 2^783 X3
@@ -184,7 +191,11 @@ BJJ_HD bool sign_schnorr_item(const u32 key[8], const u32 msg[8], const u32 k[SC
     acc = (acc >> 32) + carry;
   }
   fr_from_mont_words(h[2], out_rx); fr_from_mont_words(h[3], out_ry);
-  return true;
+  return good;
+}
+BJJ_HD bool sign_schnorr_item(const u32 key[8], const u32 msg[8], const u32 k[SCHNORR_K_WORDS], const u32* fb_table, int W,
+                              int nwin, u32 out_rx[8], u32 out_ry[8], u32 out_s[SCHNORR_S_WORDS], const Consts& K) {
+  return sign_schnorr_item(key, msg, k, GatherPerLane{fb_table}, W, nwin, out_rx, out_ry, out_s, K);
 }
 
 }  // namespace bjj

@@ -54,7 +54,7 @@ def test_init_argument_checks():
     assert lib.bjj_init(0, 0, None) == _lib.BJJ_E_INVALID
     h = ctypes.c_void_p()
     assert lib.bjj_init(0, 3, ctypes.byref(h)) == _lib.BJJ_E_INVALID  # window_bits out of range
-    assert lib.bjj_init(0, 27, ctypes.byref(h)) == _lib.BJJ_E_INVALID
+    assert lib.bjj_init(0, 29, ctypes.byref(h)) == _lib.BJJ_E_INVALID
 
 
 def test_marshalling_helpers():
