@@ -83,8 +83,9 @@ const char* bjj_last_error(void);
  * window table of B8 multiples (built on the GPU).  `window_bits` selects the
  * fixed-base window width W: scalars are reduced mod l and recoded into
  * ceil(252/W) signed digits, the table holds (2^(W-1) + 1) entries of 128 bytes per
- * window, resident in HBM (W = 16: 67 MB, 21: 1.6 GB, 23: 5.9 GB, 26: 43 GB).
- * 0 picks the default. Valid: 4..26. */
+ * window, resident in HBM (W = 16: 67 MB, 21: 1.6 GB, 23: 5.9 GB, 26: 43 GB, 28: 155 GB).
+ * 0 = auto: the widest of 28 / 26 / 23 / 21 / 16 whose table fits in 60 % of the device's free
+ * memory (155 GB on an otherwise empty MI355X; bjj_get_info reports the choice). Valid: 0, 4..28. */
 int bjj_init(int device, int window_bits, bjj_ctx** out_ctx);
 void bjj_free(bjj_ctx* ctx);
 /* Blocks until everything enqueued on the context's stream has finished. */
