@@ -718,7 +718,7 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* 
   need_exact = !msg_gt && !(ref_on_curve(rx, ry, K) && ref_on_curve(ax, ay, K));
   if (SCHNORR) { h[0] = ax; h[1] = ay; h[2] = rx; h[3] = ry; }  // :369
   else         { h[0] = rx; h[1] = ry; h[2] = ax; h[3] = ay; }  // :400
-  Fr hm = poseidon5(h, K);                                      // :400-404
+  Fr hm = poseidon5_t<true>(h, K);                              // :400-404
   Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // canonical integer, :406
   u32 sw[8];
   load_w8(in.s, sw);

@@ -39,6 +39,7 @@ struct Consts {
   Fr PSP[660];      // per partial round: m00, v[5], what[5]
   Fr PAL[25];       // 5x5 block applied after the last partial round
   Fr PM[36];        // MDS, row-major
+  Fr PCAB[30];      // per pair of partial rounds (2p, 2p+1): sum_j v_b[j] * what_a[j]
   // Pohlig-Hellman tables of the square root (gen_tables.py): digit stripping / half-exponent factors / hash
   Fr TSN[384];
   Fr TSH[448];

@@ -200,6 +200,32 @@ def poseidon_sparse(CF, K, S, AL, M, inputs):
     return st[0]
 
 
+def poseidon_pair_constants(S):
+    """Partial rounds taken in PAIRS (a, b) = (2p, 2p+1): round b's dot product sees the elements 1..5 as they were
+    BEFORE round a's update, plus one extra term  cab * x0a  with  cab = sum_j v_b[j] * what_a[j]; the elements are then
+    updated once per pair by  st_j += what_a[j] x0a + what_b[j] x0b  (one reduction instead of two)."""
+    return [sum(S[2 * p + 1][1 + j] * S[2 * p][T + j] for j in range(T - 1)) % Q for p in range(RP // 2)]
+
+
+def poseidon_sparse_paired(CF, K, S, AL, CAB, M, inputs):
+    st = [0] + list(inputs)
+    for r in range(RF // 2):
+        st = [pow((st[j] + CF[r * T + j]) % Q, 5, Q) for j in range(T)]
+        st = mat_vec(M, st)
+    for p in range(RP // 2):
+        sa, sb = S[2 * p], S[2 * p + 1]
+        x0a = pow((st[0] + K[2 * p]) % Q, 5, Q)
+        u0a = (sa[0] * x0a + sum(sa[1 + j] * st[1 + j] for j in range(T - 1))) % Q
+        x0b = pow((u0a + K[2 * p + 1]) % Q, 5, Q)
+        u0b = (sb[0] * x0b + CAB[p] * x0a + sum(sb[1 + j] * st[1 + j] for j in range(T - 1))) % Q
+        st = [u0b] + [(sa[T + j] * x0a + sb[T + j] * x0b + st[1 + j]) % Q for j in range(T - 1)]
+    st = [st[0]] + [sum(AL[i * (T - 1) + j] * st[1 + j] for j in range(T - 1)) % Q for i in range(T - 1)]
+    for r in range(RF // 2):
+        st = [pow((st[j] + CF[(RF // 2 + r) * T + j]) % Q, 5, Q) for j in range(T)]
+        st = mat_vec(M, st)
+    return st[0]
+
+
 # ---------------------------------------------------------------- emit helpers
 def limbs32(v):
     """9 x 29-bit limbs (fr.hpp N-form); the top limb takes whatever is left (< 2^26)."""
@@ -293,6 +319,10 @@ def main():
     for _ in range(6):
         ins = [rnd.randrange(Q) for _ in range(5)]
         assert poseidon_sparse(CF, KP, SP, AL, M, ins) == poseidon_plain(C, M, ins), "sparse Poseidon is not equivalent"
+    CAB = poseidon_pair_constants(SP)
+    for _ in range(6):
+        ins = [rnd.randrange(Q) for _ in range(5)]
+        assert poseidon_sparse_paired(CF, KP, SP, AL, CAB, M, ins) == poseidon_plain(C, M, ins), "paired form is not equivalent"
     o.append("#define BJJ_K_POSEIDON_C { /* plain form, 68 x 6: kept for tests / documentation */ \\")
     for v in C:
         o.append("  %s, \\" % limbs32(mont(v)))
@@ -303,6 +333,10 @@ def main():
     o.append("}")
     o.append("#define BJJ_K_POSEIDON_KP { /* scalar constant of each partial round */ \\")
     for v in KP:
+        o.append("  %s, \\" % limbs32(mont(v)))
+    o.append("}")
+    o.append("#define BJJ_K_POSEIDON_CAB { /* per PAIR of partial rounds (2p, 2p+1): sum_j v_b[j] what_a[j] */ \\")
+    for v in CAB:
         o.append("  %s, \\" % limbs32(mont(v)))
     o.append("}")
     o.append("#define BJJ_K_POSEIDON_SP { /* per partial round: m00, v[5], what[5] */ \\")

@@ -126,7 +126,7 @@ BJJ_HD bool sign_item(const u32 key[8], const u32 msg[8], const G& fb_table, int
   h[0] = fr_mul(fr_mul(Rp.X, zr), K.FINV); h[1] = fr_mul(Rp.Y, zr);
   h[2] = fr_mul(fr_mul(Ap.X, za), K.FINV); h[3] = fr_mul(Ap.Y, za);
   h[4] = fr_to_mont_words(msg);                                  // :321
-  Fr hm = poseidon5(h, K);                                       // :332-333
+  Fr hm = poseidon5(h, K);                                       // :332-333 (partial rounds one at a time: faster here, A/B'd)
   Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));            // :336
   // s = r + hm * (scalar_key << 3) mod l   (:335-339);  scalar_key << 3 == pruned
   Fr t = fl_mul(fr_from_words(pruned), K.L_R2, K);               // pruned * 2^261

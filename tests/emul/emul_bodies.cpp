@@ -12,7 +12,7 @@ using namespace bjj;
 static const Consts K = {
     BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_FINV, BJJ_K_L_R1, BJJ_K_L_R2, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y, BJJ_K_TS_G, BJJ_K_HALFQ,
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
-    BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M,
+    BJJ_K_POSEIDON_CF, BJJ_K_POSEIDON_KP, BJJ_K_POSEIDON_SP, BJJ_K_POSEIDON_AL, BJJ_K_POSEIDON_M, BJJ_K_POSEIDON_CAB,
     BJJ_K_TS_NEG, BJJ_K_TS_HALF, BJJ_K_TS_HASH};
 static std::vector<u32> g_table, g_bases; static int g_W = 0, g_nwin = 0;
 static u32* aligned16(std::vector<u32>& v) { return (u32*)(((uintptr_t)v.data() + 15) & ~(uintptr_t)15); }
