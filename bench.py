@@ -43,8 +43,12 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for fixed_base, 20 otherwise)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 50 for fixed_base, 3 otherwise)")
+    ap.add_argument("--warmup-seconds", type=float, default=1.0,
+                    help="after the W warm-up steps keep launching (untimed) until this much time has passed, so that the "
+                         "timed region runs at the sustained clocks: a 0.6 ms kernel is otherwise timed during the DVFS ramp "
+                         "(profiles/r01j_bench_warmup_effect.txt)")
     ap.add_argument("--workload", default="fixed_base", choices=sorted(ALGO_BYTES))
     ap.add_argument("--batch", type=int, default=1 << 20, help="items per GPU per step")
     ap.add_argument("--window-bits", type=int, default=0)
@@ -161,12 +165,18 @@ class Workload:
         return ok_mask and bool((got[idx] == orc.verify(h["pk"][idx], h["r"][idx], h["s"][idx], h["msg"][idx])).all())
 
 
-def timed_steps(wl, steps, warmup, world):
-    """W untimed + K timed launches; returns (wall seconds for K steps, mean kernel ms from HIP events)."""
+def timed_steps(wl, steps, warmup, world, warm_s=0.0):
+    """W untimed + K timed launches; returns (wall seconds for K steps, mean kernel ms from HIP events).
+    warm_s: extra untimed launches until that many seconds have passed (clock warm-up, see --warmup-seconds)."""
     st = wl.stream
+    t_w = time.perf_counter()
     for _ in range(warmup):
         wl.launch()
     st.synchronize()
+    while time.perf_counter() - t_w < warm_s:
+        for _ in range(8):
+            wl.launch()
+        st.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     if world > 1:
         dist.barrier()
@@ -259,6 +269,10 @@ VALU_PEAK_GINST = 1024 * 2.4 / 4.54
 
 def main():
     args = parse()
+    if args.steps is None:
+        args.steps = 200 if args.workload == "fixed_base" else 20
+    if args.warmup is None:
+        args.warmup = 50 if args.workload == "fixed_base" else 3
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -326,7 +340,7 @@ def main():
         kernel_ms = None
         extra["mode"] = "rank0-resident scatter/kernel/gather (BASELINE cfg 5 shape)"
     else:
-        dt, kernel_ms = timed_steps(wl, args.steps, args.warmup, world)
+        dt, kernel_ms = timed_steps(wl, args.steps, args.warmup, world, args.warmup_seconds)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -356,6 +370,7 @@ def main():
                        "batch_per_gpu": n, "global_batch": n * world, "window_bits": info.window_bits,
                        "fixed_base_table_mb": info.table_bytes / 1e6,
                        "limbs": "9 x 29-bit, 64-bit column accumulators (v_mad_u64_u32)",
+                       "warmup_seconds": args.warmup_seconds,
                        "parallelism": "independent shards, one process per GPU, no data-path collective"},
         }
         result.update(extra)
@@ -392,7 +407,7 @@ def main():
                 if k2 == kind:
                     continue
                 w2 = Workload(ctx, k2, n2, rank * n2, dev, stream)
-                d2, km2 = timed_steps(w2, s2, 1, 1)
+                d2, km2 = timed_steps(w2, s2, 1, 1, 0.5)
                 also[k2] = {"value_one_gpu": n2 * s2 / d2, "unit": UNITS[k2], "kernel_ms_avg": km2, "batch": n2,
                             "parity_sample_ok": w2.check_sample(orc, 128)}
                 del w2

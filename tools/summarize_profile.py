@@ -10,7 +10,7 @@ KERNEL = {"fixed_base": "bjj_k_mul_fixed_base", "var_base": "bjj_k_mul_var_base"
           "poseidon5": "bjj_k_poseidon5"}[wl]
 out = ["# rocprofv3 summary — %s, workload %s" % (tag, wl), "",
        "Command (see tools/profile_r.sh): `rocprofv3 --output-format csv --kernel-trace --stats -- python3 bench.py "
-       "--workload %s --steps 10 --warmup 2 --no-cpu-baseline --no-also`; counters in separate `--pmc` passes." % wl, ""]
+       "--workload %s --no-cpu-baseline --no-also` (default steps / warm-up, as the bench line); counters in separate `--pmc` passes." % wl, ""]
 stats = os.path.join(src, "trace_%s" % wl, "trace_kernel_stats.csv")
 out += ["## kernel stats (`--kernel-trace --stats`)", "", "```"] + open(stats).read().strip().splitlines() + ["```", ""]
 avg_ns = None
