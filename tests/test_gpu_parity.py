@@ -266,6 +266,41 @@ def test_independent_contexts_on_concurrent_threads(oracle):
     assert errors == []
 
 
+def test_automatic_window_width_and_second_context(gpu_ctx, oracle):
+    """window_bits = 0 picks the widest table that fits in 60 % of the free device memory: the session's context got
+    28 bits (154.6 GB) on an empty MI355X, a second automatic context next to it must settle for a narrower table
+    (never fail), verify its own table, and agree bit for bit -- also through the cooperative gathers of the verify and
+    sign kernels, with batch sizes that leave partially filled waves."""
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload
+    first = gpu_ctx.info()
+    assert first.window_bits in (28, 26, 23, 21, 16) and first.n_windows == -(-252 // first.window_bits)
+    ctx = bjj.Context(0, 0)
+    try:
+        info = ctx.info()
+        assert info.window_bits in (26, 23, 21, 16) or first.window_bits < 28
+        assert info.table_bytes == info.n_windows * ((1 << (info.window_bits - 1)) + 1) * 128
+        assert ctx.check_table() == 0
+        for n in (1, 63, 65, 1000):
+            sc = workload.random_u256(workload.SEED_SCALARS, n, offset=900 + n)
+            want = oracle.mul_fixed_base(sc)
+            assert (ctx.mul_fixed_base(sc) == want).all() and (gpu_ctx.mul_fixed_base(sc) == want).all()
+        A, R, S, msg = make_signatures(oracle.mul_fixed_base, oracle.poseidon5, 193)
+        S[5, 0] ^= 1
+        msg[7] = 0xff                                   # msg > Q in the middle of a wave: verdict 0, neighbours unaffected
+        want = oracle.verify(A, R, S, msg)
+        assert (ctx.eddsa_verify(A, R, S, msg) == want).all() and (gpu_ctx.eddsa_verify(A, R, S, msg) == want).all()
+        keys = workload.random_u256(workload.SEED_KEYS, 67, offset=3)
+        m = workload.random_u256(workload.SEED_MSGS, 67, offset=3, top_bits_cleared=3)
+        m[11] = 0xff                                    # Err item inside a wave of the sign kernel
+        r0, s0, ok0 = oracle.sign(keys, m)
+        for c in (ctx, gpu_ctx):
+            r1, s1, ok1 = c.sign(keys, m)
+            assert (ok1 == ok0).all() and (r1 == r0).all() and (s1 == s0).all()
+    finally:
+        ctx.close()
+
+
 # ---------------------------------------------------------------- device-pointer API
 def test_device_pointer_api_and_streams(gpu_ctx, oracle):
     import torch
