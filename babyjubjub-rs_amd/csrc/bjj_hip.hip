@@ -15,8 +15,8 @@
 //                                 wire format                    src/lib.rs:166-224, 260-268
 //   bjj_k_scalar_keys / bjj_k_sign / bjj_k_sign_schnorr  signer side   src/lib.rs:284-361
 // K5 (batched affine conversion) is the epilogue of K1/K2: Montgomery's trick per lane over its
-// items, then across the 512-lane workgroup through two LDS product scans, so that ONE
-// (binary-GCD) inversion serves blockDim * items_per_lane points.
+// items, then across the 512-lane workgroup (shuffle scans inside groups of 8 lanes, one wave inverting the
+// 64 group products with one binary-GCD inversion per lane): block_invert below.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
