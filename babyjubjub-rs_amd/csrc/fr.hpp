@@ -385,7 +385,14 @@ BJJ_HD_NOINLINE Fr fr_inv_fermat(const Fr& a) {
 // the point is LATENCY -- the workgroup-wide inversion of the affine epilogue is a serial
 // section during which the other waves of the workgroup wait.
 // ---------------------------------------------------------------------------------------
+// (u, v) are kept as SIGNED numbers -- limbs 0..7 in [0, 2^29), limb 8 a signed 32-bit top -- and are not reduced
+// between rounds: the transition matrices satisfy |f| + |g| <= 2^29 per row, so one round grows max(|u|, |v|) by at
+// most r (the q*r term), 18 rounds keep them below 19 r, and a single normalisation at the end replaces the three
+// conditional subtractions per operand and round of the straightforward form.  The matrix entries fit 32 bits.
 BJJ_HD_NOINLINE Fr fr_inv_gcd(const Fr& x) {
+  constexpr u32 R32[NL] = {0x20u, 0x01f593f0u, 0x0b848a1fu, 0x1a121e6eu, 0x10ba5067u, 0x1b681815u, 0x14dc2822u, 0x0b84c680u, 0x060c89ceu};
+  constexpr u32 R16[NL] = {0x10u, 0x10fac9f8u, 0x05c2450fu, 0x1d090f37u, 0x185d2833u, 0x0db40c0au, 0x0a6e1411u, 0x05c26340u, 0x030644e7u};
+  constexpr u32 R8[NL] = {0x8u, 0x187d64fcu, 0x12e12287u, 0x1e84879bu, 0x0c2e9419u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
   constexpr u32 R4[NL] = {0x4u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
   constexpr u32 R2c[NL] = {0x2u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u, 0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
   constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
@@ -418,17 +425,17 @@ BJJ_HD_NOINLINE Fr fr_inv_gcd(const Fr& x) {
       xa = ((u64)a.v[2] << 58) | ((u64)a.v[1] << 29) | a.v[0];
       xb = ((u64)b.v[2] << 58) | ((u64)b.v[1] << 29) | b.v[0];
     }
-    // ---- 29 binary-GCD steps on the approximations, recording the transition matrix
-    int64_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+    // ---- 29 binary-GCD steps on the approximations, recording the transition matrix (|entries| <= 2^29)
+    int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
 #pragma unroll 1
     for (int i = 0; i < 29; i++) {
       const bool odd = (xa & 1) != 0;
       const bool swp = odd && (xa < xb);
       const u64 ta = swp ? xb : xa, tb = swp ? xa : xb;
-      const int64_t tf0 = swp ? f1 : f0, tf1 = swp ? f0 : f1, tg0 = swp ? g1 : g0, tg1 = swp ? g0 : g1;
+      const int32_t tf0 = swp ? f1 : f0, tf1 = swp ? f0 : f1, tg0 = swp ? g1 : g0, tg1 = swp ? g0 : g1;
       xa = (odd ? ta - tb : ta) >> 1; xb = tb;
       f0 = odd ? tf0 - tf1 : tf0; g0 = odd ? tg0 - tg1 : tg0;
-      f1 = tf1 << 1; g1 = tg1 << 1;
+      f1 = tf1 * 2; g1 = tg1 * 2;
     }
     // ---- (a, b) <- (a f0 + b g0, a f1 + b g1) / 2^29   (exact), then make both non-negative
     Fr na, nb;
@@ -454,28 +461,36 @@ BJJ_HD_NOINLINE Fr fr_inv_gcd(const Fr& x) {
     }
     if (nega) { f0 = -f0; g0 = -g0; }
     if (negb) { f1 = -f1; g1 = -g1; }
-    // ---- (u, v) <- (u f0 + v g0, u f1 + v g1) / 2^29 mod r, back into [0, r)
-    const u32 lu = (u32)((int64_t)u.v[0] * f0 + (int64_t)v.v[0] * g0) & MASK29;
-    const u32 lv = (u32)((int64_t)u.v[0] * f1 + (int64_t)v.v[0] * g1) & MASK29;
+    // ---- (u, v) <- (u f0 + v g0 + qu r, u f1 + v g1 + qv r) / 2^29   (exact; signed, unreduced)
+    const u32 lu = (u.v[0] * (u32)f0 + v.v[0] * (u32)g0) & MASK29;
+    const u32 lv = (u.v[0] * (u32)f1 + v.v[0] * (u32)g1) & MASK29;
     const u32 qu = (lu * BJJ_NINV29) & MASK29, qv = (lv * BJJ_NINV29) & MASK29;
     Fr nu, nv;
     int64_t cu = 0, cv = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-      cu += (int64_t)u.v[i] * f0 + (int64_t)v.v[i] * g0 + (int64_t)((u64)qu * fr_modlimb(i));
-      cv += (int64_t)u.v[i] * f1 + (int64_t)v.v[i] * g1 + (int64_t)((u64)qv * fr_modlimb(i));
-      if (i > 0) {  // + 2r (limb i-1 of 2r) keeps the running value non-negative: result in (0, 5r)
-        cu += R2c[i - 1]; cv += R2c[i - 1];
-        nu.v[i - 1] = (u32)cu & MASK29; nv.v[i - 1] = (u32)cv & MASK29;
-      }
+      const int64_t ui = (i < NL - 1) ? (int64_t)u.v[i] : (int64_t)(int32_t)u.v[i];   // limb 8 is signed
+      const int64_t vi = (i < NL - 1) ? (int64_t)v.v[i] : (int64_t)(int32_t)v.v[i];
+      cu += ui * f0 + vi * g0 + (int64_t)((u64)qu * fr_modlimb(i));
+      cv += ui * f1 + vi * g1 + (int64_t)((u64)qv * fr_modlimb(i));
+      if (i > 0) { nu.v[i - 1] = (u32)cu & MASK29; nv.v[i - 1] = (u32)cv & MASK29; }
       cu >>= 29; cv >>= 29;
     }
-    cu += R2c[NL - 1]; cv += R2c[NL - 1];
-    nu.v[NL - 1] = (u32)cu; nv.v[NL - 1] = (u32)cv;
-    nu = fr_cond_sub_kr(nu, R4); nu = fr_cond_sub_kr(nu, R2c); u = fr_cond_sub_kr(nu, R1);
-    nv = fr_cond_sub_kr(nv, R4); nv = fr_cond_sub_kr(nv, R2c); v = fr_cond_sub_kr(nv, R1);
+    nu.v[NL - 1] = (u32)(int32_t)cu; nv.v[NL - 1] = (u32)(int32_t)cv;
+    BJJ_ASSERT(cu > -(1 << 28) && cu < (1 << 28) && cv > -(1 << 28) && cv < (1 << 28));
+    u = nu; v = nv;
   }
-  return v;
+  // b == 1 now (or a == b... for x == 0: v == 0): v == R^2 / y (mod r) with |v| < 19 r.  Add 32 r, then reduce.
+  Fr t;
+  {
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) { const u32 w = v.v[i] + R32[i] + c; t.v[i] = w & MASK29; c = w >> 29; }
+    t.v[NL - 1] = (u32)((int32_t)v.v[NL - 1] + (int32_t)R32[NL - 1] + (int32_t)c);   // > 0, < 2^28
+  }
+  t = fr_cond_sub_kr(t, R32); t = fr_cond_sub_kr(t, R16); t = fr_cond_sub_kr(t, R8);
+  t = fr_cond_sub_kr(t, R4); t = fr_cond_sub_kr(t, R2c); t = fr_cond_sub_kr(t, R1);
+  return t;
 }
 
 // 1/x in Montgomery form (0 -> 0): the low-latency binary-GCD inversion.
