@@ -57,37 +57,40 @@ __constant__ Consts c_K = {
 // whose 64 lanes invert one group product each (binary GCD), and every thread
 // finishes with 1/x = (1/group product) * (product of the lanes before it) * (after it).
 // ---------------------------------------------------------------------------
-#define BJJ_EPI_GROUP (BJJ_EPI_BLOCK / 64)
+template <int GROUP>
 __device__ __forceinline__ Fr fr_shfl_up(const Fr& f, int d) {
   Fr r;
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = __shfl_up(f.v[i], d, BJJ_EPI_GROUP);
+  for (int i = 0; i < NL; i++) r.v[i] = __shfl_up(f.v[i], d, GROUP);
   return r;
 }
+template <int GROUP>
 __device__ __forceinline__ Fr fr_shfl_down(const Fr& f, int d) {
   Fr r;
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = __shfl_down(f.v[i], d, BJJ_EPI_GROUP);
+  for (int i = 0; i < NL; i++) r.v[i] = __shfl_down(f.v[i], d, GROUP);
   return r;
 }
+template <int BLOCK>
 __device__ Fr block_invert(const Fr& x, u32* lds /* NL * 64 words */) {
-  const int t = threadIdx.x, gl = t & (BJJ_EPI_GROUP - 1), grp = t / BJJ_EPI_GROUP;
+  constexpr int GROUP = BLOCK / 64;
+  const int t = threadIdx.x, gl = t & (GROUP - 1), grp = t / GROUP;
   Fr pre = x, suf = x;
 #pragma unroll 1
-  for (int d = 1; d < BJJ_EPI_GROUP; d <<= 1) {  // inclusive prefix / suffix products inside the group
-    Fr yp = fr_shfl_up(pre, d), ys = fr_shfl_down(suf, d);
+  for (int d = 1; d < GROUP; d <<= 1) {  // inclusive prefix / suffix products inside the group
+    Fr yp = fr_shfl_up<GROUP>(pre, d), ys = fr_shfl_down<GROUP>(suf, d);
     pre = fr_mul(pre, fr_select(gl >= d, yp, fr_one()));
-    suf = fr_mul(suf, fr_select(gl + d < BJJ_EPI_GROUP, ys, fr_one()));
+    suf = fr_mul(suf, fr_select(gl + d < GROUP, ys, fr_one()));
   }
-  Fr epre = fr_select(gl > 0, fr_shfl_up(pre, 1), fr_one());                    // exclusive versions
-  Fr esuf = fr_select(gl + 1 < BJJ_EPI_GROUP, fr_shfl_down(suf, 1), fr_one());
-  if (gl == BJJ_EPI_GROUP - 1) {
+  Fr epre = fr_select(gl > 0, fr_shfl_up<GROUP>(pre, 1), fr_one());                    // exclusive versions
+  Fr esuf = fr_select(gl + 1 < GROUP, fr_shfl_down<GROUP>(suf, 1), fr_one());
+  if (gl == GROUP - 1) {
 #pragma unroll
     for (int i = 0; i < NL; i++) lds[i * 64 + grp] = pre.v[i];  // limb-major: conflict-free
   }
   __syncthreads();
   // the inverting wave rotates with the workgroup index so that co-resident workgroups do not queue on one SIMD
-  if ((t >> 6) == (int)((blockIdx.x + (blockIdx.x >> 8)) % (BJJ_EPI_BLOCK / 64))) {
+  if ((t >> 6) == (int)((blockIdx.x + (blockIdx.x >> 8)) % (BLOCK / 64))) {
     const int l = t & 63;
     Fr tot;
 #pragma unroll
@@ -134,7 +137,7 @@ __device__ __forceinline__ void epilogue_finish(Fr& inv, uint8_t* out_item, cons
 }
 __device__ __forceinline__ void epilogue_run(Fr run, size_t n, size_t tid, size_t nthreads, uint8_t* out, u32* scratch,
                                              u32* lds) {
-  Fr inv = fr_mul(block_invert(run, lds), fr_one_plain());  // out of Montgomery form once per lane
+  Fr inv = fr_mul(block_invert<BJJ_EPI_BLOCK>(run, lds), fr_one_plain());  // out of Montgomery form once per lane
   if (tid >= n) return;
   size_t cnt = (n - tid + nthreads - 1) / nthreads;
 #pragma unroll 1
