@@ -72,6 +72,9 @@ BJJ_HD void store_pniels(u32* p, const PNiels& n) {
 //   n is first reduced mod l (B8 has order l, so this is exact) and recoded into nwin = ceil(252 / W)
 //   signed digits d_j in [-2^(W-1), 2^(W-1)];  table[j][k] = Niels( k * 2^(W j) * B8 ), k = 0 .. 2^(W-1)
 //   (k = 0 is the identity entry), -k*P by swapping y-x / y+x and negating 2D'xy.
+//   WINDOW 0 stores 2x'y in place of 2D'x'y ("T form"): a multiplication from scratch starts by lifting the entry of
+//   window 0 to extended coordinates (2x' : 2y : 2 : 2x'y), which then costs no multiplication at all; the
+//   accumulating form (verify) multiplies that one entry by D' instead.
 // =============================================================================
 BJJ_HD int fixed_nwin(int W) { return (252 + W - 1) / W; }            // l < 2^251: the top digit absorbs the last carry
 BJJ_HD size_t fixed_stride(int W) { return ((size_t)1 << (W - 1)) + 1; }  // entries per window
@@ -132,12 +135,13 @@ struct GatherPerLane {
 
 // acc + sc * B8, sc < l.  The result's T is not computed (callers only compare or convert X, Y, Z).
 template <class G>
-BJJ_HD Ext fixed_base_accumulate(Ext acc, const G& g, int W, int nwin, const u32 sc[8]) {
+BJJ_HD Ext fixed_base_accumulate(Ext acc, const G& g, int W, int nwin, const u32 sc[8], const Consts& K) {
   u32 carry = 0;
   bool neg;
   typename G::Pending p;
   g.issue(fixed_digit_slot(sc, 0, W, carry, neg), p, 0);
   Niels cur = niels_cneg_lazy(g.finish(p, 0), neg);
+  cur.t2d = fr_mul(cur.t2d, K.DP);                                 // window 0 is stored in T form
 #pragma unroll 1
   for (int j = 0; j + 1 < nwin; j++) {
     g.issue(fixed_digit_slot(sc, j + 1, W, carry, neg), p, (j + 1) & 1);  // in flight during this window's 7 multiplications
@@ -147,13 +151,12 @@ BJJ_HD Ext fixed_base_accumulate(Ext acc, const G& g, int W, int nwin, const u32
   }
   return ext_madd<false>(acc, cur);
 }
-BJJ_HD Ext fixed_base_accumulate(Ext acc, const u32* table, int W, int nwin, const u32 sc[8]) {
-  return fixed_base_accumulate(acc, GatherPerLane{table}, W, nwin, sc);
+BJJ_HD Ext fixed_base_accumulate(Ext acc, const u32* table, int W, int nwin, const u32 sc[8], const Consts& K) {
+  return fixed_base_accumulate(acc, GatherPerLane{table}, W, nwin, sc, K);
 }
 
-// n * B8 from scratch (n any 256-bit integer): window 0's entry is lifted directly to extended coordinates
-// (X:Y:Z:T) = (2x' : 2y : 2 : 2x'y), T recovered from the stored 2D'x'y with one
-// multiplication by 1/D', instead of a 7M addition to the identity.
+// n * B8 from scratch (n any 256-bit integer): window 0's entry (T form) is lifted directly to extended coordinates
+// (X:Y:Z:T) = (2x' : 2y : 2 : 2x'y) -- additions and subtractions only -- instead of a 7M addition to the identity.
 template <class G>
 BJJ_HD Ext fixed_base_mul(const G& g, int W, int nwin, const u32 raw[8], const Consts& K) {
   u32 sc[8];
@@ -169,7 +172,7 @@ BJJ_HD Ext fixed_base_mul(const G& g, int W, int nwin, const u32 raw[8], const C
   Ext acc;
   acc.X = fr_reduce_weak(fr_sub(n0.ypx, n0.ymx));  // ext_madd wants coordinates < 2r
   acc.Y = fr_add(n0.ypx, n0.ymx);
-  acc.Z = fr_add(fr_one(), fr_one()); acc.T = fr_mul(n0.t2d, K.DPINV);
+  acc.Z = fr_add(fr_one(), fr_one()); acc.T = fr_add(n0.t2d, fr_zero());   // carry sweep only (T feeds one multiplication)
   BJJ_SCHED_FENCE();
   Niels cur = niels_cneg_lazy(g.finish(p, 1), neg);
 #pragma unroll 1
@@ -247,8 +250,8 @@ BJJ_HD void ref_mul_scalar(const Fr& x, const Fr& y, const u32* sc, int nw, Fr& 
   ox = fr_mul(r.x, zi); oy = fr_mul(r.y, zi);
 }
 
-// fixed-base table entry (j, k) = Niels( k * 2^(W j) * B8 ), fully reduced
-BJJ_HD Niels fixed_table_entry(u32 k, int j, int W, const Consts& K) {
+// fixed-base table entry (j, k) = Niels( k * 2^(W j) * B8 ), fully reduced; tform: third word = 2x'y instead of 2D'x'y
+BJJ_HD Niels fixed_table_entry(u32 k, int j, int W, const Consts& K, bool tform = false) {
   Ext base = ext_from_ref_affine(K.B8X, K.B8Y, K);
   PNiels bn = ext_to_pniels(base, K);
   PNiels idn; idn.ymx = fr_one(); idn.ypx = fr_one(); idn.t2d = fr_zero(); idn.z2 = fr_dbl(fr_one());
@@ -267,7 +270,8 @@ BJJ_HD Niels fixed_table_entry(u32 k, int j, int W, const Consts& K) {
   Fr zi = fr_inv(acc.Z);
   Fr x = fr_mul(acc.X, zi), y = fr_mul(acc.Y, zi);
   Niels n;
-  n.ymx = fr_canon(fr_sub(y, x)); n.ypx = fr_canon(fr_add(y, x)); n.t2d = fr_canon(fr_mul(fr_mul(x, y), K.D2P));
+  n.ymx = fr_canon(fr_sub(y, x)); n.ypx = fr_canon(fr_add(y, x));
+  n.t2d = tform ? fr_canon(fr_dbl(fr_mul(x, y))) : fr_canon(fr_mul(fr_mul(x, y), K.D2P));
   return n;
 }
 
@@ -289,12 +293,14 @@ BJJ_HD Fr load_chain_word(const u32* p) {
   load_w8(p, w);
   return fr_from_words(w);
 }
-BJJ_HD Niels niels_from_affine(const Fr& x, const Fr& y, const Consts& K) {
+BJJ_HD Niels niels_from_affine(const Fr& x, const Fr& y, const Consts& K, bool tform) {
   Niels n;
-  n.ymx = fr_canon(fr_sub(y, x)); n.ypx = fr_canon(fr_add(y, x)); n.t2d = fr_canon(fr_mul(fr_mul(x, y), K.D2P));
+  n.ymx = fr_canon(fr_sub(y, x)); n.ypx = fr_canon(fr_add(y, x));
+  n.t2d = tform ? fr_canon(fr_dbl(fr_mul(x, y))) : fr_canon(fr_mul(fr_mul(x, y), K.D2P));
   return n;
 }
 BJJ_HD void fixed_table_chain(u32* table, const Niels& base, size_t slot0, u32 k0, u32 cnt, int W, const Consts& K) {
+  const bool tform = slot0 < fixed_stride(W);   // window 0
   // k0 * P_j, MSB first; the addition is computed unconditionally and selected (uniform control flow)
   Ext acc = ext_identity();
 #pragma unroll 1
@@ -320,16 +326,16 @@ BJJ_HD void fixed_table_chain(u32* table, const Niels& base, size_t slot0, u32 k
     Fr prev = i > 0 ? load_chain_word(slot - NIELS_WORDS + 24) : fr_one();
     Fr zi = fr_mul(inv, prev);
     inv = fr_mul(inv, Z);
-    store_niels(slot, niels_from_affine(fr_mul(X, zi), fr_mul(Y, zi), K));
+    store_niels(slot, niels_from_affine(fr_mul(X, zi), fr_mul(Y, zi), K, tform));
   }
 }
 // Link check of the finished table (proof by induction that every entry is k * 2^(W j) * B8):
 //   T[j][0] = identity, T[j][1] = P_j, T[j][k] + P_j = T[j][k+1], P_{j+1} = 2 * T[j][2^(W-1)], P_0 = B8,
 //   every entry canonical with 2D'x'y consistent.  Returns the number of violated conditions for slot (j, k).
-BJJ_HD Ext niels_lift(const Niels& n, const Consts& K) {  // (2x' : 2y : 2 : 2x'y)
+BJJ_HD Ext niels_lift(const Niels& n, const Consts& K, bool tform) {  // (2x' : 2y : 2 : 2x'y)
   Ext e;
   e.X = fr_reduce_weak(fr_sub(n.ypx, n.ymx)); e.Y = fr_add(n.ypx, n.ymx);
-  e.Z = fr_add(fr_one(), fr_one()); e.T = fr_mul(n.t2d, K.DPINV);
+  e.Z = fr_add(fr_one(), fr_one()); e.T = tform ? n.t2d : fr_mul(n.t2d, K.DPINV);
   return e;
 }
 BJJ_HD bool ext_equals_niels(const Ext& p, const Niels& n) {  // p == (x', y) of n, projectively
@@ -345,20 +351,22 @@ BJJ_HD int fixed_table_check_slot(const u32* table, const u32* bases, int j, u32
   const size_t stride = fixed_stride(W);
   const Niels e = load_niels(table + ((size_t)j * stride + k) * NIELS_WORDS);
   const Niels base = load_niels(bases + (size_t)j * NIELS_WORDS);
+  const bool tform = j == 0;   // window 0 holds 2x'y in the third word, the bases (and every other window) 2D'x'y
   int bad = 0;
   // canonical limbs and values
   for (int i = 0; i < NL; i++) bad += (e.ymx.v[i] >> 29) != 0 || (e.ypx.v[i] >> 29) != 0 || (e.t2d.v[i] >> 29) != 0;
   bad += !niels_limbs_equal(e, Niels{fr_canon(e.ymx), fr_canon(e.ypx), fr_canon(e.t2d)});
-  // 2 * t2d == D' * (ypx^2 - ymx^2)      (4x'y = (y+x')^2 - (y-x')^2)
-  bad += !fr_eq(fr_mul(fr_sub(fr_sqr(e.ypx), fr_sqr(e.ymx)), K.DP), fr_dbl(e.t2d));
+  // 2 * t2d == D' * (ypx^2 - ymx^2)      (4x'y = (y+x')^2 - (y-x')^2);  T form: without the D'
+  const Fr dsq = fr_sub(fr_sqr(e.ypx), fr_sqr(e.ymx));
+  bad += !fr_eq(tform ? dsq : fr_mul(dsq, K.DP), fr_dbl(e.t2d));
   if (k == 0) bad += !niels_limbs_equal(e, Niels{fr_one(), fr_one(), fr_zero()});
-  if (k == 1) bad += !niels_limbs_equal(e, base);
+  if (k == 1) bad += !niels_limbs_equal(Niels{e.ymx, e.ypx, tform ? fr_canon(fr_mul(e.t2d, K.DP)) : e.t2d}, base);
   if (k + 1 < stride) {
     const Niels nx = load_niels(table + ((size_t)j * stride + k + 1) * NIELS_WORDS);
-    bad += !ext_equals_niels(ext_madd(niels_lift(e, K), base), nx);
+    bad += !ext_equals_niels(ext_madd(niels_lift(e, K, tform), base), nx);
   } else if (j + 1 < nwin) {
     const Niels nb = load_niels(bases + (size_t)(j + 1) * NIELS_WORDS);
-    bad += !ext_equals_niels(ext_dbl<false>(niels_lift(e, K)), nb);
+    bad += !ext_equals_niels(ext_dbl<false>(niels_lift(e, K, tform)), nb);
   }
   if (j == 0 && k == 1) {
     Ext g = ext_from_ref_affine(K.B8X, K.B8Y, K);
@@ -733,7 +741,7 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* 
     Ext q = vb_mul_windowed(vb_tbl, kw, 64);                    // scalar < 2^254
     u32 sl[8];
     scalar_mod_l(sw, sl, K);                                    // B8 has order l
-    q = fixed_base_accumulate(q, fb, W, nwin, sl);              // + s*B8   (:377)
+    q = fixed_base_accumulate(q, fb, W, nwin, sl, K);           // + s*B8   (:377)
     Fr fx = fr_mul(rx, K.F);                                    // compare with R on the a'=-1 curve
     verdict = (fr_eq(q.X, fr_mul(fx, q.Z)) && fr_eq(q.Y, fr_mul(ry, q.Z))) ? 1 : 0;
     return msg_gt ? 2 : verdict;
@@ -760,7 +768,7 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* 
   // (all but ~2e-5 of the pairs); the rest -- e.g. kappa = (l+1)/2 gives u of 250 bits -- take 64 windows
   const int jw = ((ub > vb ? ub : vb) <= 134) ? 34 : 64;
   Ext q = joint_mul_windowed(vb_tbl, tbl2, u, vmag, jw);
-  q = fixed_base_accumulate(q, fb, W, nwin, cw);                // + (v s mod l)*B8
+  q = fixed_base_accumulate(q, fb, W, nwin, cw, K);             // + (v s mod l)*B8
   verdict = (fr_is_zero(q.X) && fr_eq(q.Y, q.Z)) ? 1 : 0;       // projective identity (0 : z : z)
   return msg_gt ? 0 : verdict;
 }

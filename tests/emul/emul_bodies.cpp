@@ -56,7 +56,7 @@ unsigned long long emul_table_selfcheck(int W, unsigned chain, long long corrupt
   unsigned long long mism = 0, bad = 0;
   for (int j = 0; j < nwin; j++)
     for (size_t k = 0; k < stride; k++)
-      mism += !niels_limbs_equal(load_niels(t + ((size_t)j * stride + k) * NIELS_WORDS), fixed_table_entry((u32)k, j, W, K));
+      mism += !niels_limbs_equal(load_niels(t + ((size_t)j * stride + k) * NIELS_WORDS), fixed_table_entry((u32)k, j, W, K, j == 0));
   if (corrupt_slot >= 0) t[(size_t)corrupt_slot * NIELS_WORDS + 11] ^= 4u;
   for (int j = 0; j < nwin; j++)
     for (size_t k = 0; k < stride; k++) bad += fixed_table_check_slot(t, bs, j, (u32)k, W, nwin, K);
