@@ -406,15 +406,24 @@ BJJ_HD Ext var_base_item(const Fr& x, const Fr& y, const u32 sc[8], u32* tbl, co
 // depend on which square root Tonelli-Shanks returns (the sign rule of lib.rs:217-219 picks
 // by the sign bit), so any correct root is bit-identical to the reference.
 // =============================================================================
-// a^((s-1)/2), s = (r-1)/2^28: fixed 225-bit exponent, plain square-and-multiply
+// a^((s-1)/2), s = (r-1)/2^28: fixed 225-bit exponent.  Sliding 3-bit windows over the CONSTANT exponent (program
+// from gen_tables.py: 223 squarings + 51 multiplications by a, a^3, a^5 or a^7, + 4 for the table) instead of plain
+// square-and-multiply (224 + 98).  The schedule is the same for every lane.
 BJJ_HD_NOINLINE Fr fr_pow_ts(const Fr& a) {
-  const u32 E[8] = {0x1f0fac9fu, 0xcdcb848au, 0x419f4243u, 0x0c0ac2e9u, 0xc2822db4u, 0x098d014du, 0x83227397u, 0x00000001u};
-  Fr x = a;  // bit 224
+  constexpr unsigned char PROG[2 * BJJ_TS_POW_STEPS] = BJJ_TS_POW_PROG;
+  const Fr a2 = fr_sqr(a);
+  const Fr p3 = fr_mul(a, a2), p5 = fr_mul(p3, a2), p7 = fr_mul(p5, a2);
+  Fr x = fr_zero();
 #pragma unroll 1
-  for (int bit = 223; bit >= 0; bit--) {
-    x = fr_sqr(x);
-    if ((E[bit >> 5] >> (bit & 31)) & 1) x = fr_mul(x, a);
+  for (int st = 0; st < BJJ_TS_POW_STEPS; st++) {
+    const int nsq = PROG[2 * st], idx = PROG[2 * st + 1];
+    const Fr m = fr_select(idx & 2, fr_select(idx & 1, p7, p5), fr_select(idx & 1, p3, a));
+#pragma unroll 1
+    for (int k = 0; k < nsq; k++) x = fr_sqr(x);
+    x = st == 0 ? m : fr_mul(x, m);
   }
+#pragma unroll 1
+  for (int k = 0; k < BJJ_TS_POW_TAIL; k++) x = fr_sqr(x);
   return x;
 }
 // Square root in F_r (r - 1 = 2^28 s).  With w = a^((s-1)/2): x = a w satisfies x^2 = a b, b = a^s in the

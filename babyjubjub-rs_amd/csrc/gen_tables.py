@@ -267,6 +267,26 @@ def main():
     while pow(n, (Q - 1) // 2, Q) != Q - 1:
         n += 1
     o.append("#define BJJ_K_TS_G     %s  // %d^((r-1)/2^28): order 2^28" % (limbs32(mont(pow(n, ts_s, Q))), n))
+    # a^((s-1)/2): sliding 3-bit windows over the constant exponent, odd powers a, a^3, a^5, a^7.
+    # Program = (squarings, odd value) steps, most significant first; the first step just loads its power.
+    e_bits = bin((ts_s - 1) // 2)[2:]
+    prog, nsq, i = [], 0, 0
+    while i < len(e_bits):
+        if e_bits[i] == "0":
+            nsq += 1; i += 1
+            continue
+        j = min(i + 3, len(e_bits))
+        while e_bits[j - 1] == "0":
+            j -= 1
+        prog.append((0 if not prog else nsq + (j - i), int(e_bits[i:j], 2)))
+        nsq, i = 0, j
+    x = None
+    for sq, val in prog:
+        x = pow(7, val, Q) if x is None else pow(x, 1 << sq, Q) * pow(7, val, Q) % Q
+    assert pow(x, 1 << nsq, Q) == pow(7, (ts_s - 1) // 2, Q)
+    o.append("#define BJJ_TS_POW_STEPS %d" % len(prog))
+    o.append("#define BJJ_TS_POW_TAIL %d  // squarings after the last step" % nsq)
+    o.append("#define BJJ_TS_POW_PROG { " + ",".join("%d,%d" % (sq, (val - 1) // 2) for sq, val in prog) + " }  // (squarings, (odd power - 1) / 2)")
     o.append("#define BJJ_K_HALFQ    %s  // PLAIN (r-1)/2" % limbs32((Q - 1) // 2))
     # Pohlig-Hellman tables for the discrete log in <G> (order 2^28), four 7-bit digits e = sum e_k 2^(7k):
     #   TSN[k][j] = G^(-j 2^(7k))            (k = 0..2)  strips digit k from b
