@@ -23,6 +23,7 @@
 #include <string.h>
 #include <string>
 #include <new>
+#include <thread>
 
 #include "../../include/bjj_hip.h"
 #include "sign.hpp"
@@ -358,7 +359,7 @@ __device__ __forceinline__ void verify_kernel_body(const u32* __restrict__ table
     if (c + lane < nexact) {
       const size_t i = wl[WL_HDR + c + lane];
       VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
-      ok[i] = (uint8_t)verify_exact_t<SCHNORR>(in, c_K);
+      ok[i] = (uint8_t)verify_exact_t<SCHNORR>(in, table, W, nwin, tbl, c_K);
     }
   }
 #pragma unroll 1
@@ -613,6 +614,26 @@ struct PipeSpec {
   uint8_t* out[4];      size_t out_stride[4];
 };
 static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+// Staging copies between the caller's pageable memory and the pinned buffers: one thread moves ~30 GB/s, PCIe 54 GB/s
+// (tools/ubench/pcie_probe.cpp), so copies of 4 MB and more are split over up to four threads.
+static void staged_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
+  const size_t kMin = (size_t)4 << 20;
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t parts = bytes / kMin;
+  if (parts > 4) parts = 4;
+  if (hw && parts > hw) parts = hw;
+  if (parts < 2) { memcpy(dst, src, bytes); return; }
+  const size_t per = (bytes / parts + 63) & ~(size_t)63;
+  std::thread th[3];
+  size_t started = 0;
+  for (size_t i = 1; i < parts; i++) {
+    const size_t lo = i * per, len = (i + 1 == parts) ? bytes - lo : per;
+    try { th[started] = std::thread([=] { memcpy(dst + lo, src + lo, len); }); started++; }
+    catch (...) { memcpy(dst + lo, src + lo, len); }   // no thread available: copy here
+  }
+  memcpy(dst, src, per);
+  for (size_t i = 0; i < started; i++) th[i].join();
+}
 static int ensure_pipe(bjj_ctx* c, size_t bytes) {
   HIPCK(hipSetDevice(c->device));
   if (!c->s_in) {
@@ -650,14 +671,14 @@ static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch
     const int b = (int)(ch & 1);
     const size_t lo = ch * chunk, cnt = (lo + chunk <= n ? chunk : n - lo);
     HIPCK(hipEventSynchronize(c->ev_out[b]));
-    for (int i = 0; i < sp.n_out; i++) memcpy(sp.out[i] + lo * sp.out_stride[i], c->pinned[b] + off_out[i], cnt * sp.out_stride[i]);
+    for (int i = 0; i < sp.n_out; i++) staged_copy(sp.out[i] + lo * sp.out_stride[i], c->pinned[b] + off_out[i], cnt * sp.out_stride[i]);
     return BJJ_OK;
   };
   for (size_t ch = 0; ch < nchunks; ch++) {
     const int b = (int)(ch & 1);
     const size_t lo = ch * chunk, cnt = (lo + chunk <= n ? chunk : n - lo);
     if (ch >= 2) { rc = drain(ch - 2); if (rc) return rc; }     // frees pinned[b] and dstage[b]
-    for (int i = 0; i < sp.n_in; i++) memcpy(c->pinned[b] + off_in[i], sp.in[i] + lo * sp.in_stride[i], cnt * sp.in_stride[i]);
+    for (int i = 0; i < sp.n_in; i++) staged_copy(c->pinned[b] + off_in[i], sp.in[i] + lo * sp.in_stride[i], cnt * sp.in_stride[i]);
     HIPCK(hipMemcpyAsync(c->dstage[b], c->pinned[b], in_bytes, hipMemcpyHostToDevice, c->s_in));
     HIPCK(hipEventRecord(c->ev_in[b], c->s_in));
     HIPCK(hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
