@@ -57,3 +57,29 @@ def to_ints(a):
 
 def from_ints(vals):
     return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), np.uint8).reshape(-1, 32).copy()
+
+
+# ---- cfg-4 workload: valid EdDSA-Poseidon signatures, 1 in 64 corrupted ----------------------
+def make_signatures(fixed_base, poseidon5, n, offset=0):
+    """A = k*B8, R = rho*B8, S = rho + 8*hm*k mod l -- algebraically what PrivateKey::sign produces (src/lib.rs:335-339).
+    `fixed_base` / `poseidon5` are callables on (n, 32) / (n, 160) byte arrays (the GPU library or the oracle)."""
+    k = [v % L_ORDER for v in to_ints(random_u256(SEED_KEYS, n, offset))]
+    rho = [v % L_ORDER for v in to_ints(random_u256(SEED_NONCES, n, offset))]
+    msg = random_u256(SEED_MSGS, n, offset, top_bits_cleared=3)  # < 2^253 < Q
+    A = fixed_base(from_ints(k))
+    R = fixed_base(from_ints(rho))
+    hm = to_ints(poseidon5(np.concatenate([R, A, msg], axis=1)))
+    S = from_ints([(rho[i] + 8 * hm[i] * k[i]) % L_ORDER for i in range(n)])
+    return A, R, S, msg
+
+
+def corrupt(A, R, S, msg, n, offset=0):
+    """1 item in 64 gets one seeded bit flipped in S, msg, R.y or A.x (in place); returns the bad mask."""
+    r = splitmix64(SEED_BAD, n, offset)
+    bad = (r & np.uint64(63)) == 0
+    which = (r >> np.uint64(6)) & np.uint64(3)
+    bit = ((r >> np.uint64(8)) % np.uint64(250)).astype(np.int64)
+    for i in np.nonzero(bad)[0]:
+        tgt = (S[i], msg[i], R[i, 32:], A[i, :32])[int(which[i])]
+        tgt[bit[i] // 8] ^= np.uint8(1 << (bit[i] % 8))
+    return bad

@@ -95,8 +95,7 @@ class Workload:
             self.d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
             self.d_ok = torch.empty(n, dtype=torch.uint8, device=dev)
         else:  # verify / verify_compressed: cfg 4 signatures, 1/64 corrupted
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from test_gpu_parity import make_signatures, corrupt
+            make_signatures, corrupt = w.make_signatures, w.corrupt
             A, R, S, msg = make_signatures(ctx.mul_fixed_base, ctx.poseidon5, n, offset)
             if kind == "verify":
                 self.bad = corrupt(A, R, S, msg, n, offset)

@@ -103,7 +103,7 @@ def test_gpu_codec_random_vs_oracle(gpu_ctx, oracle):
 def test_gpu_verify_compressed_and_roundtrip_1m(gpu_ctx, oracle):
     """signature compress -> decompress -> verify as src/lib.rs:657-675, at scale: 2^18 signatures made
     by the GPU kernels, 1/64 corrupted; and compress(decompress(.)) == id over 2^20 points."""
-    from test_gpu_parity import make_signatures, corrupt
+    from babyjubjub_rs_amd.workload import make_signatures, corrupt
     n = 1 << 18
     A, R, S, msg = make_signatures(gpu_ctx.mul_fixed_base, gpu_ctx.poseidon5, n)
     pk_c = gpu_ctx.compress_points(A)

@@ -106,31 +106,7 @@ def test_poseidon_random(gpu_ctx, oracle):
     assert (gpu_ctx.poseidon5(a) == oracle.poseidon5(a)).all()
 
 
-def make_signatures(fixed_base, poseidon5, n, offset=0):
-    """cfg-4 workload: A = k*B8, R = rho*B8, S = rho + 8*hm*k mod l.
-    `fixed_base` / `poseidon5` are callables (GPU library or oracle)."""
-    from babyjubjub_rs_amd import workload as w
-    k = [v % L for v in w.to_ints(w.random_u256(w.SEED_KEYS, n, offset))]
-    rho = [v % L for v in w.to_ints(w.random_u256(w.SEED_NONCES, n, offset))]
-    msg = w.random_u256(w.SEED_MSGS, n, offset, top_bits_cleared=3)  # < 2^253 < Q
-    A = fixed_base(w.from_ints(k))
-    R = fixed_base(w.from_ints(rho))
-    hm = w.to_ints(poseidon5(np.concatenate([R, A, msg], axis=1)))
-    S = w.from_ints([(rho[i] + 8 * hm[i] * k[i]) % L for i in range(n)])
-    return A, R, S, msg
-
-
-def corrupt(A, R, S, msg, n, offset=0):
-    """1 item in 64 gets one seeded bit flipped in S, msg, R.y or A.x; returns the bad mask."""
-    from babyjubjub_rs_amd import workload as w
-    r = w.splitmix64(w.SEED_BAD, n, offset)
-    bad = (r & np.uint64(63)) == 0
-    which = (r >> np.uint64(6)) & np.uint64(3)
-    bit = ((r >> np.uint64(8)) % np.uint64(250)).astype(np.int64)
-    for i in np.nonzero(bad)[0]:
-        tgt = (S[i], msg[i], R[i, 32:], A[i, :32])[int(which[i])]
-        tgt[bit[i] // 8] ^= np.uint8(1 << (bit[i] % 8))
-    return bad
+from babyjubjub_rs_amd.workload import make_signatures, corrupt  # noqa: E402  (the cfg-4 generator lives with the other workloads)
 
 
 def test_verify_random_with_corruption(gpu_ctx, oracle):

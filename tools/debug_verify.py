@@ -2,7 +2,7 @@ import sys, os, numpy as np
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests")); sys.path.insert(0,os.path.join(ROOT,"oracle"))
 import babyjubjub_rs_amd as bjj
 from conftest import Oracle
-from test_gpu_parity import make_signatures, corrupt
+from babyjubjub_rs_amd.workload import make_signatures, corrupt
 import bjj_oracle as o
 L=o.SUBORDER
 ctx=bjj.Context(0); orc=Oracle()
