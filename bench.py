@@ -378,7 +378,7 @@ def main():
             ach = algo / (kernel_ms * 1e-3) / 1e9
             result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": ach / HBM_PEAK_GBPS,
-                                  "traffic": load_traffic(kind) if (n == (1 << 20) and not args.window_bits) else None,
+                                  "traffic": load_traffic(kind) if (n == (1 << 20) and load_traffic(kind, "window_bits") in (None, info.window_bits)) else None,
                                   "kernel": {"fixed_base": info.kernel_fixed_base, "var_base": info.kernel_var_base,
                                              "verify": info.kernel_verify, "poseidon5": info.kernel_poseidon5,
                                              "verify_compressed": info.kernel_verify,
@@ -386,7 +386,7 @@ def main():
                                   "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": algo,
                                   "note": "integer-ALU bound path (see DESIGN.md): HBM fraction is reported as measured"}
             vi = load_traffic(kind, "valu_insts_per_launch")
-            if vi and n == (1 << 20) and not args.window_bits:
+            if vi and n == (1 << 20) and load_traffic(kind, "window_bits") in (None, info.window_bits):
                 va = vi / (kernel_ms * 1e-3) / 1e9
                 result["valu"] = {"insts_per_launch": vi, "achieved": va, "peak": VALU_PEAK_GINST, "frac": va / VALU_PEAK_GINST,
                                   "unit": "G wave-instructions/s",

@@ -63,6 +63,11 @@ if traffic:
     d[wl] = {"bytes_per_launch": traffic, "source": "profiles/%s_%s_summary.md" % (tag, wl), "batch": int(meta.get("Grid_Size", 0)) and 1 << 20}
     if "SQ_INSTS_VALU" in counters:
         d[wl]["valu_insts_per_launch"] = counters["SQ_INSTS_VALU"][0]
+    try:  # the window width the counters were collected with (bench.py only quotes them for the same configuration)
+        bl = [l for l in open(os.path.join(src, "bench_%s.json" % wl)).read().splitlines() if l.startswith("{")][-1]
+        d[wl]["window_bits"] = json.loads(bl)["config"]["window_bits"]
+    except Exception:
+        pass
     json.dump(d, open(tj, "w"), indent=1)
 bj = os.path.join(src, "bench_%s.json" % wl)
 if os.path.exists(bj) and os.path.getsize(bj):
