@@ -7,8 +7,8 @@ benchmark (import name: babyjubjub_rs_amd, see ../babyjubjub_rs_amd.py).  The
 product is csrc/libbjj_hip.so.
 """
 from .api import (  # noqa: F401
-    Q, B8, SUBORDER, BjjError, Context, Point, PointProjective, Signature, default_context,
+    Q, B8, SUBORDER, BjjError, Context, MultiContext, Point, PointProjective, Signature, default_context,
     mul_scalar_batch, mul_fixed_base_batch, poseidon5_batch, verify_batch, verify, point_add_batch,
     decompress_point, decompress_signature, PrivateKey, verify_schnorr, new_key,
 )
-from ._lib import LIB_PATH, EXPORTED_SYMBOLS  # noqa: F401
+from ._lib import LIB_PATH, EXPORTED_SYMBOLS, BJJ_WINDOW_AUTO as WINDOW_AUTO  # noqa: F401

@@ -14,6 +14,9 @@ BJJ_E_INVALID = -1
 BJJ_E_NO_DEVICE = -2
 BJJ_E_HIP = -3
 BJJ_E_NOMEM = -4
+BJJ_E_RCCL = -5
+BJJ_WINDOW_AUTO = -1
+BJJ_MAX_SCALAR_BYTES = 4096
 
 # every symbol include/bjj_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -26,6 +29,12 @@ EXPORTED_SYMBOLS = (
     "bjj_scalar_keys", "bjj_public_keys", "bjj_sign", "bjj_scalar_keys_dev", "bjj_public_keys_dev", "bjj_sign_dev",
     "bjj_sign_schnorr", "bjj_sign_schnorr_dev",
     "bjj_compress_points_dev", "bjj_decompress_points_dev", "bjj_eddsa_verify_compressed_dev",
+    "bjj_mul_var_base_wide", "bjj_mul_var_base_wide_dev", "bjj_proj_add", "bjj_proj_add_dev",
+    "bjj_proj_affine", "bjj_proj_affine_dev",
+    "bjj_multi_init", "bjj_multi_free", "bjj_multi_size", "bjj_multi_ctx", "bjj_multi_device", "bjj_shard_bounds",
+    "bjj_mul_fixed_base_multi", "bjj_mul_var_base_multi", "bjj_eddsa_verify_multi",
+    "bjj_mul_fixed_base_multi_dev", "bjj_mul_var_base_multi_dev", "bjj_eddsa_verify_multi_dev",
+    "bjj_multi_last_timing",
 )
 
 
@@ -41,6 +50,7 @@ class BjjInfo(ctypes.Structure):
         ("kernel_var_base", ctypes.c_char_p),
         ("kernel_poseidon5", ctypes.c_char_p),
         ("kernel_verify", ctypes.c_char_p),
+        ("init_ms", ctypes.c_double),
     ]
 
 
@@ -97,4 +107,28 @@ def load():
     lib.bjj_compress_points_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.bjj_decompress_points_dev.argtypes = [vp, vp, sz, vp, vp, vp]
     lib.bjj_eddsa_verify_compressed_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    lib.bjj_mul_var_base_wide.argtypes = [vp, vp, vp, sz, sz, vp]
+    lib.bjj_mul_var_base_wide_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+    lib.bjj_proj_add.argtypes = [vp, vp, vp, sz, vp]
+    lib.bjj_proj_add_dev.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.bjj_proj_affine.argtypes = [vp, vp, sz, vp]
+    lib.bjj_proj_affine_dev.argtypes = [vp, vp, sz, vp, vp]
+    # multi-GPU
+    pd = ctypes.POINTER(ctypes.c_double)
+    lib.bjj_multi_init.argtypes = [ctypes.POINTER(ci), ci, ci, ctypes.POINTER(vp)]
+    lib.bjj_multi_free.argtypes = [vp]
+    lib.bjj_multi_free.restype = None
+    lib.bjj_multi_size.argtypes = [vp]
+    lib.bjj_multi_ctx.argtypes = [vp, ci]
+    lib.bjj_multi_ctx.restype = vp
+    lib.bjj_multi_device.argtypes = [vp, ci]
+    lib.bjj_shard_bounds.argtypes = [sz, ci, ci, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.bjj_shard_bounds.restype = None
+    lib.bjj_mul_fixed_base_multi.argtypes = [vp, vp, sz, vp]
+    lib.bjj_mul_var_base_multi.argtypes = [vp, vp, vp, sz, vp]
+    lib.bjj_eddsa_verify_multi.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    lib.bjj_mul_fixed_base_multi_dev.argtypes = [vp, vp, sz, vp]
+    lib.bjj_mul_var_base_multi_dev.argtypes = [vp, vp, vp, sz, vp]
+    lib.bjj_eddsa_verify_multi_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    lib.bjj_multi_last_timing.argtypes = [vp, pd, pd, pd, ctypes.POINTER(ci)]
     return lib

@@ -34,7 +34,17 @@ class BjjError(RuntimeError):
 def _as_u8(a, width, name):
     """Accepts an (n, width) / (n*width,) uint8 array, or a list of ints / int tuples."""
     if isinstance(a, np.ndarray):
-        arr = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+        if a.dtype != np.uint8:
+            # a value cast would keep only the low byte of every element: reinterpret little-endian unsigned
+            # limbs (e.g. the natural (n, 4) uint64 layout of Fr::into_repr().0) and refuse everything else
+            if a.dtype.kind != "u" or 32 % a.dtype.itemsize or (a.dtype.itemsize > 1 and a.dtype.byteorder == ">"):
+                raise BjjError("%s: array dtype %s is neither uint8 bytes nor little-endian unsigned limbs" % (name, a.dtype))
+            if a.dtype.byteorder == "=" and a.dtype.itemsize > 1:
+                import sys as _sys
+                if _sys.byteorder != "little":
+                    raise BjjError("%s: native-endian limbs on a big-endian host" % name)
+            a = np.ascontiguousarray(a).view(np.uint8)
+        arr = np.ascontiguousarray(a).reshape(-1)
         if arr.size % width:
             raise BjjError("%s: byte length %d is not a multiple of %d" % (name, arr.size, width))
         return arr
@@ -62,10 +72,16 @@ def _ints(arr, per_item):
 
 
 class Context:
-    """One GPU + stream + fixed-base table (bjj_init / bjj_free)."""
+    """One GPU + stream + fixed-base table (bjj_init / bjj_free).
+    window_bits: 0 = the library default (23 bits, 5.9 GB), WINDOW_AUTO = widest table that fits in 60 % of the free
+    HBM, or an explicit width 4..28 (28 = 154.6 GB, what bench.py measures)."""
 
-    def __init__(self, device=0, window_bits=0):
+    def __init__(self, device=0, window_bits=0, _borrowed=None):
         self.lib = _lib.load()
+        self._owned = _borrowed is None
+        if _borrowed is not None:  # a per-device context owned by a MultiContext
+            self.handle = ctypes.c_void_p(_borrowed)
+            return
         h = ctypes.c_void_p()
         rc = self.lib.bjj_init(int(device), int(window_bits), ctypes.byref(h))
         if rc != _lib.BJJ_OK:
@@ -74,7 +90,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.bjj_free(self.handle)
+            if self._owned:
+                self.lib.bjj_free(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -121,6 +138,37 @@ class Context:
         out = np.empty(n * 64, dtype=np.uint8)
         self._ck(self.lib.bjj_mul_var_base(self.handle, p.ctypes.data, s.ctypes.data, n, out.ctypes.data),
                  "bjj_mul_var_base")
+        return out.reshape(n, 64)
+
+    def mul_var_base_wide(self, points, scalars, scalar_bytes):
+        """Point::mul_scalar for scalars of scalar_bytes (a multiple of 32) little-endian bytes each (lib.rs:149, 156-157)."""
+        p = _as_u8(points, 64, "points")
+        s = _as_u8(scalars, scalar_bytes, "scalars")
+        n = p.size // 64
+        if s.size != n * scalar_bytes:
+            raise BjjError("mul_var_base_wide: %d points vs %d scalars" % (n, s.size // scalar_bytes))
+        out = np.empty(n * 64, dtype=np.uint8)
+        self._ck(self.lib.bjj_mul_var_base_wide(self.handle, p.ctypes.data, s.ctypes.data, scalar_bytes, n, out.ctypes.data),
+                 "bjj_mul_var_base_wide")
+        return out.reshape(n, 64)
+
+    def proj_add(self, p, q):
+        """raw PointProjective::add (lib.rs:88-131): (n, 96) x/y/z records in and out, any z"""
+        a = _as_u8(p, 96, "p")
+        b = _as_u8(q, 96, "q")
+        n = a.size // 96
+        if b.size != a.size:
+            raise BjjError("proj_add: array lengths disagree")
+        out = np.empty(n * 96, dtype=np.uint8)
+        self._ck(self.lib.bjj_proj_add(self.handle, a.ctypes.data, b.ctypes.data, n, out.ctypes.data), "bjj_proj_add")
+        return out.reshape(n, 96)
+
+    def proj_affine(self, p):
+        """PointProjective::affine (lib.rs:70-85): (n, 96) -> (n, 64); z == 0 -> (0, 0)"""
+        a = _as_u8(p, 96, "p")
+        n = a.size // 96
+        out = np.empty(n * 64, dtype=np.uint8)
+        self._ck(self.lib.bjj_proj_affine(self.handle, a.ctypes.data, n, out.ctypes.data), "bjj_proj_affine")
         return out.reshape(n, 64)
 
     def poseidon5(self, inputs):
@@ -276,6 +324,120 @@ class Context:
     def point_add_dev(self, d_p, d_q, n, d_out, stream=0):
         self._ck(self.lib.bjj_point_add_dev(self.handle, d_p, d_q, n, d_out, stream), "bjj_point_add_dev")
 
+    def proj_add_dev(self, d_p, d_q, n, d_out, stream=0):
+        self._ck(self.lib.bjj_proj_add_dev(self.handle, d_p, d_q, n, d_out, stream), "bjj_proj_add_dev")
+
+    def proj_affine_dev(self, d_p, n, d_out, stream=0):
+        self._ck(self.lib.bjj_proj_affine_dev(self.handle, d_p, n, d_out, stream), "bjj_proj_affine_dev")
+
+    def mul_var_base_wide_dev(self, d_pts, d_scalars, scalar_bytes, n, d_out, stream=0):
+        self._ck(self.lib.bjj_mul_var_base_wide_dev(self.handle, d_pts, d_scalars, scalar_bytes, n, d_out, stream),
+                 "bjj_mul_var_base_wide_dev")
+
+    def public_keys_dev(self, d_keys, n, d_out, stream=0):
+        self._ck(self.lib.bjj_public_keys_dev(self.handle, d_keys, n, d_out, stream), "bjj_public_keys_dev")
+
+    def scalar_keys_dev(self, d_keys, n, d_out, stream=0):
+        self._ck(self.lib.bjj_scalar_keys_dev(self.handle, d_keys, n, d_out, stream), "bjj_scalar_keys_dev")
+
+    def schnorr_verify_dev(self, d_pk, d_r, d_s, d_msg, n, d_ok, stream=0):
+        self._ck(self.lib.bjj_schnorr_verify_dev(self.handle, d_pk, d_r, d_s, d_msg, n, d_ok, stream),
+                 "bjj_schnorr_verify_dev")
+
+
+class MultiContext:
+    """All (or the listed) GPUs of this process behind one handle (bjj_multi_init): contiguous ceil(n/G) blocks per
+    device, replicated tables.  Host arrays -> one pipeline thread per device; *_dev -> arrays resident on the first
+    device, RCCL scatter / kernels / gather (BASELINE cfg 5)."""
+
+    def __init__(self, devices=None, window_bits=0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        if devices is None:
+            arr, n = None, 0
+        else:
+            devices = [int(d) for d in devices]
+            arr, n = (ctypes.c_int * len(devices))(*devices), len(devices)
+        rc = self.lib.bjj_multi_init(arr, n, int(window_bits), ctypes.byref(h))
+        if rc != _lib.BJJ_OK:
+            raise BjjError("bjj_multi_init failed (%d): %s" % (rc, self.lib.bjj_last_error().decode()))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.bjj_multi_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != _lib.BJJ_OK:
+            raise BjjError("%s failed (%d): %s" % (what, rc, self.lib.bjj_last_error().decode()))
+
+    @property
+    def size(self):
+        return self.lib.bjj_multi_size(self.handle)
+
+    def device(self, rank):
+        return self.lib.bjj_multi_device(self.handle, rank)
+
+    def ctx(self, rank):
+        return Context(_borrowed=self.lib.bjj_multi_ctx(self.handle, rank))
+
+    def shard_bounds(self, n, rank):
+        lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+        self.lib.bjj_shard_bounds(n, self.size, rank, ctypes.byref(lo), ctypes.byref(hi))
+        return lo.value, hi.value
+
+    def last_timing(self):
+        s, c, g, v = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        self._ck(self.lib.bjj_multi_last_timing(self.handle, ctypes.byref(s), ctypes.byref(c), ctypes.byref(g), ctypes.byref(v)),
+                 "bjj_multi_last_timing")
+        return {"scatter_ms": s.value, "compute_ms": c.value, "gather_ms": g.value, "rccl_version": v.value}
+
+    def mul_fixed_base(self, scalars):
+        s = _as_u8(scalars, 32, "scalars")
+        n = s.size // 32
+        out = np.empty(n * 64, dtype=np.uint8)
+        self._ck(self.lib.bjj_mul_fixed_base_multi(self.handle, s.ctypes.data, n, out.ctypes.data), "bjj_mul_fixed_base_multi")
+        return out.reshape(n, 64)
+
+    def mul_var_base(self, points, scalars):
+        p = _as_u8(points, 64, "points")
+        s = _as_u8(scalars, 32, "scalars")
+        n = s.size // 32
+        if p.size != n * 64:
+            raise BjjError("mul_var_base: %d points vs %d scalars" % (p.size // 64, n))
+        out = np.empty(n * 64, dtype=np.uint8)
+        self._ck(self.lib.bjj_mul_var_base_multi(self.handle, p.ctypes.data, s.ctypes.data, n, out.ctypes.data),
+                 "bjj_mul_var_base_multi")
+        return out.reshape(n, 64)
+
+    def eddsa_verify(self, pk, r_b8, s, msg):
+        a, r, sv, m = _as_u8(pk, 64, "pk"), _as_u8(r_b8, 64, "r_b8"), _as_u8(s, 32, "s"), _as_u8(msg, 32, "msg")
+        n = sv.size // 32
+        if a.size != n * 64 or r.size != n * 64 or m.size != n * 32:
+            raise BjjError("eddsa_verify: array lengths disagree")
+        ok = np.empty(n, dtype=np.uint8)
+        self._ck(self.lib.bjj_eddsa_verify_multi(self.handle, a.ctypes.data, r.ctypes.data, sv.ctypes.data, m.ctypes.data, n,
+                                                 ok.ctypes.data), "bjj_eddsa_verify_multi")
+        return ok
+
+    # device-resident form: integer device addresses on the handle's first device; synchronous
+    def mul_fixed_base_dev(self, d_scalars, n, d_out):
+        self._ck(self.lib.bjj_mul_fixed_base_multi_dev(self.handle, d_scalars, n, d_out), "bjj_mul_fixed_base_multi_dev")
+
+    def mul_var_base_dev(self, d_pts, d_scalars, n, d_out):
+        self._ck(self.lib.bjj_mul_var_base_multi_dev(self.handle, d_pts, d_scalars, n, d_out), "bjj_mul_var_base_multi_dev")
+
+    def eddsa_verify_dev(self, d_pk, d_r, d_s, d_msg, n, d_ok):
+        self._ck(self.lib.bjj_eddsa_verify_multi_dev(self.handle, d_pk, d_r, d_s, d_msg, n, d_ok),
+                 "bjj_eddsa_verify_multi_dev")
+
 
 _DEFAULT = None
 
@@ -304,9 +466,14 @@ class Point:
         n = abs(int(n))
         ctx = ctx or default_context()
         if n >> 256:
-            # the C ABI carries 32-byte scalars; for an ON-CURVE point n*P == (n mod 8l)*P
-            raise BjjError("mul_scalar: scalars wider than 256 bits are outside the accelerated boundary")
-        if (self.x, self.y) == B8:
+            # `n: &BigInt` is unbounded (lib.rs:149): wide records of 32 k bytes; the device reduces mod 8l for an
+            # on-curve point (exact) and replays all n.bits() bits of the reference's loop for an off-curve one
+            nbytes = ((n.bit_length() + 255) // 256) * 32
+            if nbytes > _lib.BJJ_MAX_SCALAR_BYTES:
+                raise BjjError("mul_scalar: scalars wider than %d bits are outside the accelerated boundary"
+                               % (8 * _lib.BJJ_MAX_SCALAR_BYTES))
+            out = ctx.mul_var_base_wide([(self.x, self.y)], np.frombuffer(n.to_bytes(nbytes, "little"), np.uint8), nbytes)
+        elif (self.x, self.y) == B8:
             out = ctx.mul_fixed_base([n])
         else:
             out = ctx.mul_var_base([(self.x, self.y)], [n])
@@ -327,28 +494,20 @@ class Point:
 
 
 class PointProjective:
-    """`pub struct PointProjective { x, y, z }` (lib.rs:62-67).  Only z == 1 inputs reach the
-    GPU (`Point::projective()` always produces them); add() returns the affine sum lifted back."""
+    """`pub struct PointProjective { pub x, pub y, pub z }` (lib.rs:62-67): any z, like the reference."""
 
     __slots__ = ("x", "y", "z")
 
     def __init__(self, x, y, z=1):
         self.x, self.y, self.z = int(x) % Q, int(y) % Q, int(z) % Q
 
-    def affine(self):  # lib.rs:70-85
-        if self.z == 0:
-            return Point(0, 0)
-        if self.z != 1:
-            zi = pow(self.z, Q - 2, Q)
-            return Point(self.x * zi % Q, self.y * zi % Q)
-        return Point(self.x, self.y)
+    def affine(self, ctx=None):  # lib.rs:70-85 (z == 0 -> (0, 0))
+        x, y = _ints((ctx or default_context()).proj_affine([(self.x, self.y, self.z)]), 2)[0]
+        return Point(x, y)
 
-    def add(self, q, ctx=None):  # lib.rs:88-131 (+ affine), for z == 1 operands
-        if self.z != 1 or q.z != 1:
-            raise BjjError("PointProjective.add: the accelerated boundary takes affine (z == 1) operands")
-        ctx = ctx or default_context()
-        x, y = _ints(ctx.point_add([(self.x, self.y)], [(q.x, q.y)]), 2)[0]
-        return PointProjective(x, y, 1)
+    def add(self, q, ctx=None):  # lib.rs:88-131: the raw (x, y, z) of the reference's formula sequence
+        x, y, z = _ints((ctx or default_context()).proj_add([(self.x, self.y, self.z)], [(q.x, q.y, q.z)]), 3)[0]
+        return PointProjective(x, y, z)
 
 
 class Signature:

@@ -1,0 +1,62 @@
+// Interface between the host side of libbjj_hip.so (bjj_hip.hip: contexts + the extern "C" boundary) and its kernel
+// translation units (k_*.hip).  Plain pointers and sizes only; every launcher enqueues on `st` and returns the launch status.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define BJJ_BLOCK 256
+// Workgroup size of the kernels that end in the shared-inversion epilogue: one binary-GCD
+// inversion (executed by one wave) is amortised over the whole workgroup.
+#define BJJ_EPI_BLOCK 512
+
+namespace bjjk {
+
+template <typename K>
+static inline int occupancy_of(K kernel, int block) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) nb = 1;
+  return nb;
+}
+
+// resident workgroups per CU (queried on the current device)
+int occ_fixed_base();
+int occ_var_base();
+int occ_point_add();
+int occ_poseidon5();
+int occ_decompress();
+int occ_verify();
+int occ_verify_scan();
+int occ_sign();
+int occ_sign_schnorr();
+
+// k_fixed.hip
+hipError_t build_fixed_table(hipStream_t st, uint32_t* table, uint32_t* bases, int W, int nwin);
+hipError_t check_fixed_table(hipStream_t st, int grid, const uint32_t* table, const uint32_t* bases, int W, int nwin,
+                             unsigned long long* d_bad);
+hipError_t mul_fixed_base(hipStream_t st, int grid, const uint32_t* table, int W, int nwin, const uint8_t* scalars, size_t n,
+                          uint8_t* out, uint32_t* scratch);
+// k_var.hip (sc_words: 32-bit words per scalar record, 8 for the 32-byte form)
+hipError_t mul_var_base(hipStream_t st, int grid, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
+                        uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow);
+hipError_t point_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);
+hipError_t proj_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);
+hipError_t proj_affine(hipStream_t st, int grid, const uint8_t* p, size_t n, uint8_t* out);
+// k_hash_codec.hip
+hipError_t poseidon5(hipStream_t st, int grid, const uint8_t* in, size_t n, uint8_t* out);
+hipError_t compress_points(hipStream_t st, int grid, const uint8_t* in_xy, size_t n, uint8_t* out);
+hipError_t decompress_points(hipStream_t st, int grid, const uint8_t* in, size_t stride, size_t n, uint8_t* out_xy, uint8_t* ok,
+                             uint8_t* out_s);
+hipError_t merge_codec_flags(hipStream_t st, int grid, uint8_t* ok, const uint8_t* f_pk, const uint8_t* f_r, size_t n);
+hipError_t scalar_keys(hipStream_t st, int grid, const uint8_t* keys, size_t n, uint8_t* out);
+// k_verify.hip
+hipError_t verify(hipStream_t st, int grid_scan, int grid, bool schnorr, const uint32_t* table, int W, int nwin, const uint8_t* pk,
+                  const uint8_t* rb8, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok, uint32_t* vb_tables,
+                  uint32_t* wl);
+// k_sign.hip
+hipError_t sign(hipStream_t st, int grid, const uint32_t* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n,
+                uint8_t* out_r, uint8_t* out_s, uint8_t* ok);
+hipError_t sign_schnorr(hipStream_t st, int grid, const uint32_t* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs,
+                        const uint8_t* nonces, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok);
+
+}  // namespace bjjk

@@ -27,7 +27,7 @@
 
 #if defined(__HIPCC__)
 #define BJJ_HD __host__ __device__ __forceinline__
-#define BJJ_HD_NOINLINE __host__ __device__ __noinline__
+#define BJJ_HD_NOINLINE static __host__ __device__ __noinline__   // internal linkage: the library has several translation units
 #else
 #define BJJ_HD inline
 #define BJJ_HD_NOINLINE

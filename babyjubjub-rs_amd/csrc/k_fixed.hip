@@ -1,0 +1,84 @@
+// libbjj_hip.so, kernel unit 1: the fixed-base table (build / check) and K1, B8.mul_scalar(n)
+// (src/lib.rs:149-164 with self = B8, src/lib.rs:37-46; the engine of PrivateKey::public, :304-306).
+#include "k_common.hpp"
+
+// ---------------------------------------------------------------------------
+// init: fixed-base table (layout and recoding: bjj_device.hpp "fixed base").
+//   bases:  one thread per window j -> P_j = 2^(W j) * B8 (ladder + inversion; nwin threads)
+//   build:  one thread per chain of `chain` consecutive digits of one window (fixed_table_chain)
+//   check:  one thread per entry, link conditions of fixed_table_check_slot (bjj_check_table)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) bjj_k_fixed_window_bases(u32* bases, int W, int nwin) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nwin) return;
+  store_niels(bases + (size_t)j * NIELS_WORDS, fixed_table_entry(1u, j, W, c_K));
+}
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_build_fixed_table(u32* table, const u32* __restrict__ bases, int W, int nwin,
+                                                                 u32 chain) {
+  const size_t stride = fixed_stride(W);
+  const size_t cpw = (stride + chain - 1) / chain;  // chains per window
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cpw * (size_t)nwin) return;
+  const int j = (int)(t / cpw);
+  const size_t k0 = (t % cpw) * chain;
+  const u32 cnt = (u32)(stride - k0 < chain ? stride - k0 : chain);
+  fixed_table_chain(table, load_niels(bases + (size_t)j * NIELS_WORDS), (size_t)j * stride + k0, (u32)k0, cnt, W, c_K);
+}
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_check_fixed_table(const u32* __restrict__ table, const u32* __restrict__ bases,
+                                                                 int W, int nwin, unsigned long long* bad) {
+  const size_t stride = fixed_stride(W);
+  const size_t total = stride * (size_t)nwin, nthreads = (size_t)gridDim.x * blockDim.x;
+  unsigned long long mine = 0;
+#pragma unroll 1
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += nthreads)
+    mine += (unsigned long long)fixed_table_check_slot(table, bases, (int)(e / stride), (u32)(e % stride), W, nwin, c_K);
+  if (mine) atomicAdd(bad, mine);
+}
+
+
+__global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
+                                                                  const uint8_t* __restrict__ scalars, size_t n,
+                                                                  uint8_t* __restrict__ out, u32* __restrict__ scratch) {
+  __shared__ u32 lds[NL * 64];
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_EPI_BLOCK / 64) * 2 * FB_STAGE_WORDS];
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const GatherCoopLds<2> fb = {table, stage + (threadIdx.x >> 6) * 2 * FB_STAGE_WORDS, lane};
+  Fr run = fr_one();
+#pragma unroll 1
+  for (size_t i = tid; i - lane < n; i += nthreads) {  // wave-uniform trip count: the gathers are cooperative
+    const bool valid = i < n;
+    u32 sc[8];
+    load_w8(scalars + (valid ? i : n - 1) * 32, sc);
+    Ext p = fixed_base_mul(fb, W, nwin, sc, c_K);
+    if (valid) epilogue_stash(p, run, out + i * 64, scratch + i * 16);
+  }
+  epilogue_run(run, n, tid, nthreads, out, scratch, lds);
+}
+
+// ---- launchers (declared in bjj_launch.hpp) ------------------------------------------------------------
+namespace bjjk {
+int occ_fixed_base() { return occupancy_of(bjj_k_mul_fixed_base, BJJ_EPI_BLOCK); }
+hipError_t build_fixed_table(hipStream_t st, u32* table, u32* bases, int W, int nwin) {
+  const size_t entries = fixed_stride(W) * (size_t)nwin;
+  // chain length: long enough to amortise the start ladder and the inversion, short enough to fill the GPU
+  size_t chain = entries >> 18;
+  chain = chain < 4 ? 4 : (chain > 256 ? 256 : chain);
+  const size_t chains = ((fixed_stride(W) + chain - 1) / chain) * (size_t)nwin;
+  hipLaunchKernelGGL(bjj_k_fixed_window_bases, dim3((nwin + 63) / 64), dim3(64), 0, st, bases, W, nwin);
+  hipLaunchKernelGGL(bjj_k_build_fixed_table, dim3((unsigned)((chains + BJJ_BLOCK - 1) / BJJ_BLOCK)), dim3(BJJ_BLOCK), 0, st,
+                     table, bases, W, nwin, (u32)chain);
+  return hipGetLastError();
+}
+hipError_t check_fixed_table(hipStream_t st, int grid, const u32* table, const u32* bases, int W, int nwin,
+                             unsigned long long* d_bad) {
+  hipLaunchKernelGGL(bjj_k_check_fixed_table, dim3((unsigned)grid), dim3(BJJ_BLOCK), 0, st, table, bases, W, nwin, d_bad);
+  return hipGetLastError();
+}
+hipError_t mul_fixed_base(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* scalars, size_t n,
+                          uint8_t* out, u32* scratch) {
+  hipLaunchKernelGGL(bjj_k_mul_fixed_base, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
+  return hipGetLastError();
+}
+}  // namespace bjjk

@@ -1,0 +1,74 @@
+// libbjj_hip.so, kernel unit 5: signer side, PrivateKey::sign / sign_schnorr (src/lib.rs:308-361).
+#include "k_common.hpp"
+
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign(const u32* __restrict__ table, int W, int nwin,
+                                                           const uint8_t* __restrict__ keys,
+                                                           const uint8_t* __restrict__ msgs, size_t n,
+                                                           uint8_t* __restrict__ out_r, uint8_t* __restrict__ out_s,
+                                                           uint8_t* __restrict__ ok) {
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_BLOCK / 64) * FB_STAGE_WORDS];
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const GatherCoopLds<1> fb = {table, stage + (threadIdx.x >> 6) * FB_STAGE_WORDS, lane};
+#pragma unroll 1
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i - lane < n; i += nthreads) {  // wave-uniform trip count
+    const size_t ic = i < n ? i : n - 1;
+    u32 k[8], m[8], rx[8], ry[8], s[8];
+    load_w8(keys + ic * 32, k); load_w8(msgs + ic * 32, m);
+    const bool good = sign_item(k, m, fb, W, nwin, rx, ry, s, c_K);
+    if (i < n) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { rx[j] = good ? rx[j] : 0u; ry[j] = good ? ry[j] : 0u; s[j] = good ? s[j] : 0u; }
+      store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry); store_w8(out_s + i * 32, s);
+      ok[i] = good ? 1 : 0;
+    }
+  }
+}
+
+// PrivateKey::sign_schnorr (src/lib.rs:344-361) with caller-supplied 1024-bit nonces (128 B each); s is the
+// reference's unreduced integer k + scalar_key*h in a 160-byte little-endian record.
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign_schnorr(const u32* __restrict__ table, int W, int nwin,
+                                                                   const uint8_t* __restrict__ keys,
+                                                                   const uint8_t* __restrict__ msgs,
+                                                                   const uint8_t* __restrict__ nonces, size_t n,
+                                                                   uint8_t* __restrict__ out_r, uint8_t* __restrict__ out_s,
+                                                                   uint8_t* __restrict__ ok) {
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_BLOCK / 64) * FB_STAGE_WORDS];
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const GatherCoopLds<1> fb = {table, stage + (threadIdx.x >> 6) * FB_STAGE_WORDS, lane};
+#pragma unroll 1
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i - lane < n; i += nthreads) {  // wave-uniform trip count
+    const size_t ic = i < n ? i : n - 1;
+    u32 k[8], m[8], rx[8], ry[8], kn[SCHNORR_K_WORDS], s[SCHNORR_S_WORDS];
+    load_w8(keys + ic * 32, k); load_w8(msgs + ic * 32, m);
+#pragma unroll
+    for (int j = 0; j < SCHNORR_K_WORDS / 8; j++) load_w8(nonces + ic * (SCHNORR_K_WORDS * 4) + j * 32, kn + 8 * j);
+    const bool good = sign_schnorr_item(k, m, kn, fb, W, nwin, rx, ry, s, c_K);
+    if (i < n) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { rx[j] = good ? rx[j] : 0u; ry[j] = good ? ry[j] : 0u; }
+#pragma unroll
+      for (int j = 0; j < SCHNORR_S_WORDS; j++) s[j] = good ? s[j] : 0u;
+      store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry);
+#pragma unroll
+      for (int j = 0; j < SCHNORR_S_WORDS / 8; j++) store_w8(out_s + i * (SCHNORR_S_WORDS * 4) + j * 32, s + 8 * j);
+      ok[i] = good ? 1 : 0;
+    }
+  }
+}
+
+namespace bjjk {
+int occ_sign() { return occupancy_of(bjj_k_sign, BJJ_BLOCK); }
+int occ_sign_schnorr() { return occupancy_of(bjj_k_sign_schnorr, BJJ_BLOCK); }
+hipError_t sign(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n,
+                uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
+  hipLaunchKernelGGL(bjj_k_sign, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
+  return hipGetLastError();
+}
+hipError_t sign_schnorr(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs,
+                        const uint8_t* nonces, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
+  hipLaunchKernelGGL(bjj_k_sign_schnorr, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, nonces, n, out_r, out_s, ok);
+  return hipGetLastError();
+}
+}  // namespace bjjk

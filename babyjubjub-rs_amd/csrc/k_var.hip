@@ -1,0 +1,187 @@
+// libbjj_hip.so, kernel unit 2: K2 / K6 Point::mul_scalar for arbitrary points (src/lib.rs:149-164) and the raw
+// PointProjective::add / affine (src/lib.rs:88-131, 70-85).
+#include "k_common.hpp"
+
+// (n >> 3) mod l of a little-endian integer of nw words, as 8 words -> n mod 8l = 8*that + (n & 7) < 2^254.
+// Horner over 261-bit chunks, most significant first: acc <- acc * 2^261 + chunk (mod l), with the mod-l Montgomery
+// products of the signer row (fl_mul(acc, 2^522) = acc * 2^261, fl_mul(chunk, 2^261) = chunk; each < 2l).
+__device__ void wide_scalar_mod_order(const u32* __restrict__ w, int nw, u32 out[8]) {
+  const int bits = nw * 32 - 3;
+  const int chunks = (bits + 260) / 261;
+  Fr acc = fr_zero();
+#pragma unroll 1
+  for (int c = chunks - 1; c >= 0; c--) {
+    Fr hi = fl_mul(acc, c_K.L_R2, c_K);
+    Fr lo = fl_mul(limbs_from_bits(w, nw, 3 + 261 * c), c_K.L_R1, c_K);
+    acc = fl_canon4(fr_add(hi, lo), c_K);
+  }
+  u32 q[8];
+  fr_to_words(acc, q);   // < l < 2^251
+  out[0] = (q[0] << 3) | (w[0] & 7u);
+#pragma unroll
+  for (int i = 1; i < 8; i++) out[i] = (q[i] << 3) | (q[i - 1] >> 29);
+}
+
+// ---------------------------------------------------------------------------
+// K2: variable base.  Off-curve points are appended to `slow` (slow[0] = count, item indices from
+// slow[8]) and finished by K6 (bjj_k_mul_var_base_exact) right after this kernel.
+// WIDE: scalars are records of `sc_words` 32-bit words (a multiple of 8; `n: &BigInt` is unbounded, src/lib.rs:149,
+// 156-157); for an on-curve point n*P == (n mod 8l)*P exactly.
+// ---------------------------------------------------------------------------
+template <bool WIDE>
+__device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars, int sc_words,
+                                              size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch,
+                                              u32* __restrict__ vb_tables, u32* __restrict__ slow, u32* lds) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
+  Fr run = fr_one();
+#pragma unroll 1
+  for (size_t i = tid; i < n; i += nthreads) {
+    u32 w[8], sc[8];
+    load_w8(pts + i * 64, w);      Fr x = fr_to_mont_words(w);
+    load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
+    Ext p = ext_identity();
+    if (ref_on_curve(x, y, c_K)) {
+      if (WIDE) {
+        wide_scalar_mod_order((const u32*)(scalars + i * (size_t)sc_words * 4), sc_words, sc);
+        Ext P = ext_from_ref_affine(x, y, c_K);
+        vb_build_table(P, tbl, c_K);
+        p = vb_mul_windowed(tbl, sc, 64);
+      } else {
+        load_w8(scalars + i * 32, sc);
+        p = var_base_fast(x, y, sc, tbl, c_K);
+      }
+    } else {
+      slow[8 + atomicAdd(&slow[0], 1u)] = (u32)i;  // placeholder result; K6 overwrites the output
+    }
+    epilogue_stash(p, run, out + i * 64, scratch + i * 16);
+  }
+  epilogue_run(run, n, tid, nthreads, out, scratch, lds);
+}
+__global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
+                                                                const uint8_t* __restrict__ scalars, size_t n,
+                                                                uint8_t* __restrict__ out, u32* __restrict__ scratch,
+                                                                u32* __restrict__ vb_tables, u32* __restrict__ slow) {
+  __shared__ u32 lds[NL * 64];
+  var_base_body<false>(pts, scalars, 8, n, out, scratch, vb_tables, slow, lds);
+}
+__global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_var_base_wide(const uint8_t* __restrict__ pts,
+                                                                     const uint8_t* __restrict__ scalars, int sc_words, size_t n,
+                                                                     uint8_t* __restrict__ out, u32* __restrict__ scratch,
+                                                                     u32* __restrict__ vb_tables, u32* __restrict__ slow) {
+  __shared__ u32 lds[NL * 64];
+  var_base_body<true>(pts, scalars, sc_words, n, out, scratch, vb_tables, slow, lds);
+}
+// K6: exact replay of the reference's loop for the (rare) off-curve inputs, one per lane; sc_words words per scalar.
+__global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __restrict__ pts,
+                                                               const uint8_t* __restrict__ scalars, int sc_words,
+                                                               uint8_t* __restrict__ out, const u32* __restrict__ slow) {
+  const u32 cnt = slow[0];
+  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
+    const size_t i = slow[8 + j];
+    u32 w[8];
+    load_w8(pts + i * 64, w);      Fr x = fr_to_mont_words(w);
+    load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
+    Fr ox, oy;
+    ref_mul_scalar(x, y, (const u32*)(scalars + i * (size_t)sc_words * 4), sc_words, ox, oy, c_K);
+    fr_from_mont_words(ox, w); store_w8(out + i * 64, w);
+    fr_from_mont_words(oy, w); store_w8(out + i * 64 + 32, w);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// PointProjective::add on affine inputs followed by affine()  (reference-exact)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_point_add(const uint8_t* __restrict__ p, const uint8_t* __restrict__ q,
+                                                             size_t n, uint8_t* __restrict__ out) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = tid; i < n; i += nthreads) {
+    u32 w[8];
+    RefProj a, b;
+    load_w8(p + i * 64, w); a.x = fr_to_mont_words(w);
+    load_w8(p + i * 64 + 32, w); a.y = fr_to_mont_words(w); a.z = fr_one();
+    load_w8(q + i * 64, w); b.x = fr_to_mont_words(w);
+    load_w8(q + i * 64 + 32, w); b.y = fr_to_mont_words(w); b.z = fr_one();
+    RefProj r = ref_add(a, b, c_K);
+    Fr ox = fr_zero(), oy = fr_zero();
+    if (!fr_is_zero(r.z)) { Fr zi = fr_inv(r.z); ox = fr_mul(r.x, zi); oy = fr_mul(r.y, zi); }
+    fr_from_mont_words(ox, w); store_w8(out + i * 64, w);
+    fr_from_mont_words(oy, w); store_w8(out + i * 64 + 32, w);
+  }
+}
+// The raw PointProjective::add (src/lib.rs:88-131): (x, y, z) records of 96 bytes in and out, any z, no normalisation.
+// The result is the canonical value of each of the reference's three output field elements.
+__device__ __forceinline__ RefProj load_proj(const uint8_t* p) {
+  u32 w[8];
+  RefProj a;
+  load_w8(p, w);      a.x = fr_to_mont_words(w);
+  load_w8(p + 32, w); a.y = fr_to_mont_words(w);
+  load_w8(p + 64, w); a.z = fr_to_mont_words(w);
+  return a;
+}
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_proj_add(const uint8_t* __restrict__ p, const uint8_t* __restrict__ q, size_t n,
+                                                            uint8_t* __restrict__ out) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    const RefProj r = ref_add(load_proj(p + i * 96), load_proj(q + i * 96), c_K);
+    u32 w[8];
+    fr_from_mont_words(r.x, w); store_w8(out + i * 96, w);
+    fr_from_mont_words(r.y, w); store_w8(out + i * 96 + 32, w);
+    fr_from_mont_words(r.z, w); store_w8(out + i * 96 + 64, w);
+  }
+}
+// PointProjective::affine (src/lib.rs:70-85): z == 0 -> (0, 0), else (x / z, y / z).
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_proj_affine(const uint8_t* __restrict__ p, size_t n, uint8_t* __restrict__ out) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    const RefProj a = load_proj(p + i * 96);
+    Fr ox = fr_zero(), oy = fr_zero();
+    if (!fr_is_zero(a.z)) { Fr zi = fr_inv(a.z); ox = fr_mul(a.x, zi); oy = fr_mul(a.y, zi); }
+    u32 w[8];
+    fr_from_mont_words(ox, w); store_w8(out + i * 64, w);
+    fr_from_mont_words(oy, w); store_w8(out + i * 64 + 32, w);
+  }
+}
+
+namespace bjjk {
+int occ_var_base() {
+  const int a = occupancy_of(bjj_k_mul_var_base, BJJ_EPI_BLOCK), b = occupancy_of(bjj_k_mul_var_base_wide, BJJ_EPI_BLOCK);
+  return a < b ? a : b;   // one grid size (and one per-lane table allocation) serves both
+}
+int occ_point_add() {
+  const int a = occupancy_of(bjj_k_point_add, BJJ_BLOCK), b = occupancy_of(bjj_k_proj_add, BJJ_BLOCK),
+            c = occupancy_of(bjj_k_proj_affine, BJJ_BLOCK);
+  return a < b ? (a < c ? a : c) : (b < c ? b : c);
+}
+hipError_t mul_var_base(hipStream_t st, int grid, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
+                        uint8_t* out, u32* scratch, u32* vb_tables, u32* slow) {
+  hipError_t e = hipMemsetAsync(slow, 0, 8 * sizeof(u32), st);
+  if (e != hipSuccess) return e;
+  if (sc_words == 8)
+    hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow);
+  else
+    hipLaunchKernelGGL(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
+                       vb_tables, slow);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bjj_k_mul_var_base_exact, dim3(grid_exact), dim3(64), 0, st, pts, scalars, sc_words, out, slow);
+  return hipGetLastError();
+}
+hipError_t point_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out) {
+  hipLaunchKernelGGL(bjj_k_point_add, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, q, n, out);
+  return hipGetLastError();
+}
+hipError_t proj_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out) {
+  hipLaunchKernelGGL(bjj_k_proj_add, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, q, n, out);
+  return hipGetLastError();
+}
+hipError_t proj_affine(hipStream_t st, int grid, const uint8_t* p, size_t n, uint8_t* out) {
+  hipLaunchKernelGGL(bjj_k_proj_affine, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, n, out);
+  return hipGetLastError();
+}
+}  // namespace bjjk

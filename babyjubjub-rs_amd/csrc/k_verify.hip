@@ -1,0 +1,101 @@
+// libbjj_hip.so, kernel unit 4: K4, verify(pk, sig, msg) (src/lib.rs:395-412) and verify_schnorr (:375-385).
+#include "k_common.hpp"
+
+// ---------------------------------------------------------------------------
+// K4: EdDSA-Poseidon verify, two launches:
+//  (1) bjj_k_eddsa_verify_scan: on-curve tests only (14 multiplications per item); items whose
+//      pk or R is off the curve -- they need the reference's exact, ~3x longer, strictly serial
+//      formula sequence -- are appended to the work list `wl`.
+//  (2) bjj_k_eddsa_verify: waves pull work through atomic cursors: first 64-item groups of the
+//      exact list (so the long items start at t = 0 and overlap everything else), then 64-item
+//      chunks of the whole batch on the fast path.  No wave ever runs both paths for one group.
+// wl layout (u32 words): [0] exact count, [2..3] exact cursor (u64), [4..5] batch cursor (u64),
+// [8..] exact item indices.
+// ---------------------------------------------------------------------------
+#define WL_HDR 8
+__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_eddsa_verify_scan(const uint8_t* __restrict__ pk,
+                                                                     const uint8_t* __restrict__ rb8,
+                                                                     const uint8_t* __restrict__ msg, size_t n,
+                                                                     u32* __restrict__ wl) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+    VerifyIn in = {pk + i * 64, rb8 + i * 64, nullptr, msg + i * 32};
+    if (verify_needs_exact(in, c_K)) wl[WL_HDR + atomicAdd(&wl[0], 1u)] = (u32)i;
+  }
+}
+__device__ __forceinline__ unsigned long long wave_grab(u32* cursor_words, int lane) {
+  unsigned long long c = 0;
+  if (lane == 0) c = atomicAdd((unsigned long long*)cursor_words, 64ULL);
+  return __shfl(c, 0, 64);
+}
+template <bool SCHNORR>
+__device__ __forceinline__ void verify_kernel_body(const u32* __restrict__ table, int W, int nwin,
+                                                   const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
+                                                   const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg, size_t n,
+                                                   uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
+                                                   u32* __restrict__ wl) {
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_BLOCK / 64) * FB_STAGE_WORDS];
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const GatherCoopLds<1> fb = {table, stage + (threadIdx.x >> 6) * FB_STAGE_WORDS, lane};
+  u32* tbl = vb_tables + tid * VB_VERIFY_WORDS;
+  const unsigned long long nexact = wl[0];
+#pragma unroll 1
+  for (;;) {  // exact-path groups first
+    const unsigned long long c = wave_grab(wl + 2, lane);
+    if (c >= nexact) break;
+    if (c + lane < nexact) {
+      const size_t i = wl[WL_HDR + c + lane];
+      VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
+      ok[i] = (uint8_t)verify_exact_t<SCHNORR>(in, table, W, nwin, tbl, c_K);
+    }
+  }
+#pragma unroll 1
+  for (;;) {  // then the bulk
+    const unsigned long long c = wave_grab(wl + 4, lane);
+    if (c >= n) break;
+    const size_t i = c + lane, ic = i < n ? i : n - 1;  // every lane runs (cooperative gathers); the tail repeats the last item
+    VerifyIn in = {pk + ic * 64, rb8 + ic * 64, s + ic * 32, msg + ic * 32};
+    bool need_exact;
+    const int v = verify_fast_t<SCHNORR>(in, fb, W, nwin, tbl, c_K, need_exact);
+    if (i < n && !need_exact) ok[i] = (uint8_t)v;  // exact items were written by the first loop
+  }
+}
+// verify_schnorr (src/lib.rs:375-385): same structure, verdict 2 = Err (msg > Q)
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_schnorr_verify(const u32* __restrict__ table, int W, int nwin,
+                                                                     const uint8_t* __restrict__ pk,
+                                                                     const uint8_t* __restrict__ rb8,
+                                                                     const uint8_t* __restrict__ s,
+                                                                     const uint8_t* __restrict__ msg, size_t n,
+                                                                     uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
+                                                                     u32* __restrict__ wl) {
+  verify_kernel_body<true>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+}
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
+                                                                   const uint8_t* __restrict__ pk,
+                                                                   const uint8_t* __restrict__ rb8,
+                                                                   const uint8_t* __restrict__ s,
+                                                                   const uint8_t* __restrict__ msg, size_t n,
+                                                                   uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
+                                                                   u32* __restrict__ wl) {
+  verify_kernel_body<false>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+}
+
+namespace bjjk {
+int occ_verify() { return occupancy_of(bjj_k_eddsa_verify, BJJ_BLOCK); }
+int occ_verify_scan() { return occupancy_of(bjj_k_eddsa_verify_scan, BJJ_BLOCK); }
+hipError_t verify(hipStream_t st, int grid_scan, int grid, bool schnorr, const u32* table, int W, int nwin, const uint8_t* pk,
+                  const uint8_t* rb8, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok, u32* vb_tables, u32* wl) {
+  hipError_t e = hipMemsetAsync(wl, 0, WL_HDR * sizeof(u32), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_scan), dim3(BJJ_BLOCK), 0, st, pk, rb8, msg, n, wl);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (schnorr)
+    hipLaunchKernelGGL(bjj_k_schnorr_verify, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+  else
+    hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+  return hipGetLastError();
+}
+}  // namespace bjjk

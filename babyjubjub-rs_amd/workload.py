@@ -74,12 +74,23 @@ def make_signatures(fixed_base, poseidon5, n, offset=0):
 
 
 def corrupt(A, R, S, msg, n, offset=0):
-    """1 item in 64 gets one seeded bit flipped in S, msg, R.y or A.x (in place); returns the bad mask."""
+    """1 item in 64 gets one seeded bit flipped in S, msg, R.y or A.x (in place); returns the bad mask (numpy bool).
+    A, R: (n, 64), S, msg: (n, 32) uint8 -- numpy arrays or torch tensors (on any device): vectorised, so that the
+    2^24-item batch of BASELINE cfg 5 is corrupted in place in HBM."""
     r = splitmix64(SEED_BAD, n, offset)
     bad = (r & np.uint64(63)) == 0
-    which = (r >> np.uint64(6)) & np.uint64(3)
-    bit = ((r >> np.uint64(8)) % np.uint64(250)).astype(np.int64)
-    for i in np.nonzero(bad)[0]:
-        tgt = (S[i], msg[i], R[i, 32:], A[i, :32])[int(which[i])]
-        tgt[bit[i] // 8] ^= np.uint8(1 << (bit[i] % 8))
+    idx = np.nonzero(bad)[0]
+    which = ((r[idx] >> np.uint64(6)) & np.uint64(3)).astype(np.int64)
+    bit = ((r[idx] >> np.uint64(8)) % np.uint64(250)).astype(np.int64)
+    for t, (arr, col0) in enumerate(((S, 0), (msg, 0), (R, 32), (A, 0))):
+        sel = which == t
+        rows, cols = idx[sel], bit[sel] // 8 + col0
+        mask = (1 << (bit[sel] % 8)).astype(np.uint8)
+        if isinstance(arr, np.ndarray):
+            arr[rows, cols] ^= mask
+        else:  # torch tensor
+            import torch
+            ri = torch.from_numpy(rows).to(arr.device)
+            ci = torch.from_numpy(cols).to(arr.device)
+            arr[ri, ci] = arr[ri, ci] ^ torch.from_numpy(mask).to(arr.device)
     return bad

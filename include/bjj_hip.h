@@ -15,8 +15,13 @@
  *                        src/lib.rs:400-404 (poseidon-rs 0.0.8, Cargo.toml:20)
  *   bjj_eddsa_verify     verify(pk, sig, msg)        src/lib.rs:395-412
  *   bjj_schnorr_verify   verify_schnorr(pk, m, r, s) src/lib.rs:375-385 (+ schnorr_hash :364-373)
+ *   bjj_mul_var_base_wide  the same for scalars wider than 256 bits (`n: &BigInt` is unbounded,
+ *                        src/lib.rs:149, 156-157): records of scalar_bytes = 32 k bytes
  *   bjj_point_add        PointProjective::add(..).affine()
  *                        src/lib.rs:88-131 + 70-85 on affine inputs (z = 1)
+ *   bjj_proj_add         PointProjective::add(&self, q)  src/lib.rs:88-131: raw (x, y, z) in and out, any z
+ *                        (what the reference's own test chains, src/lib.rs:513-516)
+ *   bjj_proj_affine      PointProjective::affine(&self)  src/lib.rs:70-85  (z == 0 -> (0, 0))
  *   bjj_compress_points  Point::compress(&self)      src/lib.rs:166-178
  *   bjj_decompress_points decompress_point(bb)       src/lib.rs:192-224 (+ utils.rs modinv/modsqrt)
  *   bjj_scalar_keys      PrivateKey::scalar_key()    src/lib.rs:284-302 (Blake-512, prune, >> 3)
@@ -35,7 +40,14 @@
  *                  the reference's exact formula sequence
  *   scalar / s / msg  32 bytes, unsigned integer (BigInt::to_bytes_le zero-padded
  *                  to 32 bytes, as src/lib.rs:249-252 does for `s`)
+ *   projective point  96 bytes: x, y, z  (the crate's `PointProjective { x, y, z }`, src/lib.rs:62-67)
  *   ok             1 byte per item: 1 = verify() returned true, 0 = false
+ *
+ * Domain restrictions of the boundary (everything else is total, like the reference):
+ *   bjj_point_add takes affine operands (z = 1) and returns the affine sum -- use bjj_proj_add /
+ *   bjj_proj_affine for general z and the raw (x, y, z) result;  32-byte scalar entry points
+ *   take n < 2^256 -- use bjj_mul_var_base_wide beyond;  negative integers do not exist at this
+ *   boundary (the reference drops the sign of n, src/lib.rs:156, and panics on a negative msg, :399).
  *
  * Error model: the reference's functions on this path are infallible
  * (mul_scalar, add) or fold every failure into `false` (verify, src/lib.rs:396-404).
@@ -46,8 +58,18 @@
  * Batch size: any n < 2^32 per call (byte offsets are 64-bit; item indices travel as 32-bit words).
  *
  * Threading: a context is bound to one device and one internal stream; calls on
- * the same context are serialised by the caller; different contexts are
- * independent.  The library keeps no pointer past return.
+ * the same context are serialised by the caller (one host thread at a time);
+ * different contexts are independent, also across devices of one process: every
+ * entry point selects its context's device.  *_dev calls return before the work
+ * has run; the context orders them itself: each call records an event on its
+ * stream and a later call on a DIFFERENT stream first waits (on the device) for
+ * it, so the context's scratch is never used by two streams at once.  The
+ * library keeps no pointer past return.
+ *
+ * Key material: the signer-side entry points wipe every library-owned buffer the
+ * keys / nonces passed through (staging buffers, derived scalar keys) before they
+ * return, and bjj_free zeroes what is left.  They are NOT constant-time: the
+ * fixed-base table is indexed with digits of the secret scalar.
  *
  * Host entry points take host pointers and do H2D / kernel / D2H synchronously.
  * *_dev entry points take DEVICE pointers (16-byte aligned) plus a hipStream_t
@@ -71,8 +93,13 @@ enum {
   BJJ_E_INVALID = -1,   /* bad argument (NULL pointer, misaligned device pointer, ...) */
   BJJ_E_NO_DEVICE = -2, /* no usable HIP device: there is NO CPU fallback */
   BJJ_E_HIP = -3,       /* HIP runtime error, text in bjj_last_error() */
-  BJJ_E_NOMEM = -4
+  BJJ_E_NOMEM = -4,
+  BJJ_E_RCCL = -5       /* RCCL could not be loaded / a collective failed (multi-GPU entry points) */
 };
+
+#define BJJ_WINDOW_AUTO (-1)        /* bjj_init: widest fixed-base table that fits in 60 % of the free HBM */
+#define BJJ_MAX_SCALAR_BYTES 4096   /* bjj_mul_var_base_wide: scalars up to 32768 bits */
+#define BJJ_MAX_DEVICES 64
 
 /* Library / build identification: "bjj-hip <version> gfx950". */
 const char* bjj_version(void);
@@ -84,8 +111,11 @@ const char* bjj_last_error(void);
  * fixed-base window width W: scalars are reduced mod l and recoded into
  * ceil(252/W) signed digits, the table holds (2^(W-1) + 1) entries of 128 bytes per
  * window, resident in HBM (W = 16: 67 MB, 21: 1.6 GB, 23: 5.9 GB, 26: 43 GB, 28: 155 GB).
- * 0 = auto: the widest of 28 / 26 / 23 / 21 / 16 whose table fits in 60 % of the device's free
- * memory (155 GB on an otherwise empty MI355X; bjj_get_info reports the choice). Valid: 0, 4..28. */
+ * 0 = the default, W = 23 (5.9 GB): a modest footprint for a library that shares the GPU with a
+ * prover.  The wide tables are opt-in: pass 26 / 28 explicitly (28 is what bench.py measures: one
+ * addition less per digit saved), or BJJ_WINDOW_AUTO = the widest of 28 / 26 / 23 / 21 / 16 whose
+ * table fits in 60 % of the device's free memory.  bjj_get_info reports the choice and the bytes.
+ * Valid: 0, BJJ_WINDOW_AUTO, 4..28. */
 int bjj_init(int device, int window_bits, bjj_ctx** out_ctx);
 void bjj_free(bjj_ctx* ctx);
 /* Blocks until everything enqueued on the context's stream has finished. */
@@ -98,6 +128,10 @@ int bjj_mul_fixed_base(bjj_ctx* ctx, const uint8_t* scalars /* n*32 */, size_t n
                        uint8_t* out_xy /* n*64 */);
 int bjj_mul_var_base(bjj_ctx* ctx, const uint8_t* pts_xy /* n*64 */,
                      const uint8_t* scalars /* n*32 */, size_t n, uint8_t* out_xy /* n*64 */);
+/* scalars: n records of scalar_bytes (a multiple of 32, <= BJJ_MAX_SCALAR_BYTES) little-endian bytes each.  On-curve
+ * points use n mod 8l (exact: the group order); off-curve points replay the reference's loop over all n.bits() bits. */
+int bjj_mul_var_base_wide(bjj_ctx* ctx, const uint8_t* pts_xy /* n*64 */, const uint8_t* scalars /* n*scalar_bytes */,
+                          size_t scalar_bytes, size_t n, uint8_t* out_xy /* n*64 */);
 int bjj_poseidon5(bjj_ctx* ctx, const uint8_t* in /* n*160 */, size_t n, uint8_t* out /* n*32 */);
 int bjj_eddsa_verify(bjj_ctx* ctx, const uint8_t* pk_xy /* n*64 */, const uint8_t* r_xy /* n*64 */,
                      const uint8_t* s /* n*32 */, const uint8_t* msg /* n*32 */, size_t n,
@@ -109,6 +143,11 @@ int bjj_schnorr_verify(bjj_ctx* ctx, const uint8_t* pk_xy /* n*64 */, const uint
                        const uint8_t* s /* n*32 */, const uint8_t* msg /* n*32 */, size_t n, uint8_t* ok /* n */);
 int bjj_point_add(bjj_ctx* ctx, const uint8_t* p_xy /* n*64 */, const uint8_t* q_xy /* n*64 */,
                   size_t n, uint8_t* out_xy /* n*64 */);
+/* Raw PointProjective::add (src/lib.rs:88-131): 96-byte (x, y, z) records, any z, result not normalised -- the
+ * canonical values of the three field elements the reference computes.  bjj_proj_affine: src/lib.rs:70-85. */
+int bjj_proj_add(bjj_ctx* ctx, const uint8_t* p_xyz /* n*96 */, const uint8_t* q_xyz /* n*96 */, size_t n,
+                 uint8_t* out_xyz /* n*96 */);
+int bjj_proj_affine(bjj_ctx* ctx, const uint8_t* p_xyz /* n*96 */, size_t n, uint8_t* out_xy /* n*64 */);
 /* Wire format (src/lib.rs:166-178): 32 bytes = y little-endian, bit 255 = (x > (r-1)/2). */
 int bjj_compress_points(bjj_ctx* ctx, const uint8_t* pts_xy /* n*64 */, size_t n, uint8_t* out /* n*32 */);
 /* ok[i] = 1 where decompress_point returns Ok, 0 where it returns Err (y >= r, x^2 a non-residue,
@@ -142,6 +181,8 @@ int bjj_sign_schnorr(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, const uint8_t
 int bjj_mul_fixed_base_dev(bjj_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* stream);
 int bjj_mul_var_base_dev(bjj_ctx* ctx, const void* d_pts_xy, const void* d_scalars, size_t n,
                          void* d_out_xy, void* stream);
+int bjj_mul_var_base_wide_dev(bjj_ctx* ctx, const void* d_pts_xy, const void* d_scalars, size_t scalar_bytes, size_t n,
+                              void* d_out_xy, void* stream);
 int bjj_poseidon5_dev(bjj_ctx* ctx, const void* d_in, size_t n, void* d_out, void* stream);
 int bjj_eddsa_verify_dev(bjj_ctx* ctx, const void* d_pk_xy, const void* d_r_xy, const void* d_s,
                          const void* d_msg, size_t n, void* d_ok, void* stream);
@@ -149,6 +190,8 @@ int bjj_schnorr_verify_dev(bjj_ctx* ctx, const void* d_pk_xy, const void* d_r_xy
                            const void* d_msg, size_t n, void* d_ok, void* stream);
 int bjj_point_add_dev(bjj_ctx* ctx, const void* d_p_xy, const void* d_q_xy, size_t n, void* d_out_xy,
                       void* stream);
+int bjj_proj_add_dev(bjj_ctx* ctx, const void* d_p_xyz, const void* d_q_xyz, size_t n, void* d_out_xyz, void* stream);
+int bjj_proj_affine_dev(bjj_ctx* ctx, const void* d_p_xyz, size_t n, void* d_out_xy, void* stream);
 int bjj_scalar_keys_dev(bjj_ctx* ctx, const void* d_keys, size_t n, void* d_out, void* stream);
 int bjj_public_keys_dev(bjj_ctx* ctx, const void* d_keys, size_t n, void* d_out_xy, void* stream);
 int bjj_sign_dev(bjj_ctx* ctx, const void* d_keys, const void* d_msgs, size_t n, void* d_out_r_xy, void* d_out_s,
@@ -181,8 +224,43 @@ typedef struct {
   const char* kernel_var_base;
   const char* kernel_poseidon5;
   const char* kernel_verify;
+  double init_ms;           /* wall time of bjj_init (allocation + table build on the GPU) */
 } bjj_info;
 int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
+
+/* ---- multi-GPU (BASELINE.json configs[4]) -----------------------------------------
+ * The path shards with no exchange step (src/lib.rs:149-164, 395-412 have no cross-item state): a
+ * bjj_multi handle owns one context per device (replicated fixed-base table), rank i of G processes
+ * the contiguous block [i*ceil(n/G), min(n, (i+1)*ceil(n/G))) -- bjj_shard_bounds.  One process,
+ * all devices: this is the form a Rust host calls.
+ *   host-pointer form    arrays in host memory; one host thread per device drives that device's
+ *                        pinned-staging pipeline over its block.  No inter-GPU traffic.
+ *   *_multi_dev form     arrays resident in the HBM of the handle's FIRST device (rank 0 holds all
+ *                        inputs, as in BASELINE cfg 5): RCCL over xGMI scatters the input blocks in
+ *                        one ncclGroup (ncclScatter, in place at the root; exact-count ncclSend /
+ *                        ncclRecv pairs when G does not divide n), every device runs the kernels on
+ *                        its block, a second group gathers the results (ncclGather) into the
+ *                        caller's output array.  Synchronous.  RCCL is loaded with dlopen on the
+ *                        first such call (single process, ncclCommInitAll); BJJ_E_RCCL if absent. */
+typedef struct bjj_multi bjj_multi;
+/* devices: n_devices distinct HIP device indices (NULL = 0 .. n_devices-1; NULL and 0 = all visible devices). */
+int bjj_multi_init(const int* devices, int n_devices, int window_bits, bjj_multi** out);
+void bjj_multi_free(bjj_multi* m);
+int bjj_multi_size(const bjj_multi* m);
+bjj_ctx* bjj_multi_ctx(bjj_multi* m, int rank);     /* the per-device context (owned by the handle) */
+int bjj_multi_device(const bjj_multi* m, int rank); /* HIP device index of a rank */
+void bjj_shard_bounds(size_t n, int n_devices, int rank, size_t* lo, size_t* hi);
+int bjj_mul_fixed_base_multi(bjj_multi* m, const uint8_t* scalars /* n*32 */, size_t n, uint8_t* out_xy /* n*64 */);
+int bjj_mul_var_base_multi(bjj_multi* m, const uint8_t* pts_xy /* n*64 */, const uint8_t* scalars /* n*32 */, size_t n,
+                           uint8_t* out_xy /* n*64 */);
+int bjj_eddsa_verify_multi(bjj_multi* m, const uint8_t* pk_xy, const uint8_t* r_xy, const uint8_t* s, const uint8_t* msg,
+                           size_t n, uint8_t* ok /* n */);
+int bjj_mul_fixed_base_multi_dev(bjj_multi* m, const void* d_scalars, size_t n, void* d_out_xy);
+int bjj_mul_var_base_multi_dev(bjj_multi* m, const void* d_pts_xy, const void* d_scalars, size_t n, void* d_out_xy);
+int bjj_eddsa_verify_multi_dev(bjj_multi* m, const void* d_pk_xy, const void* d_r_xy, const void* d_s, const void* d_msg,
+                               size_t n, void* d_ok /* 16-byte aligned */);
+/* Phase times of the last *_multi_dev call (HIP events, max over devices), and the RCCL version in use. */
+int bjj_multi_last_timing(bjj_multi* m, double* scatter_ms, double* compute_ms, double* gather_ms, int* rccl_version);
 
 #ifdef __cplusplus
 }

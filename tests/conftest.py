@@ -166,7 +166,9 @@ def emul():
 @pytest.fixture(scope="session")
 def gpu_ctx():
     import babyjubjub_rs_amd as bjj
-    ctx = bjj.Context(0, 0)  # raises loudly if the library or the GPU is missing: no fallback
+    # the widest fixed-base table that fits (28 bits = 154.6 GB on an empty MI355X: the configuration bench.py measures);
+    # raises loudly if the library or the GPU is missing: no fallback
+    ctx = bjj.Context(0, bjj.WINDOW_AUTO)
     yield ctx
     ctx.close()
 

@@ -55,6 +55,33 @@ def test_init_argument_checks():
     h = ctypes.c_void_p()
     assert lib.bjj_init(0, 3, ctypes.byref(h)) == _lib.BJJ_E_INVALID  # window_bits out of range
     assert lib.bjj_init(0, 29, ctypes.byref(h)) == _lib.BJJ_E_INVALID
+    assert lib.bjj_init(0, -2, ctypes.byref(h)) == _lib.BJJ_E_INVALID
+
+
+def test_multi_argument_checks_and_partition():
+    """bjj_shard_bounds is pure host arithmetic: contiguous ceil(n/G) blocks, ragged tails, empty ranks"""
+    import torch
+    from babyjubjub_rs_amd import _lib
+    from babyjubjub_rs_amd import workload as w
+    lib = _lib.load()
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    for g in range(1, 9):
+        for n in (0, 1, 7, 8, 9, 37, 1000, (1 << 20) + 333, 1 << 24):
+            covered = 0
+            for r in range(g):
+                lib.bjj_shard_bounds(n, g, r, ctypes.byref(lo), ctypes.byref(hi))
+                assert (lo.value, hi.value) == w.shard_bounds(n, g, r)
+                assert lo.value == covered or lo.value == hi.value == n
+                assert hi.value - lo.value <= -(-n // g)
+                covered = hi.value
+            assert covered == n
+    h = ctypes.c_void_p()
+    assert lib.bjj_multi_init(None, 1, 0, None) == _lib.BJJ_E_INVALID
+    if not torch.cuda.is_available():
+        assert lib.bjj_multi_init(None, 1, 0, ctypes.byref(h)) == _lib.BJJ_E_NO_DEVICE and not h.value
+    assert lib.bjj_mul_fixed_base_multi(None, None, 4, None) == _lib.BJJ_E_INVALID
+    assert lib.bjj_eddsa_verify_multi_dev(None, None, None, None, None, 4, None) == _lib.BJJ_E_INVALID
+    assert lib.bjj_multi_size(None) == 0 and lib.bjj_multi_device(None, 0) == -1
 
 
 def test_marshalling_helpers():
@@ -71,7 +98,17 @@ def test_marshalling_helpers():
     # reference-shaped objects
     p = api.Point(api.Q + 5, 7)
     assert p.x == 5 and p.projective().z == 1 and p.equals(api.Point(5, 7))
-    assert api.PointProjective(1, 2, 0).affine().equals(api.Point(0, 0))  # lib.rs:71-76
+    assert api.PointProjective(api.Q + 1, 2, 3).x == 1
+    # little-endian unsigned limbs are reinterpreted, everything else that is not bytes is refused (no value cast)
+    limbs = np.array([[1, 0, 0, 0], [2, 0, 0, 1 << 63]], dtype=np.uint64)
+    b = api._as_u8(limbs, 32, "s")
+    assert b.size == 64 and b[0] == 1 and b[32] == 2 and b[63] == 0x80
+    with pytest.raises(api.BjjError):
+        api._as_u8(np.zeros((2, 4), np.int64), 32, "s")
+    with pytest.raises(api.BjjError):
+        api._as_u8(np.zeros((2, 8), np.float32), 32, "s")
+    with pytest.raises(api.BjjError):
+        api._as_u8(np.zeros((2, 4), ">u8"), 32, "s")
     # verify(): msg > Q is false before anything touches the device (lib.rs:396-398)
     sig = api.Signature(api.Point(0, 1), 0)
     assert api.verify(api.Point(0, 1), sig, api.Q + 1, ctx=object()) is False
@@ -91,7 +128,8 @@ def test_library_is_not_older_than_its_sources():
     """a stale libbjj_hip.so (sources edited, library not rebuilt) invalidates every GPU measurement"""
     d = os.path.join(ROOT, "babyjubjub-rs_amd", "csrc")
     so = os.path.join(d, "libbjj_hip.so")
-    srcs = ["bjj_hip.hip", "fr.hpp", "fr_mul_columns.inc", "curve.hpp", "poseidon.hpp", "bjj_device.hpp", "sign.hpp",
-            "bjj_constants.inc", os.path.join("..", "..", "include", "bjj_hip.h")]
+    srcs = ["bjj_hip.hip", "bjj_multi.inc", "bjj_launch.hpp", "k_common.hpp", "k_fixed.hip", "k_var.hip", "k_hash_codec.hip",
+            "k_verify.hip", "k_sign.hip", "fr.hpp", "fr_mul_columns.inc", "curve.hpp", "poseidon.hpp", "bjj_device.hpp",
+            "sign.hpp", "bjj_constants.inc", os.path.join("..", "..", "include", "bjj_hip.h")]
     newest = max(os.path.getmtime(os.path.join(d, s)) for s in srcs)
     assert os.path.getmtime(so) >= newest, "rebuild: python -c 'import __graft_entry__ as g; g.build()'"

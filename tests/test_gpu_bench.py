@@ -1,0 +1,53 @@
+"""bench.py's N > 1 path on the single-GPU box: `python bench.py --gpus 2` must start its two ranks itself (child
+processes, before the parent touches a GPU), shard the batch, and report n_gpus == 2.  The ranks share the one GPU through
+the developer mode (gloo; RCCL refuses two ranks per device); on an N-GPU box the same command needs no launcher either."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra, env_extra=None, timeout=1200):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_2_self_launch_shared_gpu():
+    r, j = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--warmup-seconds", "0", "--batch", "65536", "--batches", "2",
+                 "--window-bits", "16", "--strong-total", str(1 << 18), "--no-cpu-baseline"],
+                {"BJJ_BENCH_SHARE_GPU": "1", "BJJ_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and len(j["devices"]) == 2 and j["backend"] == "gloo"
+    assert j["parity_sample_ok"] is True and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["global_batch"] == 2 * 65536
+    assert j["also"]["verify"]["parity_sample_ok"] and j["also"]["var_base"]["parity_sample_ok"]
+    s = j["strong"]
+    assert s["fixed_base_1M_total"]["total_items"] == 1 << 20
+    assert s["verify_total"]["total_items"] == 1 << 18 and s["verify_total"]["rank0_resident"]["gathered_verdicts_ok"]
+
+
+def test_bench_rejects_world_size_mismatch():
+    r, j = _run(["--gpus", "2", "--no-also", "--no-strong"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, 300)
+    assert r.returncode != 0 and j is None and "WORLD_SIZE=1 but --gpus 2" in r.stderr
+
+
+def test_bench_one_gpu_line_has_every_block():
+    r, j = _run(["--steps", "20", "--warmup", "5", "--warmup-seconds", "0.2", "--batch", str(1 << 16), "--window-bits", "16",
+                 "--strong-total", str(1 << 18)])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert j["n_gpus"] == 1 and j["parity_sample_ok"] and j["roofline"]["frac"] > 0 and j["cpu_baseline"]["value"] > 0
+    assert j["rotating_batches"] == 4 and j["single_batch_kernel_ms"] > 0
+    for k in ("verify", "var_base"):
+        assert j["also"][k]["roofline"]["kernel_ms_avg"] > 0 and j["also"][k]["cpu_baseline"]["cores"] >= 1
+    assert j["also"]["fixed_base_window_bits_23"]["parity_sample_ok"]
+    assert j["config"]["init_ms"] > 0 and j["config"]["table_bytes"] > 0

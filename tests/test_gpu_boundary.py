@@ -1,0 +1,258 @@
+"""Round-2 boundary additions through the C ABI, against the oracle: raw PointProjective::add / affine for any z
+(src/lib.rs:88-131, 70-85, chained as in the reference's own test :513-516), scalars wider than 256 bits
+(`n: &BigInt`, src/lib.rs:149, 156-157), the default / automatic table width, ordering of calls on different
+streams, and the multi-GPU handle (bjj_multi_*: partition, host-pointer form, RCCL scatter/gather form).
+Needs a real MI355X: run with `pytest -m gpu`."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import pack, unpack
+
+pytestmark = pytest.mark.gpu
+
+Q = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+L = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+B8 = (5299619240641551281634865583518297030282874472190772894086521144482721001553,
+      16950150798460657717958625567821834550301663161624707787222815936182638968203)
+
+
+def _proj_add_oracle(oracle, p, q):
+    out = np.empty_like(p)
+    for i in range(p.shape[0]):
+        oracle.lib.bjjref_proj_add(oracle._p(p[i]), oracle._p(q[i]), oracle._p(out[i]))
+    return out
+
+
+def _proj_affine_oracle(oracle, p):
+    out = np.empty((p.shape[0], 64), np.uint8)
+    for i in range(p.shape[0]):
+        oracle.lib.bjjref_proj_affine(oracle._p(p[i]), oracle._p(out[i]))
+    return out
+
+
+def _mul_scalar_oracle(oracle, pts, scalars, nbytes):
+    out = np.empty((pts.shape[0], 64), np.uint8)
+    for i in range(pts.shape[0]):
+        oracle.lib.bjjref_mul_scalar(oracle._p(pts[i]), oracle._p(scalars[i]), ctypes.c_size_t(nbytes), oracle._p(out[i]))
+    return out
+
+
+# ---------------------------------------------------------------- PointProjective::add / affine, any z
+def test_proj_add_and_affine_general_z(gpu_ctx, oracle):
+    from babyjubjub_rs_amd import workload as w
+    n = 777
+    p = w.random_u256(0x5052, 3 * n, 0, top_bits_cleared=3).reshape(n, 96).copy()   # arbitrary (x, y, z): off the curve too
+    q = w.random_u256(0x5053, 3 * n, 0, top_bits_cleared=3).reshape(n, 96).copy()
+    p[5, 64:] = 0                       # z == 0
+    q[6, 64:] = 0
+    p[7] = 0                            # all zero
+    p[8, :32] = 0xFF                    # x >= r: reduced like Fr::from_repr would refuse -- the ABI reduces mod r
+    # on-curve operands with z != 1: (x*z, y*z, z)
+    sc = w.scalars_254(64)
+    aff = gpu_ctx.mul_fixed_base(sc)
+    for i in range(64):
+        x, y = unpack(aff[i], 2)[0]
+        z = int.from_bytes(p[100 + i, 64:].tobytes(), "little") % Q or 1
+        p[100 + i] = pack([(x * z % Q, y * z % Q, z)])
+    got = gpu_ctx.proj_add(p, q)
+    want = _proj_add_oracle(oracle, p, q)
+    assert (got == want).all()
+    ga = gpu_ctx.proj_affine(np.concatenate([p, got]))
+    assert (ga == _proj_affine_oracle(oracle, np.concatenate([p, got]))).all()
+    assert (ga[5] == 0).all() and (ga[7] == 0).all()           # z == 0 -> (0, 0), src/lib.rs:71-76
+    assert (ga[100:164] == aff).all()                          # (xz, yz, z) -> (x, y)
+
+
+def test_reference_chained_add_equals_mul_scalar_3(gpu_ctx, golden):
+    """src/lib.rs:513-516: p.mul_scalar(3) == p.projective().add(&p.projective()).add(&p.projective()).affine() -- the
+    second add has a z != 1 operand, which is why the raw (x, y, z) entry point exists."""
+    import babyjubjub_rs_amd as bjj
+    b = golden["reference_kats"]["bench_inputs"]
+    p = bjj.Point(int(b["p"][0], 16) if isinstance(b["p"][0], str) else b["p"][0],
+                  int(b["p"][1], 16) if isinstance(b["p"][1], str) else b["p"][1])
+    two = p.projective().add(p.projective(), ctx=gpu_ctx)
+    assert two.z != 1
+    three = two.add(p.projective(), ctx=gpu_ctx)
+    r = p.mul_scalar(3, ctx=gpu_ctx)
+    assert three.affine(ctx=gpu_ctx).equals(r)
+    assert bjj.PointProjective(1, 2, 0).affine(ctx=gpu_ctx).equals(bjj.Point(0, 0))
+
+
+# ---------------------------------------------------------------- scalars wider than 256 bits
+@pytest.mark.parametrize("nbytes", [64, 128, 352])
+def test_wide_scalars_on_and_off_curve(gpu_ctx, oracle, nbytes):
+    from babyjubjub_rs_amd import workload as w
+    n = 130
+    k = nbytes // 32
+    sc = w.random_u256(0x5749 + nbytes, k * n).reshape(n, nbytes).copy()
+    sc[0] = 0                                   # zero scalar -> (0, 1)
+    sc[1] = 0; sc[1, 0] = 1                     # one
+    sc[2, 32:] = 0                              # fits in 256 bits
+    sc[3] = 0xFF                                # all ones
+    pts = gpu_ctx.mul_fixed_base(w.scalars_254(n, offset=77)).copy()
+    pts[10::13, 0] ^= 1                         # off the curve: the device replays all n.bits() bits of src/lib.rs:157-162
+    pts[4] = pack([(0, 1)])                     # identity
+    pts[5] = pack([(0, Q - 1)])                 # order 2
+    got = gpu_ctx.mul_var_base_wide(pts, sc, nbytes)
+    want = _mul_scalar_oracle(oracle, pts, sc, nbytes)
+    assert (got == want).all(), np.nonzero((got != want).any(axis=1))[0][:8]
+    # the 32-byte record through the wide entry is the plain entry
+    assert (gpu_ctx.mul_var_base_wide(pts, sc[:, :32].copy(), 32) == gpu_ctx.mul_var_base(pts, sc[:, :32].copy())).all()
+
+
+def test_point_mul_scalar_wide_bigint(gpu_ctx, pyoracle):
+    import babyjubjub_rs_amd as bjj
+    n = (1 << 1023) + 0x1234567 * (1 << 300) + 99
+    p = bjj.Point(*B8)
+    r = p.mul_scalar(n, ctx=gpu_ctx)
+    assert (r.x, r.y) == pyoracle.mul_scalar(B8, n) == pyoracle.mul_scalar(B8, n % (8 * L))
+    assert p.mul_scalar(-n, ctx=gpu_ctx).equals(r)      # sign dropped, src/lib.rs:156
+    with pytest.raises(bjj.BjjError):
+        gpu_ctx.mul_var_base_wide(pack([B8]), np.zeros(48, np.uint8), 48)      # not a multiple of 32
+
+
+# ---------------------------------------------------------------- table width: default is modest, wide is opt-in
+def test_default_window_is_modest(gpu_ctx, oracle):
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    ctx = bjj.Context(0)
+    try:
+        info = ctx.info()
+        assert info.window_bits == 23 and info.table_bytes == 11 * ((1 << 22) + 1) * 128 < 6 << 30
+        assert info.init_ms > 0
+        sc = w.scalars_254(500, offset=31)
+        assert (ctx.mul_fixed_base(sc) == oracle.mul_fixed_base(sc)).all()
+    finally:
+        ctx.close()
+
+
+# ---------------------------------------------------------------- calls on different streams are ordered by the context
+def test_calls_on_two_streams_share_scratch_safely(gpu_ctx, oracle):
+    """verify (stream A) and variable-base (stream B) both use the context's work list / per-lane tables; the second call is
+    enqueued while the first is still running.  The context inserts the cross-stream dependency itself."""
+    import torch
+    from babyjubjub_rs_amd import workload as w
+    dev = torch.device("cuda", 0)
+    n = 1 << 16
+    A, R, S, msg = w.make_signatures(gpu_ctx.mul_fixed_base, gpu_ctx.poseidon5, n)
+    bad = w.corrupt(A, R, S, msg, n)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)  # noqa: E731
+    d_pk, d_r, d_s, d_m = up(A), up(R), up(S), up(msg)
+    sc = w.scalars_254(n, offset=5)
+    d_sc = up(sc)
+    d_ok = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    d_out2 = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        gpu_ctx.eddsa_verify_dev(d_pk.data_ptr(), d_r.data_ptr(), d_s.data_ptr(), d_m.data_ptr(), n, d_ok.data_ptr(), sa.cuda_stream)
+        gpu_ctx.mul_var_base_dev(d_pk.data_ptr(), d_sc.data_ptr(), n, d_out.data_ptr(), sb.cuda_stream)
+        gpu_ctx.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out2.data_ptr(), sa.cuda_stream)
+    gpu_ctx.sync()      # also waits for work enqueued on a caller's stream
+    torch.cuda.synchronize()
+    assert (d_ok.cpu().numpy() == (~bad).astype(np.uint8)).all()
+    idx = np.arange(0, n, 61)
+    assert (d_out.cpu().numpy().reshape(n, 64)[idx] == oracle.mul_var_base(A[idx], sc[idx])).all()
+    assert (d_out2.cpu().numpy().reshape(n, 64)[idx] == oracle.mul_fixed_base(sc[idx])).all()
+
+
+# ---------------------------------------------------------------- multi-GPU handle
+def _multi(devs):
+    import babyjubjub_rs_amd as bjj
+    return bjj.MultiContext(devs, 16)       # a small table per device keeps the test light
+
+
+@pytest.mark.parametrize("n", [1, 64, 4099])
+def test_multi_host_form_one_device(oracle, n):
+    from babyjubjub_rs_amd import workload as w
+    m = _multi([0])
+    try:
+        assert m.size == 1 and m.device(0) == 0 and m.shard_bounds(n, 0) == (0, n)
+        sc = w.scalars_254(n, offset=11)
+        fb = m.mul_fixed_base(sc)
+        assert (fb == oracle.mul_fixed_base(sc)).all()
+        assert (m.mul_var_base(fb, sc) == oracle.mul_var_base(fb, sc)).all()
+        A, R, S, msg = w.make_signatures(oracle.mul_fixed_base, oracle.poseidon5, n)
+        bad = w.corrupt(A, R, S, msg, n)
+        assert (m.eddsa_verify(A, R, S, msg) == (~bad).astype(np.uint8)).all()
+    finally:
+        m.close()
+
+
+def test_multi_dev_form_rccl_one_device(oracle):
+    """G = 1 through the device-resident entry points: RCCL is loaded (dlopen), ncclCommInitAll creates the clique, the
+    grouped ncclScatter / ncclGather run in place at the root, the kernels run on the caller's buffers."""
+    import torch
+    from babyjubjub_rs_amd import workload as w
+    dev = torch.device("cuda", 0)
+    m = _multi([0])
+    try:
+        n = 5000
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)  # noqa: E731
+        sc = w.scalars_254(n, offset=3)
+        d_sc = up(sc)
+        d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        m.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out.data_ptr())
+        fb = d_out.cpu().numpy().reshape(n, 64)
+        assert (fb == oracle.mul_fixed_base(sc)).all()
+        t = m.last_timing()
+        assert t["rccl_version"] > 0 and t["compute_ms"] > 0
+        d_out2 = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        m.mul_var_base_dev(d_out.data_ptr(), d_sc.data_ptr(), n, d_out2.data_ptr())
+        assert (d_out2.cpu().numpy().reshape(n, 64) == oracle.mul_var_base(fb, sc)).all()
+        A, R, S, msg = w.make_signatures(oracle.mul_fixed_base, oracle.poseidon5, n)
+        bad = w.corrupt(A, R, S, msg, n)
+        d_ok = torch.empty(n, dtype=torch.uint8, device=dev)
+        m.eddsa_verify_dev(up(A).data_ptr(), up(R).data_ptr(), up(S).data_ptr(), up(msg).data_ptr(), n, d_ok.data_ptr())
+        assert (d_ok.cpu().numpy() == (~bad).astype(np.uint8)).all()
+    finally:
+        m.close()
+
+
+def test_multi_all_devices_scatter_gather(oracle):
+    """every visible device (the driver's 8-GPU box; skipped on a 1-GPU box): ragged and even batches through both forms"""
+    import torch
+    from babyjubjub_rs_amd import workload as w
+    g = torch.cuda.device_count()
+    if g < 2:
+        pytest.skip("needs at least two GPUs")
+    m = _multi(None)
+    dev = torch.device("cuda", m.device(0))
+    try:
+        assert m.size == g
+        for n in (g * 1000, g * 1000 + 7, 3):
+            sc = w.scalars_254(n, offset=n)
+            want = oracle.mul_fixed_base(sc)
+            assert (m.mul_fixed_base(sc) == want).all()
+            d_sc = torch.from_numpy(sc.reshape(-1)).to(dev)
+            d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+            m.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out.data_ptr())
+            assert (d_out.cpu().numpy().reshape(n, 64) == want).all()
+    finally:
+        m.close()
+
+
+def test_two_contexts_on_two_devices_in_one_process(oracle):
+    """every *_dev entry selects its context's device: a context on GPU 1 next to one on GPU 0 (skipped on a 1-GPU box)"""
+    import torch
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs at least two GPUs")
+    c0, c1 = bjj.Context(0, 16), bjj.Context(1, 16)
+    try:
+        n = 3000
+        inp = w.random_u256(w.SEED_MSGS, 5 * n, 0, top_bits_cleared=3).reshape(n, 160)
+        for c, d in ((c1, 1), (c0, 0), (c1, 1)):
+            dev = torch.device("cuda", d)
+            d_in = torch.from_numpy(inp.reshape(-1)).to(dev)
+            d_out = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+            torch.cuda.set_device(0)            # the caller's current device is NOT the context's
+            c.poseidon5_dev(d_in.data_ptr(), n, d_out.data_ptr(), 0)
+            c.sync()
+            assert (d_out.cpu().numpy().reshape(n, 32) == oracle.poseidon5(inp)).all()
+    finally:
+        c0.close(); c1.close()

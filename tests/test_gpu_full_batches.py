@@ -1,0 +1,112 @@
+"""BASELINE.json configs[1..4] at their full size, EVERY item byte-compared with the threaded C oracle (SURVEY.md 8d:
+"100 % byte-compare"), plus configs[4]'s shape -- 2^24 verifications as 8 contiguous 2^21-item shards -- on one GPU.
+The oracle needs ~10-30 s per 2^20-item batch on the GPU box's host cores.  Needs a real MI355X (`pytest -m gpu`)."""
+import numpy as np
+import pytest
+
+from conftest import pack
+
+pytestmark = pytest.mark.gpu
+
+L = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+N = 1 << 20
+
+
+def _mismatches(got, want):
+    bad = np.nonzero((got != want).reshape(got.shape[0], -1).any(axis=1))[0]
+    return bad.size, bad[:8].tolist()
+
+
+def test_cfg2_fixed_base_1m_every_item(gpu_ctx, oracle):
+    """configs[1]: 2^20 fixed-base multiplications (src/lib.rs:149-164 with self = B8), all 2^20 outputs vs the oracle."""
+    from babyjubjub_rs_amd import workload as w
+    sc = w.scalars_254(N)
+    got = gpu_ctx.mul_fixed_base(sc)
+    assert _mismatches(got, oracle.mul_fixed_base(sc)) == (0, [])
+
+
+def cfg3_points(gpu_ctx, pyoracle, n, offset=0):
+    """SURVEY.md 8d cfg 3: P_i = k_i*B8 + c_i*T (k_i < l, c_i in 0..7, T of order 8: the full group), every 97th point
+    pushed off the curve."""
+    from babyjubjub_rs_amd import workload as w
+    k = w.from_ints([v % L for v in w.to_ints(w.random_u256(w.SEED_POINTS, n, offset))])
+    c = (w.splitmix64(w.SEED_POINTS ^ 0x77, n, offset) & np.uint64(7)).astype(np.int64)
+    tors = pack([pyoracle.mul_scalar(pyoracle.T8, j) for j in range(8)]).reshape(8, 64)
+    pts = gpu_ctx.point_add(gpu_ctx.mul_fixed_base(k), tors[c]).copy()
+    pts[::97, 0] ^= 1
+    return pts
+
+
+def test_cfg3_var_base_1m_every_item(gpu_ctx, oracle, pyoracle):
+    """configs[2]: 2^20 variable-base multiplications on random points of the whole group (cofactor components
+    included) with every 97th point off the curve (exact-replay path), all outputs vs the oracle."""
+    from babyjubjub_rs_amd import workload as w
+    pts = cfg3_points(gpu_ctx, pyoracle, N)
+    idx = np.arange(0, N, 4099)
+    on = np.array([pyoracle.on_curve((int.from_bytes(pts[i, :32].tobytes(), "little"), int.from_bytes(pts[i, 32:].tobytes(), "little")))
+                   for i in idx])
+    assert (on == (idx % 97 != 0)).all()        # the generator did what it says (group points, off-curve every 97th)
+    sc = w.scalars_254(N)
+    got = gpu_ctx.mul_var_base(pts, sc)
+    assert _mismatches(got, oracle.mul_var_base(pts, sc)) == (0, [])
+
+
+def test_cfg4_verify_1m_every_item(gpu_ctx, oracle):
+    """configs[3]: 2^20 EdDSA-Poseidon verifications, 1/64 corrupted: every verdict vs the oracle and vs the known mask."""
+    from babyjubjub_rs_amd import workload as w
+    A, R, S, msg = w.make_signatures(gpu_ctx.mul_fixed_base, gpu_ctx.poseidon5, N)
+    bad = w.corrupt(A, R, S, msg, N)
+    got = gpu_ctx.eddsa_verify(A, R, S, msg)
+    assert (got == (~bad).astype(np.uint8)).all()
+    assert _mismatches(got, oracle.verify(A, R, S, msg)) == (0, [])
+
+
+def test_poseidon_1m_every_item(gpu_ctx, oracle):
+    from babyjubjub_rs_amd import workload as w
+    inp = w.random_u256(w.SEED_MSGS, 5 * N, 0).reshape(N, 160)      # full 256-bit inputs: reduced mod r on both sides
+    got = gpu_ctx.poseidon5(inp)
+    assert _mismatches(got, oracle.poseidon5(inp)) == (0, [])
+
+
+def test_cfg5_shape_16m_verifies_as_8_shards(gpu_ctx, oracle):
+    """configs[4]: 2^24 verifications partitioned exactly as bjj_multi / bench.py partition them over 8 devices --
+    contiguous ceil(n/8) blocks -- executed here as 8 sequential shards on ONE GPU (the driver's 8-GPU box runs them
+    side by side).  Signatures are produced on the device by the (oracle-checked) signer kernels; every verdict must
+    equal the corruption mask, and a sample of every shard goes through the oracle."""
+    import torch
+    from babyjubjub_rs_amd import workload as w
+    from babyjubjub_rs_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    n, G = 1 << 24, 8
+    total_ok = 0
+    for r in range(G):
+        lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+        lib.bjj_shard_bounds(n, G, r, ctypes.byref(lo), ctypes.byref(hi))
+        lo, m = lo.value, hi.value - lo.value
+        assert m == 1 << 21
+        keys = torch.from_numpy(w.random_u256(w.SEED_KEYS, m, lo).reshape(-1)).to(dev)
+        msg_h = w.random_u256(w.SEED_MSGS, m, lo, top_bits_cleared=3)
+        msgs = torch.from_numpy(msg_h.reshape(-1)).to(dev)
+        d_A = torch.empty(m * 64, dtype=torch.uint8, device=dev)
+        d_R = torch.empty(m * 64, dtype=torch.uint8, device=dev)
+        d_S = torch.empty(m * 32, dtype=torch.uint8, device=dev)
+        d_f = torch.empty(m, dtype=torch.uint8, device=dev)
+        d_ok = torch.empty(m, dtype=torch.uint8, device=dev)
+        gpu_ctx.public_keys_dev(keys.data_ptr(), m, d_A.data_ptr(), 0)
+        gpu_ctx.sign_dev(keys.data_ptr(), msgs.data_ptr(), m, d_R.data_ptr(), d_S.data_ptr(), d_f.data_ptr(), 0)
+        gpu_ctx.sync()
+        assert bool(d_f.all())
+        A, R, S = (t.cpu().numpy() for t in (d_A.view(m, 64), d_R.view(m, 64), d_S.view(m, 32)))
+        bad = w.corrupt(A, R, S, msg_h, m, lo)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)  # noqa: E731
+        t_A, t_R, t_S, t_m = up(A), up(R), up(S), up(msg_h)
+        gpu_ctx.eddsa_verify_dev(t_A.data_ptr(), t_R.data_ptr(), t_S.data_ptr(), t_m.data_ptr(), m, d_ok.data_ptr(), 0)
+        gpu_ctx.sync()
+        got = d_ok.cpu().numpy()
+        assert (got == (~bad).astype(np.uint8)).all(), r
+        idx = np.arange(r, m, 8191)
+        assert (got[idx] == oracle.verify(A[idx], R[idx], S[idx], msg_h[idx])).all()
+        total_ok += int(got.sum())
+    assert n - n // 48 > total_ok > n - n // 80     # ~1/64 of the 2^24 signatures were corrupted

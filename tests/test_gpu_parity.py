@@ -243,7 +243,7 @@ def test_independent_contexts_on_concurrent_threads(oracle):
 
 
 def test_automatic_window_width_and_second_context(gpu_ctx, oracle):
-    """window_bits = 0 picks the widest table that fits in 60 % of the free device memory: the session's context got
+    """BJJ_WINDOW_AUTO picks the widest table that fits in 60 % of the free device memory: the session's context got
     28 bits (154.6 GB) on an empty MI355X, a second automatic context next to it must settle for a narrower table
     (never fail), verify its own table, and agree bit for bit -- also through the cooperative gathers of the verify and
     sign kernels, with batch sizes that leave partially filled waves."""
@@ -251,7 +251,7 @@ def test_automatic_window_width_and_second_context(gpu_ctx, oracle):
     from babyjubjub_rs_amd import workload
     first = gpu_ctx.info()
     assert first.window_bits in (28, 26, 23, 21, 16) and first.n_windows == -(-252 // first.window_bits)
-    ctx = bjj.Context(0, 0)
+    ctx = bjj.Context(0, bjj.WINDOW_AUTO)
     try:
         info = ctx.info()
         assert info.window_bits in (26, 23, 21, 16) or first.window_bits < 28

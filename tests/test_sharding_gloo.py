@@ -48,22 +48,31 @@ def _worker(rank, ws, port, n, q):
             q.put(("shard0_ok", bool((mine == want[lo:hi]).all())))
         else:
             want = orc.mul_fixed_base(workload.scalars_254(n))
-            q.put(("shard1_ok", bool((mine == want[lo:hi]).all())))
+            q.put(("shard%d_ok" % rank, bool((mine == want[lo:hi]).all())))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_scatter_compute_gather_world2():
+def _run_world(ws, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    n = 37  # ragged: not a multiple of the world size
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, n, q)) for r in range(ws)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
-    got = dict(q.get(timeout=5) for _ in range(3))
-    assert got == {"gather_ok": True, "shard0_ok": True, "shard1_ok": True}
+    return dict(q.get(timeout=5) for _ in range(ws + 1))
+
+
+def test_scatter_compute_gather_world2():
+    # ragged: 37 is not a multiple of the world size -- exact block sizes travel, nothing is padded
+    assert _run_world(2, 37) == {"gather_ok": True, "shard0_ok": True, "shard1_ok": True}
+
+
+def test_scatter_compute_gather_world3_with_an_empty_rank():
+    # n = 2 over 3 ranks: blocks [0,1) [1,2) and an EMPTY block for rank 2 (no message is posted for it)
+    assert _run_world(3, 2) == {"gather_ok": True, "shard0_ok": True, "shard1_ok": True, "shard2_ok": True}
+    assert _run_world(3, 36) == {"gather_ok": True, "shard0_ok": True, "shard1_ok": True, "shard2_ok": True}

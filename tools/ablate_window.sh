@@ -3,7 +3,7 @@
 # plus the PCIe-inclusive rate of the host-pointer API.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 for W in ${WIDTHS:-12 14 16 17 18 20 21 23 26}; do
-  python3 bench.py --workload fixed_base --window-bits $W --steps 10 --warmup 2 --no-cpu-baseline --no-also 2>/dev/null | python3 -c "
+  python3 bench.py --workload fixed_base --window-bits $W --steps 10 --warmup 2 --no-cpu-baseline --no-also --no-strong 2>/dev/null | python3 -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):

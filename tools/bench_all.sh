@@ -2,7 +2,7 @@
 # Developer tool: one compact line per workload (value, ms/step, parity) on a GPU box.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 for WL in ${@:-fixed_base var_base poseidon5 verify}; do
-  python3 bench.py --workload $WL --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-also 2>/dev/null | python3 -c "
+  python3 bench.py --workload $WL --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-also --no-strong 2>/dev/null | python3 -c "
 import sys, json
 for line in sys.stdin:
     line=line.strip()

@@ -5,9 +5,9 @@ TAG=${1:-r01}; WL=${2:-fixed_base}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
-python3 bench.py --workload $WL --no-also > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; tail -c 3000 $OUT/bench_$WL.json
+python3 bench.py --workload $WL --no-also --no-strong > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; tail -c 3000 $OUT/bench_$WL.json
 export TMPDIR=/tmp
-ARGS="bench.py --workload $WL --no-cpu-baseline --no-also"   # same steps / warm-up as the default bench line
+ARGS="bench.py --workload $WL --no-cpu-baseline --no-also --no-strong"   # same steps / warm-up as the default bench line
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_$WL -o trace -- python3 $ARGS > $OUT/trace_$WL.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$WL -o pmc -- python3 $ARGS > $OUT/pmc_fetch_$WL.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$WL -o pmc -- python3 $ARGS > $OUT/pmc_write_$WL.log 2>&1
