@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbjj_hip.so")
+# BJJ_LIB_PATH: developer override for interleaved A/B runs of several builds (tools/ab_*.sh) -- never a fallback
+LIB_PATH = os.environ.get("BJJ_LIB_PATH") or os.path.join(_HERE, "csrc", "libbjj_hip.so")
 
 BJJ_OK = 0
 BJJ_E_INVALID = -1
@@ -54,6 +55,31 @@ class BjjInfo(ctypes.Structure):
     ]
 
 
+class _Stub:
+    """placeholder for a symbol an older A/B build does not export: calling it raises"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __call__(self, *a):
+        raise AttributeError("%s is not exported by %s" % (self.name, LIB_PATH))
+
+
+class _Tolerant:
+    """attribute access that survives missing symbols (only used with BJJ_LIB_PATH, for A/B runs against older builds)"""
+
+    def __init__(self, lib):
+        object.__setattr__(self, "_lib", lib)
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._lib, name)
+        except AttributeError:
+            stub = _Stub(name)
+            object.__setattr__(self, name, stub)
+            return stub
+
+
 def load():
     # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  If torch is going to
     # be used in this process (device memory / streams / torch.distributed), it must be the
@@ -68,7 +94,7 @@ def load():
         raise ImportError(
             "libbjj_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C babyjubjub-rs_amd/csrc`. There is no CPU fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = _Tolerant(ctypes.CDLL(LIB_PATH)) if os.environ.get("BJJ_LIB_PATH") else ctypes.CDLL(LIB_PATH)
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     lib.bjj_version.restype = ctypes.c_char_p
     lib.bjj_last_error.restype = ctypes.c_char_p

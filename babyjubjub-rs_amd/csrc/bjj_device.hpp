@@ -42,12 +42,28 @@ BJJ_HD void store_niels(u32* p, const Niels& n) {
   q[6] = U4{n.t2d.v[6], n.t2d.v[7], n.t2d.v[8], 0};
   q[7] = U4{0, 0, 0, 0};
 }
-// ---- per-lane variable-base table: entry = PNiels in 36 words (144 B) ---------
+// ---- per-lane variable-base table -------------------------------------------------------------------
+// {0..8} * P in projective-Niels form, an entry = the raw 4 x 9 limb words (144 B, nine 16-byte quarters).
+// -DBJJ_PNIELS_PACKED=1 is the measured-and-rejected alternative: four 256-bit integers per entry (128 B = one cache
+// line; Y-X weakly reduced first so that every component is below 2^256) and no stored identity (digit 0 selects the
+// constant (1, 1, 0, 2)): 1 KB instead of 1 296 B per lane and table, ~40 % less HBM-side traffic -- and 1.3 % (variable
+// base) / 3 % (verify) SLOWER, because the unpacking costs ~100 plain instructions per entry in a kernel that is bound by
+// VALU issue, not by bytes (profiles/r02_ab_pniels_packed_rejected.txt).
+#if !defined(BJJ_PNIELS_PACKED)
 constexpr int PNIELS_WORDS = 36;
 constexpr int VB_TABLE_ENTRIES = 9;  // 0*P .. 8*P
+#else
+constexpr int PNIELS_WORDS = 32;
+constexpr int VB_TABLE_ENTRIES = 8;  // 1*P .. 8*P
+#endif
 constexpr int VB_TABLE_WORDS = PNIELS_WORDS * VB_TABLE_ENTRIES;
 constexpr int VB_VERIFY_WORDS = 2 * VB_TABLE_WORDS;  // verify keeps two per-lane tables (-8A and -+R)
-BJJ_HD PNiels load_pniels(const u32* p) {
+BJJ_HD PNiels pniels_identity() {
+  PNiels id; id.ymx = fr_one(); id.ypx = fr_one(); id.t2d = fr_zero(); id.z2 = fr_dbl(fr_one());
+  return id;
+}
+#if defined(BJJ_PNIELS_RAW)
+BJJ_HD PNiels load_pniels_raw(const u32* p) {
   const U4* q = (const U4*)p;
   U4 t[9];
 #pragma unroll
@@ -58,7 +74,7 @@ BJJ_HD PNiels load_pniels(const u32* p) {
   for (int i = 0; i < 9; i++) { n.ymx.v[i] = w[i]; n.ypx.v[i] = w[9 + i]; n.t2d.v[i] = w[18 + i]; n.z2.v[i] = w[27 + i]; }
   return n;
 }
-BJJ_HD void store_pniels(u32* p, const PNiels& n) {
+BJJ_HD void store_pniels_raw(u32* p, const PNiels& n) {
   u32 w[36];
 #pragma unroll
   for (int i = 0; i < 9; i++) { w[i] = n.ymx.v[i]; w[9 + i] = n.ypx.v[i]; w[18 + i] = n.t2d.v[i]; w[27 + i] = n.z2.v[i]; }
@@ -66,6 +82,35 @@ BJJ_HD void store_pniels(u32* p, const PNiels& n) {
 #pragma unroll
   for (int i = 0; i < 9; i++) q[i] = U4{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
 }
+// entry k (0..8) of a per-lane table
+BJJ_HD PNiels vb_table_load(const u32* tbl, u32 k) { return load_pniels_raw(tbl + k * PNIELS_WORDS); }
+BJJ_HD void vb_table_store(u32* tbl, u32 k, const PNiels& n) { store_pniels_raw(tbl + k * PNIELS_WORDS, n); }
+BJJ_HD void vb_table_store_identity(u32* tbl) { store_pniels_raw(tbl, pniels_identity()); }
+#else
+BJJ_HD PNiels vb_table_load(const u32* tbl, u32 k) {
+  const u32* p = tbl + (k ? k - 1 : 0) * PNIELS_WORDS;
+  u32 w[8];
+  PNiels n;
+  load_w8(p, w);      n.ymx = fr_from_words(w);
+  load_w8(p + 8, w);  n.ypx = fr_from_words(w);
+  load_w8(p + 16, w); n.t2d = fr_from_words(w);
+  load_w8(p + 24, w); n.z2 = fr_from_words(w);
+  const PNiels id = pniels_identity();
+  const bool z = k == 0;
+  n.ymx = fr_select(z, id.ymx, n.ymx); n.ypx = fr_select(z, id.ypx, n.ypx);
+  n.t2d = fr_select(z, id.t2d, n.t2d); n.z2 = fr_select(z, id.z2, n.z2);
+  return n;
+}
+BJJ_HD void vb_table_store(u32* tbl, u32 k, const PNiels& n) {  // k = 1..8; components N-form: ymx < 8r, the others < 4r
+  u32* p = tbl + (k - 1) * PNIELS_WORDS;
+  u32 w[8];
+  fr_to_words(fr_reduce_weak(n.ymx), w); store_w8(p, w);
+  fr_to_words(n.ypx, w); store_w8(p + 8, w);
+  fr_to_words(n.t2d, w); store_w8(p + 16, w);
+  fr_to_words(n.z2, w);  store_w8(p + 24, w);
+}
+BJJ_HD void vb_table_store_identity(u32*) {}
+#endif
 
 // =============================================================================
 // fixed base:  acc + n * B8   with the precomputed signed-window table
@@ -194,15 +239,14 @@ BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 raw[8], c
 // memory (global scratch on the GPU).
 // =============================================================================
 BJJ_HD void vb_build_table(const Ext& P, u32* tbl, const Consts& K) {
-  PNiels id; id.ymx = fr_one(); id.ypx = fr_one(); id.t2d = fr_zero(); id.z2 = fr_dbl(fr_one());
-  store_pniels(tbl, id);
+  vb_table_store_identity(tbl);
   PNiels p1 = ext_to_pniels(P, K);
-  store_pniels(tbl + PNIELS_WORDS, p1);
+  vb_table_store(tbl, 1, p1);
   Ext cur = P;
 #pragma unroll 1
   for (int k = 2; k <= 8; k++) {
     cur = ext_add_pn(cur, p1);
-    store_pniels(tbl + k * PNIELS_WORDS, ext_to_pniels(cur, K));
+    vb_table_store(tbl, (u32)k, ext_to_pniels(cur, K));
   }
 }
 // nwin windows of 4 bits, most significant first; needs sc < 2^(4*nwin - 2) so that the
@@ -219,7 +263,7 @@ BJJ_HD Ext vb_mul_windowed(const u32* tbl, const u32 sc[8], int nwin) {
     int d = (int)((t[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
     bool neg = d < 0;
     u32 idx = (u32)(neg ? -d : d);
-    PNiels e = load_pniels(tbl + idx * PNIELS_WORDS);  // issued ahead of the doublings
+    PNiels e = vb_table_load(tbl, idx);  // issued ahead of the doublings
     if (j != nwin - 1) {
 #pragma unroll 1
       for (int k = 0; k < 3; k++) acc = ext_dbl<false>(acc);
@@ -254,7 +298,7 @@ BJJ_HD void ref_mul_scalar(const Fr& x, const Fr& y, const u32* sc, int nw, Fr& 
 BJJ_HD Niels fixed_table_entry(u32 k, int j, int W, const Consts& K, bool tform = false) {
   Ext base = ext_from_ref_affine(K.B8X, K.B8Y, K);
   PNiels bn = ext_to_pniels(base, K);
-  PNiels idn; idn.ymx = fr_one(); idn.ypx = fr_one(); idn.t2d = fr_zero(); idn.z2 = fr_dbl(fr_one());
+  PNiels idn = pniels_identity();
   Ext acc = ext_identity();
 #pragma unroll 1
   for (int b = W - 1; b >= 0; b--) {
@@ -698,8 +742,8 @@ BJJ_HD Ext joint_mul_windowed(const u32* tbl1, const u32* tbl2, const Fr& u, con
   for (int j = nwin - 1; j >= 0; j--) {
     const int du = (int)((tu[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
     const int dv = (int)((tv[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
-    PNiels e1 = load_pniels(tbl1 + (u32)(du < 0 ? -du : du) * PNIELS_WORDS);
-    PNiels e2 = load_pniels(tbl2 + (u32)(dv < 0 ? -dv : dv) * PNIELS_WORDS);
+    PNiels e1 = vb_table_load(tbl1, (u32)(du < 0 ? -du : du));
+    PNiels e2 = vb_table_load(tbl2, (u32)(dv < 0 ? -dv : dv));
     if (j != nwin - 1) {
 #pragma unroll 1
       for (int k = 0; k < 3; k++) acc = ext_dbl<false>(acc);

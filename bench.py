@@ -149,6 +149,7 @@ class Workload:
             tors = c.mul_var_base([T8] * 8, list(range(8)))                       # (8, 64): j * T8
             cidx = (w.splitmix64(w.SEED_POINTS ^ 0x77, n, offset) & np.uint64(7)).astype(np.int64)
             d_t = self._up(tors)[None].reshape(8, 64)[torch.from_numpy(cidx).to(self.dev)].reshape(-1).contiguous()
+            torch.cuda.synchronize()      # torch's gather ran on torch's stream; the library launches on its own
             B.d_pts = self._empty(n * 64)
             c.point_add_dev(d_kb.data_ptr(), d_t.data_ptr(), n, B.d_pts.data_ptr(), s)
             c.sync()
@@ -193,6 +194,7 @@ class Workload:
                 B.d_pk = A_t[:, :32].contiguous().reshape(-1)
                 B.d_sig = torch.cat([R_t[:, 32:], B.d_s.view(n, 32)], dim=1).contiguous().reshape(-1)
             B.d_out = self._empty(n)
+        torch.cuda.synchronize()          # everything torch did to the inputs (uploads, corruption) is complete
         return B
 
     def launch(self, k=0):

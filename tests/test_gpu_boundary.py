@@ -206,7 +206,8 @@ def test_multi_dev_form_rccl_one_device(oracle):
         A, R, S, msg = w.make_signatures(oracle.mul_fixed_base, oracle.poseidon5, n)
         bad = w.corrupt(A, R, S, msg, n)
         d_ok = torch.empty(n, dtype=torch.uint8, device=dev)
-        m.eddsa_verify_dev(up(A).data_ptr(), up(R).data_ptr(), up(S).data_ptr(), up(msg).data_ptr(), n, d_ok.data_ptr())
+        t_A, t_R, t_S, t_m = up(A), up(R), up(S), up(msg)       # keep the tensors alive across the call
+        m.eddsa_verify_dev(t_A.data_ptr(), t_R.data_ptr(), t_S.data_ptr(), t_m.data_ptr(), n, d_ok.data_ptr())
         assert (d_ok.cpu().numpy() == (~bad).astype(np.uint8)).all()
     finally:
         m.close()

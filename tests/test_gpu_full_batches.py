@@ -109,4 +109,4 @@ def test_cfg5_shape_16m_verifies_as_8_shards(gpu_ctx, oracle):
         idx = np.arange(r, m, 8191)
         assert (got[idx] == oracle.verify(A[idx], R[idx], S[idx], msg_h[idx])).all()
         total_ok += int(got.sum())
-    assert n - n // 48 > total_ok > n - n // 80     # ~1/64 of the 2^24 signatures were corrupted
+    assert n - n // 80 > total_ok > n - n // 48     # ~1/64 of the 2^24 signatures were corrupted
