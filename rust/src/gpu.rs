@@ -1,0 +1,230 @@
+//! One GPU context (`bjj_init` / `bjj_free`) and the batch calls over byte records.
+//!
+//! Records are what `../include/bjj_hip.h` defines: a field element is the 32-byte little-endian canonical integer
+//! (`Fr::into_repr().0` as `[u64; 4]`), a point is `x || y` (64 bytes), a projective point `x || y || z` (96 bytes),
+//! a scalar / `s` / `msg` a 32-byte little-endian unsigned integer.
+use crate::ffi;
+use std::cell::RefCell;
+use std::ffi::CStr;
+use std::os::raw::c_int;
+use std::ptr;
+use std::rc::Rc;
+
+pub struct Gpu {
+    ctx: *mut ffi::BjjCtx,
+    owned: bool,
+}
+
+pub(crate) fn last_error() -> String {
+    unsafe { CStr::from_ptr(ffi::bjj_last_error()).to_string_lossy().into_owned() }
+}
+
+pub(crate) fn check(rc: c_int, what: &str) -> Result<(), String> {
+    if rc == ffi::BJJ_OK {
+        Ok(())
+    } else {
+        Err(format!("{} failed ({}): {}", what, rc, last_error()))
+    }
+}
+
+impl Gpu {
+    /// `window_bits`: 0 = the library default (23-bit windows, 5.9 GB table), `ffi::BJJ_WINDOW_AUTO`, or 4..=28.
+    pub fn new(device: i32, window_bits: i32) -> Result<Gpu, String> {
+        let mut ctx: *mut ffi::BjjCtx = ptr::null_mut();
+        check(unsafe { ffi::bjj_init(device as c_int, window_bits as c_int, &mut ctx) }, "bjj_init")?;
+        Ok(Gpu { ctx, owned: true })
+    }
+
+    /// A context owned by a `multi::MultiGpu` handle.
+    pub(crate) fn borrowed(ctx: *mut ffi::BjjCtx) -> Gpu {
+        Gpu { ctx, owned: false }
+    }
+
+    pub fn info(&self) -> Result<ffi::BjjInfo, String> {
+        let mut i = std::mem::MaybeUninit::<ffi::BjjInfo>::zeroed();
+        check(unsafe { ffi::bjj_get_info(self.ctx, i.as_mut_ptr()) }, "bjj_get_info")?;
+        Ok(unsafe { i.assume_init() })
+    }
+
+    /// `B8.mul_scalar(n)` for every 32-byte scalar (reference src/lib.rs:149-164 with self = B8).
+    pub fn mul_fixed_base(&self, scalars: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(scalars, 32, "scalars")?;
+        let mut out = vec![0u8; n * 64];
+        check(unsafe { ffi::bjj_mul_fixed_base(self.ctx, scalars.as_ptr(), n, out.as_mut_ptr()) }, "bjj_mul_fixed_base")?;
+        Ok(out)
+    }
+
+    /// `P.mul_scalar(n)`; `scalar_bytes` per scalar record (a multiple of 32; 32 takes the fast entry point).
+    pub fn mul_var_base(&self, points: &[u8], scalars: &[u8], scalar_bytes: usize) -> Result<Vec<u8>, String> {
+        let n = records(points, 64, "points")?;
+        if scalar_bytes == 0 || scalar_bytes % 32 != 0 || scalars.len() != n * scalar_bytes {
+            return Err("mul_var_base: scalar records do not match the points".into());
+        }
+        let mut out = vec![0u8; n * 64];
+        let rc = unsafe {
+            if scalar_bytes == 32 {
+                ffi::bjj_mul_var_base(self.ctx, points.as_ptr(), scalars.as_ptr(), n, out.as_mut_ptr())
+            } else {
+                ffi::bjj_mul_var_base_wide(self.ctx, points.as_ptr(), scalars.as_ptr(), scalar_bytes, n, out.as_mut_ptr())
+            }
+        };
+        check(rc, "bjj_mul_var_base")?;
+        Ok(out)
+    }
+
+    pub fn poseidon5(&self, inputs: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(inputs, 160, "inputs")?;
+        let mut out = vec![0u8; n * 32];
+        check(unsafe { ffi::bjj_poseidon5(self.ctx, inputs.as_ptr(), n, out.as_mut_ptr()) }, "bjj_poseidon5")?;
+        Ok(out)
+    }
+
+    /// one verdict byte per signature: 1 = `verify` returned true, 0 = false (reference src/lib.rs:395-412)
+    pub fn eddsa_verify(&self, pk: &[u8], r_b8: &[u8], s: &[u8], msg: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(s, 32, "s")?;
+        if pk.len() != n * 64 || r_b8.len() != n * 64 || msg.len() != n * 32 {
+            return Err("eddsa_verify: array lengths disagree".into());
+        }
+        let mut ok = vec![0u8; n];
+        check(
+            unsafe { ffi::bjj_eddsa_verify(self.ctx, pk.as_ptr(), r_b8.as_ptr(), s.as_ptr(), msg.as_ptr(), n, ok.as_mut_ptr()) },
+            "bjj_eddsa_verify",
+        )?;
+        Ok(ok)
+    }
+
+    /// 1 / 0 = `Ok(true / false)`, 2 = `Err` (msg > Q); `s` already reduced mod 8l into 32 bytes
+    pub fn schnorr_verify(&self, pk: &[u8], r: &[u8], s: &[u8], msg: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(s, 32, "s")?;
+        if pk.len() != n * 64 || r.len() != n * 64 || msg.len() != n * 32 {
+            return Err("schnorr_verify: array lengths disagree".into());
+        }
+        let mut ok = vec![0u8; n];
+        check(
+            unsafe { ffi::bjj_schnorr_verify(self.ctx, pk.as_ptr(), r.as_ptr(), s.as_ptr(), msg.as_ptr(), n, ok.as_mut_ptr()) },
+            "bjj_schnorr_verify",
+        )?;
+        Ok(ok)
+    }
+
+    /// raw `PointProjective::add` (reference src/lib.rs:88-131): 96-byte records, any z
+    pub fn proj_add(&self, p: &[u8], q: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(p, 96, "p")?;
+        if q.len() != p.len() {
+            return Err("proj_add: array lengths disagree".into());
+        }
+        let mut out = vec![0u8; n * 96];
+        check(unsafe { ffi::bjj_proj_add(self.ctx, p.as_ptr(), q.as_ptr(), n, out.as_mut_ptr()) }, "bjj_proj_add")?;
+        Ok(out)
+    }
+
+    /// `PointProjective::affine` (reference src/lib.rs:70-85); z == 0 gives (0, 0)
+    pub fn proj_affine(&self, p: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(p, 96, "p")?;
+        let mut out = vec![0u8; n * 64];
+        check(unsafe { ffi::bjj_proj_affine(self.ctx, p.as_ptr(), n, out.as_mut_ptr()) }, "bjj_proj_affine")?;
+        Ok(out)
+    }
+
+    pub fn compress_points(&self, pts: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(pts, 64, "points")?;
+        let mut out = vec![0u8; n * 32];
+        check(unsafe { ffi::bjj_compress_points(self.ctx, pts.as_ptr(), n, out.as_mut_ptr()) }, "bjj_compress_points")?;
+        Ok(out)
+    }
+
+    /// (points, ok): ok[i] == 0 where `decompress_point` returns `Err` (reference src/lib.rs:192-224)
+    pub fn decompress_points(&self, comp: &[u8]) -> Result<(Vec<u8>, Vec<u8>), String> {
+        let n = records(comp, 32, "compressed points")?;
+        let (mut out, mut ok) = (vec![0u8; n * 64], vec![0u8; n]);
+        check(
+            unsafe { ffi::bjj_decompress_points(self.ctx, comp.as_ptr(), n, out.as_mut_ptr(), ok.as_mut_ptr()) },
+            "bjj_decompress_points",
+        )?;
+        Ok((out, ok))
+    }
+
+    pub fn scalar_keys(&self, keys: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(keys, 32, "keys")?;
+        let mut out = vec![0u8; n * 32];
+        check(unsafe { ffi::bjj_scalar_keys(self.ctx, keys.as_ptr(), n, out.as_mut_ptr()) }, "bjj_scalar_keys")?;
+        Ok(out)
+    }
+
+    pub fn public_keys(&self, keys: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(keys, 32, "keys")?;
+        let mut out = vec![0u8; n * 64];
+        check(unsafe { ffi::bjj_public_keys(self.ctx, keys.as_ptr(), n, out.as_mut_ptr()) }, "bjj_public_keys")?;
+        Ok(out)
+    }
+
+    /// (R, s, ok): ok[i] == 0 where `PrivateKey::sign` returns `Err` (msg > Q, reference src/lib.rs:309-311)
+    pub fn sign(&self, keys: &[u8], msgs: &[u8]) -> Result<(Vec<u8>, Vec<u8>, Vec<u8>), String> {
+        let n = records(keys, 32, "keys")?;
+        if msgs.len() != n * 32 {
+            return Err("sign: array lengths disagree".into());
+        }
+        let (mut r, mut s, mut ok) = (vec![0u8; n * 64], vec![0u8; n * 32], vec![0u8; n]);
+        check(
+            unsafe { ffi::bjj_sign(self.ctx, keys.as_ptr(), msgs.as_ptr(), n, r.as_mut_ptr(), s.as_mut_ptr(), ok.as_mut_ptr()) },
+            "bjj_sign",
+        )?;
+        Ok((r, s, ok))
+    }
+
+    /// `PrivateKey::sign_schnorr` with caller-supplied 1024-bit nonces (128 bytes each); s = 160-byte unreduced integers
+    pub fn sign_schnorr(&self, keys: &[u8], msgs: &[u8], nonces: &[u8]) -> Result<(Vec<u8>, Vec<u8>, Vec<u8>), String> {
+        let n = records(keys, 32, "keys")?;
+        if msgs.len() != n * 32 || nonces.len() != n * ffi::BJJ_SCHNORR_NONCE_BYTES {
+            return Err("sign_schnorr: array lengths disagree".into());
+        }
+        let (mut r, mut s, mut ok) = (vec![0u8; n * 64], vec![0u8; n * ffi::BJJ_SCHNORR_S_BYTES], vec![0u8; n]);
+        check(
+            unsafe {
+                ffi::bjj_sign_schnorr(self.ctx, keys.as_ptr(), msgs.as_ptr(), nonces.as_ptr(), n, r.as_mut_ptr(), s.as_mut_ptr(), ok.as_mut_ptr())
+            },
+            "bjj_sign_schnorr",
+        )?;
+        Ok((r, s, ok))
+    }
+}
+
+impl Drop for Gpu {
+    fn drop(&mut self) {
+        if self.owned && !self.ctx.is_null() {
+            unsafe { ffi::bjj_free(self.ctx) }
+        }
+    }
+}
+
+fn records(bytes: &[u8], width: usize, name: &str) -> Result<usize, String> {
+    if bytes.len() % width != 0 {
+        return Err(format!("{}: byte length {} is not a multiple of {}", name, bytes.len(), width));
+    }
+    Ok(bytes.len() / width)
+}
+
+thread_local! {
+    /// The context behind the reference-shaped single-item API: created on first use, one per thread (a `bjj_ctx` is
+    /// used by one host thread at a time).  BJJ_DEVICE / BJJ_WINDOW_BITS select the device and the table width.
+    static GPU: RefCell<Option<Rc<Gpu>>> = RefCell::new(None);
+}
+
+fn env_i32(name: &str, default: i32) -> i32 {
+    std::env::var(name).ok().and_then(|v| v.parse().ok()).unwrap_or(default)
+}
+
+/// Runs `f` with this thread's GPU context.  Panics if no GPU is usable: like the reference, the path functions are
+/// infallible, and there is no CPU fallback to fall back to.
+pub fn with_gpu<R>(f: impl FnOnce(&Gpu) -> R) -> R {
+    let gpu = GPU.with(|cell| {
+        let mut slot = cell.borrow_mut();
+        if slot.is_none() {
+            let g = Gpu::new(env_i32("BJJ_DEVICE", 0), env_i32("BJJ_WINDOW_BITS", 0))
+                .unwrap_or_else(|e| panic!("babyjubjub_rs (HIP): {}", e));
+            *slot = Some(Rc::new(g));
+        }
+        slot.as_ref().unwrap().clone()
+    });
+    f(&gpu)
+}
