@@ -91,13 +91,15 @@ inline void check(int rc, const char* what) {
 struct Point;
 struct PointProjective {  // lib.rs:62-67
   Fr x, y, z;
-  Point affine() const;                                   // lib.rs:70-85 (z must be 0 or 1 at this boundary)
-  PointProjective add(const PointProjective& q) const;    // lib.rs:88-131 (operands with z == 1)
+  Point affine() const;                                   // lib.rs:70-85 (z == 0 -> (0, 0))
+  PointProjective add(const PointProjective& q) const;    // lib.rs:88-131: the raw (x, y, z), any z
 };
 struct Point {  // lib.rs:134-138
   Fr x, y;
   PointProjective projective() const { return PointProjective{x, y, Fr(1)}; }  // lib.rs:141-147
   Point mul_scalar(const U256& n) const;                                       // lib.rs:149-164
+  // `n: &BigInt` is unbounded (lib.rs:149, 156-157): little-endian magnitude of any width (padded to 32 k bytes here)
+  Point mul_scalar_wide(const std::vector<uint8_t>& n_le) const;
   bool equals(const Point& p) const { return x == p.x && y == p.y; }           // lib.rs:180-185
   std::array<uint8_t, 32> compress() const;                                    // lib.rs:166-178
 };
@@ -248,17 +250,66 @@ inline Point Point::mul_scalar(const U256& n) const {
   if (equals(B8())) return mul_fixed_base_batch({n})[0];
   return mul_scalar_batch({*this}, {n})[0];
 }
+inline Point Point::mul_scalar_wide(const std::vector<uint8_t>& n_le) const {
+  size_t nbytes = ((n_le.size() + 31) / 32) * 32;
+  if (nbytes == 0) nbytes = 32;
+  if (nbytes > BJJ_MAX_SCALAR_BYTES) throw std::runtime_error("mul_scalar_wide: scalar wider than BJJ_MAX_SCALAR_BYTES");
+  std::vector<uint8_t> sc(nbytes, 0);
+  std::memcpy(sc.data(), n_le.data(), n_le.size());
+  Point o;
+  check(bjj_mul_var_base_wide(Context::global().handle(), (const uint8_t*)this, sc.data(), nbytes, 1, (uint8_t*)&o),
+        "bjj_mul_var_base_wide");
+  return o;
+}
 inline PointProjective PointProjective::add(const PointProjective& q) const {
-  if (z != Fr(1) || q.z != Fr(1)) throw std::runtime_error("PointProjective::add: boundary takes z == 1 operands");
-  Point a{x, y}, b{q.x, q.y}, o;
-  check(bjj_point_add(Context::global().handle(), (const uint8_t*)&a, (const uint8_t*)&b, 1, (uint8_t*)&o), "bjj_point_add");
-  return PointProjective{o.x, o.y, Fr(1)};
+  static_assert(sizeof(PointProjective) == 96, "records must be tightly packed");
+  PointProjective o;
+  check(bjj_proj_add(Context::global().handle(), (const uint8_t*)this, (const uint8_t*)&q, 1, (uint8_t*)&o), "bjj_proj_add");
+  return o;
 }
 inline Point PointProjective::affine() const {
-  if (z == Fr(0)) return Point{Fr(0), Fr(0)};  // lib.rs:71-76
-  if (z != Fr(1)) throw std::runtime_error("PointProjective::affine: boundary holds z in {0, 1}");
-  return Point{x, y};
+  Point o;
+  check(bjj_proj_affine(Context::global().handle(), (const uint8_t*)this, 1, (uint8_t*)&o), "bjj_proj_affine");
+  return o;
 }
+inline std::vector<PointProjective> proj_add_batch(const std::vector<PointProjective>& p, const std::vector<PointProjective>& q,
+                                                   Context& c = Context::global()) {
+  if (p.size() != q.size()) throw std::runtime_error("proj_add_batch: length mismatch");
+  std::vector<PointProjective> out(p.size());
+  check(bjj_proj_add(c.handle(), (const uint8_t*)p.data(), (const uint8_t*)q.data(), p.size(), (uint8_t*)out.data()), "bjj_proj_add");
+  return out;
+}
+
+// every GPU of the node behind one handle (bjj_multi_*): contiguous ceil(n/G) blocks per device
+class MultiContext {
+ public:
+  explicit MultiContext(const std::vector<int>& devices = {}, int window_bits = 0) {
+    int rc = bjj_multi_init(devices.empty() ? nullptr : devices.data(), (int)devices.size(), window_bits, &h_);
+    if (rc != BJJ_OK) throw std::runtime_error(std::string("bjj_multi_init: ") + bjj_last_error());
+  }
+  ~MultiContext() { bjj_multi_free(h_); }
+  MultiContext(const MultiContext&) = delete;
+  MultiContext& operator=(const MultiContext&) = delete;
+  bjj_multi* handle() const { return h_; }
+  int size() const { return bjj_multi_size(h_); }
+  std::vector<uint8_t> verify_batch(const std::vector<Point>& pk, const std::vector<Signature>& sig, const std::vector<U256>& msg) {
+    size_t n = pk.size();
+    if (sig.size() != n || msg.size() != n) throw std::runtime_error("verify_batch: length mismatch");
+    std::vector<Point> r(n); std::vector<U256> s(n);
+    for (size_t i = 0; i < n; i++) { r[i] = sig[i].r_b8; s[i] = sig[i].s; }
+    std::vector<uint8_t> ok(n);
+    check(bjj_eddsa_verify_multi(h_, (const uint8_t*)pk.data(), (const uint8_t*)r.data(), (const uint8_t*)s.data(),
+                                 (const uint8_t*)msg.data(), n, ok.data()), "bjj_eddsa_verify_multi");
+    return ok;
+  }
+  std::vector<Point> mul_fixed_base_batch(const std::vector<U256>& n) {
+    std::vector<Point> out(n.size());
+    check(bjj_mul_fixed_base_multi(h_, (const uint8_t*)n.data(), n.size(), (uint8_t*)out.data()), "bjj_mul_fixed_base_multi");
+    return out;
+  }
+ private:
+  bjj_multi* h_ = nullptr;
+};
 // little-endian integer of any width mod ORDER = 8l (the group order): bit-serial shift-and-subtract on the host.
 // Exact for the scalar of B8.mul_scalar (lib.rs:377) because B8 lies on the curve.
 inline U256 reduce_mod_order(const uint8_t* le, size_t nbytes) {

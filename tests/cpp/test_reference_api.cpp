@@ -33,6 +33,16 @@ static void test_mul_scalar() {  // lib.rs:502-552
   ASSERT_EQ(res_m.x, res_a.x);
   ASSERT_EQ(res_m.x, Fr::from_str("19372461775513343691590086534037741906533799473648040012278229434133483800898"));
   ASSERT_EQ(res_m.y, Fr::from_str("9458658722007214007257525444427903161243386465067105737478306991484593958249"));
+  // the chained add goes through z != 1 (raw PointProjective::add); a scalar wider than 256 bits: 3 + 8l * 2^300
+  ASSERT_TRUE(!(p.projective().add(p.projective()).z == Fr(1)));
+  ASSERT_TRUE((PointProjective{Fr(1), Fr(2), Fr(0)}.affine().equals(Point{Fr(0), Fr(0)})));   // lib.rs:71-76
+  {
+    U256 order = U256::from_str("21888242871839275222246405745257275088614511777268538073601725287587578984328");
+    std::vector<uint8_t> wide(96, 0);   // 8l << 296 occupies bytes 37.. ; + 3
+    for (int i = 0; i < 32; i++) wide[37 + i] = order.le[i];
+    wide[0] = 3;
+    ASSERT_TRUE(p.mul_scalar_wide(wide).equals(res_m));
+  }
   U256 n = U256::from_str("14035240266687799601661095864649209771790948434046947201833777492504781204499");
   Point res2 = p.mul_scalar(n);
   ASSERT_EQ(res2.x, Fr::from_str("17070357974431721403481313912716834497662307308519659060910483826664480189605"));
