@@ -18,6 +18,8 @@ BJJ_E_NOMEM = -4
 BJJ_E_RCCL = -5
 BJJ_WINDOW_AUTO = -1
 BJJ_MAX_SCALAR_BYTES = 4096
+BJJ_TRANSPORT_RCCL = 0
+BJJ_TRANSPORT_PEER_COPY = 1
 
 # every symbol include/bjj_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -35,7 +37,7 @@ EXPORTED_SYMBOLS = (
     "bjj_multi_init", "bjj_multi_free", "bjj_multi_size", "bjj_multi_ctx", "bjj_multi_device", "bjj_shard_bounds",
     "bjj_mul_fixed_base_multi", "bjj_mul_var_base_multi", "bjj_eddsa_verify_multi",
     "bjj_mul_fixed_base_multi_dev", "bjj_mul_var_base_multi_dev", "bjj_eddsa_verify_multi_dev",
-    "bjj_multi_last_timing",
+    "bjj_multi_last_timing", "bjj_multi_set_transport",
 )
 
 
@@ -157,4 +159,5 @@ def load():
     lib.bjj_mul_var_base_multi_dev.argtypes = [vp, vp, vp, sz, vp]
     lib.bjj_eddsa_verify_multi_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp]
     lib.bjj_multi_last_timing.argtypes = [vp, pd, pd, pd, ctypes.POINTER(ci)]
+    lib.bjj_multi_set_transport.argtypes = [vp, ci]
     return lib

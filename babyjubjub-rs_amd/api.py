@@ -350,7 +350,7 @@ class MultiContext:
     device, replicated tables.  Host arrays -> one pipeline thread per device; *_dev -> arrays resident on the first
     device, RCCL scatter / kernels / gather (BASELINE cfg 5)."""
 
-    def __init__(self, devices=None, window_bits=0):
+    def __init__(self, devices=None, window_bits=0, transport="rccl"):
         self.lib = _lib.load()
         h = ctypes.c_void_p()
         if devices is None:
@@ -362,6 +362,13 @@ class MultiContext:
         if rc != _lib.BJJ_OK:
             raise BjjError("bjj_multi_init failed (%d): %s" % (rc, self.lib.bjj_last_error().decode()))
         self.handle = h
+        if transport != "rccl":
+            self.set_transport(transport)
+
+    def set_transport(self, transport):
+        """"rccl" (grouped ncclScatter / ncclGather) or "peer" (hipMemcpyPeerAsync of the same blocks) for the *_dev form"""
+        t = {"rccl": _lib.BJJ_TRANSPORT_RCCL, "peer": _lib.BJJ_TRANSPORT_PEER_COPY}[transport]
+        self._ck(self.lib.bjj_multi_set_transport(self.handle, t), "bjj_multi_set_transport")
 
     def close(self):
         if getattr(self, "handle", None):

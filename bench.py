@@ -81,6 +81,10 @@ def parse():
     ap.add_argument("--no-strong", action="store_true", help="skip the fixed-total-work (strong scaling / cfg 5) lines")
     ap.add_argument("--native-multi", action="store_true",
                     help="ONE process, all --gpus devices through bjj_multi_* (RCCL inside the library)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "peer"],
+                    help="--native-multi: grouped ncclScatter / ncclGather, or hipMemcpyPeerAsync of the same blocks")
+    ap.add_argument("--devices", default=None,
+                    help="--native-multi: comma-separated device list (default 0..gpus-1; a device may repeat with --transport peer)")
     return ap.parse_args()
 
 
@@ -435,8 +439,9 @@ def run_native_multi(args):
     """ONE process, all GPUs through the C ABI: bjj_multi_init + bjj_*_multi_dev (RCCL scatter / kernels / gather inside
     libbjj_hip.so).  Times BASELINE cfg 5's shape: the batch lives in the HBM of device 0."""
     import babyjubjub_rs_amd as bjj
-    g = args.gpus
-    m = bjj.MultiContext(list(range(g)), args.window_bits)
+    devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    g = len(devs)
+    m = bjj.MultiContext(devs, args.window_bits, args.transport)
     dev = torch.device("cuda", m.device(0))
     torch.cuda.set_device(dev)
     ctx0 = m.ctx(0)
@@ -469,7 +474,9 @@ def run_native_multi(args):
         del wl
     res = {"metric": "BabyJubJub native multi-GPU (bjj_multi_*): fixed-base mults/sec and EdDSA verifies/sec, batch resident on device 0",
            "value": out["verify"]["value"], "unit": "verifies/s", "n_gpus": g, "devices": [m.device(i) for i in range(g)],
-           "mode": "single process, ncclCommInitAll, grouped ncclScatter / kernels / ncclGather inside libbjj_hip.so",
+           "mode": ("single process, ncclCommInitAll, grouped ncclScatter / kernels / ncclGather inside libbjj_hip.so" if args.transport == "rccl"
+                    else "single process, hipMemcpyPeerAsync blocks / kernels / hipMemcpyPeerAsync results inside libbjj_hip.so"),
+           "transport": args.transport,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4] shape", "window_bits": ctx0.info().window_bits},
            "results": out, "parity_sample_ok": ok_all}

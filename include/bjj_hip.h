@@ -240,11 +240,19 @@ int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
  *                        one ncclGroup (ncclScatter, in place at the root; exact-count ncclSend /
  *                        ncclRecv pairs when G does not divide n), every device runs the kernels on
  *                        its block, a second group gathers the results (ncclGather) into the
- *                        caller's output array.  Synchronous.  RCCL is loaded with dlopen on the
- *                        first such call (single process, ncclCommInitAll); BJJ_E_RCCL if absent. */
+ *                        caller's output array.  Synchronous; the input arrays must be complete
+ *                        when the call is made (no pending writes on other streams).  RCCL is loaded
+ *                        with dlopen on the first such call (single process, ncclCommInitAll);
+ *                        BJJ_E_RCCL if absent. */
 typedef struct bjj_multi bjj_multi;
-/* devices: n_devices distinct HIP device indices (NULL = 0 .. n_devices-1; NULL and 0 = all visible devices). */
+/* devices: n_devices HIP device indices (NULL = 0 .. n_devices-1; NULL and 0 = all visible devices).  A device may be
+ * named more than once (several contexts on one GPU; how the G > 1 block arithmetic is tested on a one-GPU box) -- the
+ * host-pointer form and BJJ_TRANSPORT_PEER_COPY accept that, RCCL does not (BJJ_E_RCCL). */
 int bjj_multi_init(const int* devices, int n_devices, int window_bits, bjj_multi** out);
+/* Transport of the *_multi_dev form: BJJ_TRANSPORT_RCCL (default: grouped ncclScatter / ncclGather over xGMI) or
+ * BJJ_TRANSPORT_PEER_COPY (hipMemcpyPeerAsync of the same blocks on the peers' streams; needs no RCCL). */
+enum { BJJ_TRANSPORT_RCCL = 0, BJJ_TRANSPORT_PEER_COPY = 1 };
+int bjj_multi_set_transport(bjj_multi* m, int transport);
 void bjj_multi_free(bjj_multi* m);
 int bjj_multi_size(const bjj_multi* m);
 bjj_ctx* bjj_multi_ctx(bjj_multi* m, int rank);     /* the per-device context (owned by the handle) */

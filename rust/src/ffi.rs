@@ -40,6 +40,8 @@ pub const BJJ_WINDOW_AUTO: c_int = -1;
 pub const BJJ_MAX_SCALAR_BYTES: usize = 4096;
 pub const BJJ_SCHNORR_NONCE_BYTES: usize = 128;
 pub const BJJ_SCHNORR_S_BYTES: usize = 160;
+pub const BJJ_TRANSPORT_RCCL: c_int = 0;
+pub const BJJ_TRANSPORT_PEER_COPY: c_int = 1;
 
 extern "C" {
     pub fn bjj_version() -> *const c_char;
@@ -84,6 +86,7 @@ extern "C" {
     pub fn bjj_check_table(ctx: *mut BjjCtx, n_bad: *mut u64) -> c_int;
     pub fn bjj_get_info(ctx: *mut BjjCtx, info: *mut BjjInfo) -> c_int;
     pub fn bjj_multi_init(devices: *const c_int, n_devices: c_int, window_bits: c_int, out: *mut *mut BjjMulti) -> c_int;
+    pub fn bjj_multi_set_transport(m: *mut BjjMulti, transport: c_int) -> c_int;
     pub fn bjj_multi_free(m: *mut BjjMulti);
     pub fn bjj_multi_size(m: *const BjjMulti) -> c_int;
     pub fn bjj_multi_ctx(m: *mut BjjMulti, rank: c_int) -> *mut BjjCtx;

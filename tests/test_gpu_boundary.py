@@ -213,6 +213,54 @@ def test_multi_dev_form_rccl_one_device(oracle):
         m.close()
 
 
+@pytest.mark.parametrize("g", [2, 3, 8])
+def test_multi_block_arithmetic_with_several_contexts_on_one_gpu(oracle, g):
+    """G > 1 on the one-GPU box: the handle names device 0 g times (g contexts, g streams, g block buffers), the
+    device-resident form moves the blocks with the peer-copy transport (RCCL refuses duplicate devices and says so), the
+    host-pointer form runs its g pipeline threads concurrently.  Even, ragged and tiny batches; every output vs the oracle."""
+    import torch
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    dev = torch.device("cuda", 0)
+    m = bjj.MultiContext([0] * g, 8)
+    try:
+        assert m.size == g
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)  # noqa: E731
+        sc0 = w.scalars_254(16)
+        d0, o0 = up(sc0), torch.empty(16 * 64, dtype=torch.uint8, device=dev)
+        with pytest.raises(bjj.BjjError, match="distinct devices"):
+            m.mul_fixed_base_dev(d0.data_ptr(), 16, o0.data_ptr())          # default transport = RCCL
+        m.set_transport("peer")
+        for n in (g * 512, g * 512 + 5, 3, 1, g):
+            sc = w.scalars_254(n, offset=7 * n)
+            want = oracle.mul_fixed_base(sc)
+            assert (m.mul_fixed_base(sc) == want).all()                      # host-pointer form, g threads
+            d_sc = up(sc)
+            d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            m.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out.data_ptr())
+            fb = d_out.cpu().numpy().reshape(n, 64)
+            assert (fb == want).all(), n
+            d_out2 = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+            m.mul_var_base_dev(d_out.data_ptr(), d_sc.data_ptr(), n, d_out2.data_ptr())
+            assert (d_out2.cpu().numpy().reshape(n, 64) == oracle.mul_var_base(fb, sc)).all(), n
+            A, R, S, msg = w.make_signatures(oracle.mul_fixed_base, oracle.poseidon5, n, offset=n)
+            bad = w.corrupt(A, R, S, msg, n, offset=n)
+            if n > 2:
+                A[2, 5] ^= 1; bad[2] = True                                  # an off-curve pk: the exact path inside a block
+            assert (m.eddsa_verify(A, R, S, msg) == (~bad).astype(np.uint8)).all()
+            t_A, t_R, t_S, t_m = up(A), up(R), up(S), up(msg)
+            d_ok = torch.full((((n + 15) // 16) * 16,), 7, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            m.eddsa_verify_dev(t_A.data_ptr(), t_R.data_ptr(), t_S.data_ptr(), t_m.data_ptr(), n, d_ok.data_ptr())
+            got = d_ok.cpu().numpy()
+            assert (got[:n] == (~bad).astype(np.uint8)).all() and (got[n:] == 7).all(), n   # nothing written past n
+        t = m.last_timing()
+        assert t["compute_ms"] > 0 and t["rccl_version"] == 0
+    finally:
+        m.close()
+
+
 def test_multi_all_devices_scatter_gather(oracle):
     """every visible device (the driver's 8-GPU box; skipped on a 1-GPU box): ragged and even batches through both forms"""
     import torch

@@ -56,7 +56,8 @@ def main():
              "pub const BJJ_OK: c_int = 0;", "pub const BJJ_E_INVALID: c_int = -1;", "pub const BJJ_E_NO_DEVICE: c_int = -2;",
              "pub const BJJ_E_HIP: c_int = -3;", "pub const BJJ_E_NOMEM: c_int = -4;", "pub const BJJ_E_RCCL: c_int = -5;",
              "pub const BJJ_WINDOW_AUTO: c_int = -1;", "pub const BJJ_MAX_SCALAR_BYTES: usize = 4096;",
-             "pub const BJJ_SCHNORR_NONCE_BYTES: usize = 128;", "pub const BJJ_SCHNORR_S_BYTES: usize = 160;", "",
+             "pub const BJJ_SCHNORR_NONCE_BYTES: usize = 128;", "pub const BJJ_SCHNORR_S_BYTES: usize = 160;",
+             "pub const BJJ_TRANSPORT_RCCL: c_int = 0;", "pub const BJJ_TRANSPORT_PEER_COPY: c_int = 1;", "",
              'extern "C" {']
     for ret, name, ps in decls:
         args = ", ".join("%s: %s" % param(p) for p in ps)
