@@ -37,6 +37,25 @@ def test_soak_all_entry_points(gpu_ctx, oracle, seed):
     assert (gpu_ctx.mul_fixed_base(sc) == oracle.mul_fixed_base(sc)).all()
     assert (gpu_ctx.mul_var_base(pts, sc) == oracle.mul_var_base(pts, sc)).all()
     assert (gpu_ctx.point_add(pts, pk) == oracle.point_add(pts, pk)).all()
+    # raw projective add / affine on arbitrary (x, y, z) records, and scalars wider than 256 bits
+    m = min(n, 300)
+    pa = rng.integers(0, 256, (m, 96), dtype=np.uint8)
+    pb = np.concatenate([pts[:m], rng.integers(0, 256, (m, 32), dtype=np.uint8)], axis=1)
+    pa[rng.random(m) < 0.05, 64:] = 0                                        # some z == 0
+    want_add = np.empty_like(pa)
+    want_aff = np.empty((m, 64), np.uint8)
+    for i in range(m):
+        oracle.lib.bjjref_proj_add(oracle._p(pa[i]), oracle._p(pb[i]), oracle._p(want_add[i]))
+        oracle.lib.bjjref_proj_affine(oracle._p(pa[i]), oracle._p(want_aff[i]))
+    assert (gpu_ctx.proj_add(pa, pb) == want_add).all()
+    assert (gpu_ctx.proj_affine(pa) == want_aff).all()
+    import ctypes
+    wb = 32 * int(rng.integers(2, 6))
+    wsc = rng.integers(0, 256, (m, wb), dtype=np.uint8)
+    want_w = np.empty((m, 64), np.uint8)
+    for i in range(m):
+        oracle.lib.bjjref_mul_scalar(oracle._p(pts[i]), oracle._p(wsc[i]), ctypes.c_size_t(wb), oracle._p(want_w[i]))
+    assert (gpu_ctx.mul_var_base_wide(pts[:m], wsc, wb) == want_w).all()
     # verification with corruption anywhere
     A, R, S, M = pk.copy(), r.copy(), s.copy(), msgs.copy()
     for arr in (A, R, S, M):
