@@ -518,7 +518,13 @@ def main():
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import babyjubjub_rs_amd as bjj
-    ctx = bjj.Context(local_rank, args.window_bits)
+    try:
+        ctx = bjj.Context(local_rank, args.window_bits)
+    except bjj.BjjError as e:
+        if "cannot allocate the fixed-base table" not in str(e):
+            raise
+        # the requested table does not fit next to the GPU's other tenants: take the widest that does, and say so in `config`
+        ctx = bjj.Context(local_rank, bjj.WINDOW_AUTO)
     n = args.batch
     ctx.reserve(max(n, 1))
     stream = torch.cuda.Stream(device=dev)

@@ -11,13 +11,14 @@ import bench
 kind = sys.argv[1] if len(sys.argv) > 1 else "fixed_base"
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
 dev = torch.device("cuda", 0)
-ctx = bjj.Context(0, int(os.environ.get("W", "0")))
+ctx = bjj.Context(0, int(os.environ.get("W", "28")))
 n = 1 << 20
 ctx.reserve(n)
 st = torch.cuda.Stream(device=dev)
 wl = bench.Workload(ctx, kind, n, 0, dev, st)
 if os.environ.get("REPEAT") == "1" and kind == "fixed_base":   # every lane multiplies by the same scalar
-    wl.d_sc.view(n, 32)[:] = wl.d_sc.view(n, 32)[0].clone()
+    wl.batches[0].d_sc.view(n, 32)[:] = wl.batches[0].d_sc.view(n, 32)[0].clone()
+    torch.cuda.synchronize()
 for _ in range(3):
     wl.launch()
 st.synchronize()
