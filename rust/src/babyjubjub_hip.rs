@@ -18,7 +18,7 @@ pub mod multi;
 
 use ff::{Field, PrimeField};
 use gpu::with_gpu;
-use num_bigint::{BigInt, RandBigInt, Sign, ToBigInt};
+use num_bigint::{BigInt, RandBigInt, Sign};
 use num_traits::Zero;
 
 pub type Fr = poseidon_rs::Fr; // lib.rs:7
@@ -233,8 +233,7 @@ impl PrivateKey {
         if m > q() || m.sign() == Sign::Minus {
             return Err("msg outside the Finite Field".to_string());
         }
-        let mut rng = rand::thread_rng();
-        let k = rng.gen_biguint(1024).to_bigint().unwrap();
+        let k = BigInt::from(rand::thread_rng().gen_biguint(1024));
         let (r, s, ok) = with_gpu(|g| g.sign_schnorr(&self.key, &bigint_to_le(&m, 32), &bigint_to_le(&k, ffi::BJJ_SCHNORR_NONCE_BYTES)))?;
         if ok[0] == 0 {
             return Err("msg outside the Finite Field".to_string());
@@ -269,11 +268,10 @@ pub fn verify_schnorr(pk: Point, m: BigInt, r: Point, s: BigInt) -> Result<bool,
 }
 
 pub fn new_key() -> PrivateKey {
-    // lib.rs:387-393
-    let mut rng = rand::thread_rng();
-    let sk_raw = rng.gen_biguint(1024).to_bigint().unwrap();
-    let (_, sk_raw_bytes) = sk_raw.to_bytes_be();
-    PrivateKey::import(sk_raw_bytes[..32].to_vec()).unwrap()
+    // lib.rs:387-393: 1024 random bits; the first 32 bytes of their big-endian form become the key
+    let raw = rand::thread_rng().gen_biguint(1024);
+    let be = raw.to_bytes_be();
+    PrivateKey::import(be[..32].to_vec()).unwrap()
 }
 
 pub fn verify(pk: Point, sig: Signature, msg: BigInt) -> bool {
