@@ -46,9 +46,10 @@ BJJ_HD void store_niels(u32* p, const Niels& n) {
 // {0..8} * P in projective-Niels form, an entry = the raw 4 x 9 limb words (144 B, nine 16-byte quarters).
 // -DBJJ_PNIELS_PACKED=1 is the measured-and-rejected alternative: four 256-bit integers per entry (128 B = one cache
 // line; Y-X weakly reduced first so that every component is below 2^256) and no stored identity (digit 0 selects the
-// constant (1, 1, 0, 2)): 1 KB instead of 1 296 B per lane and table, ~40 % less HBM-side traffic -- and 1.3 % (variable
-// base) / 3 % (verify) SLOWER, because the unpacking costs ~100 plain instructions per entry in a kernel that is bound by
-// VALU issue, not by bytes (profiles/r02_ab_pniels_packed_rejected.txt).
+// constant (1, 1, 0, 2)): 1 KB instead of 1 296 B per lane and table, 40-47 % less HBM-side traffic -- for a result within
+// +-3 % whose sign depends on the chip (slower under the bench protocol on one box, faster in sustained loops on a more
+// power-limited one): the unpacking costs ~100 plain instructions per entry in kernels that are bound by VALU issue, not by
+// bytes (profiles/r02_ab_pniels_packed.txt).
 #if !defined(BJJ_PNIELS_PACKED)
 constexpr int PNIELS_WORDS = 36;
 constexpr int VB_TABLE_ENTRIES = 9;  // 0*P .. 8*P
