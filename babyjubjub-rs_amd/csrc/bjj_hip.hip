@@ -125,7 +125,7 @@ static int ensure_scratch(bjj_ctx* c, size_t n) {
     HIPCK(hipMalloc((void**)&c->slow, (n + 16) * sizeof(u32)));
     c->slow_items = n;
   }
-  size_t tv = (size_t)c->occ_var * BJJ_EPI_BLOCK, te = (size_t)c->occ_verify * BJJ_BLOCK * 2;  // verify: 2 tables per lane
+  size_t tv = (size_t)c->occ_var, te = (size_t)c->occ_verify * BJJ_BLOCK * 2;  // lanes per CU; verify: 2 tables per lane
   size_t threads = (size_t)c->cus * (tv > te ? tv : te);
   if (threads > c->vb_threads) {
     if (c->vb_tables) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->vb_tables)); c->vb_tables = nullptr; }
@@ -317,8 +317,8 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   }
   c->W = W;
   c->nwin = fixed_nwin(W);
-  c->occ_fixed = bjjk::occ_fixed_base();
-  c->occ_var = bjjk::occ_var_base();
+  c->occ_fixed = bjjk::fixed_base_lanes_per_cu();   // resident LANES per CU, like occ_var
+  c->occ_var = bjjk::var_base_lanes_per_cu();   // resident LANES per CU (the other occ_* are workgroups per CU)
   c->occ_poseidon = bjjk::occ_poseidon5();
   c->occ_verify = bjjk::occ_verify();
   c->occ_scan = bjjk::occ_verify_scan();
@@ -436,7 +436,7 @@ int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_
   CHECK_PTR(d_scalars, "bjj_mul_fixed_base_dev"); CHECK_PTR(d_out, "bjj_mul_fixed_base_dev");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   DEV_ENTER(c, stream);
-  LAUNCHCK(bjjk::mul_fixed_base(st, grid_for(c, n, c->occ_fixed, BJJ_EPI_BLOCK), c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
+  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->occ_fixed, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
                                 (uint8_t*)d_out, c->scratch), "bjj_mul_fixed_base_dev");
   DEV_LEAVE(c);
 }
@@ -451,7 +451,7 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   DEV_ENTER(c, stream);
-  LAUNCHCK(bjjk::mul_var_base(st, grid_for(c, n, c->occ_var, BJJ_EPI_BLOCK), c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
+  LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->occ_var, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
                               (int)(scalar_bytes / 4), n, (uint8_t*)d_out, c->scratch, c->vb_tables, c->slow), "bjj_mul_var_base_dev");
   DEV_LEAVE(c);
 }
@@ -587,7 +587,7 @@ int bjj_public_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy
   // B8.mul_scalar(&self.scalar_key()), src/lib.rs:304-306; the scalar keys live in the codec scratch only for the
   // duration of the multiplication and are wiped on the same stream right behind it
   LAUNCHCK(bjjk::scalar_keys(st, grid_for(c, n, 4), (const uint8_t*)d_keys, n, c->codec), "scalar_keys");
-  LAUNCHCK(bjjk::mul_fixed_base(st, grid_for(c, n, c->occ_fixed, BJJ_EPI_BLOCK), c->table, c->W, c->nwin, c->codec, n, (uint8_t*)d_out_xy,
+  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->occ_fixed, c->table, c->W, c->nwin, c->codec, n, (uint8_t*)d_out_xy,
                                 c->scratch), "mul_fixed_base");
   HIPCK(hipMemsetAsync(c->codec, 0, n * 32, st));
   DEV_LEAVE(c);

@@ -106,9 +106,10 @@ __device__ __forceinline__ void epilogue_finish(Fr& inv, uint8_t* out_item, cons
   fr_to_words(x, w); store_w8(out_item, w);
   fr_to_words(y, w); store_w8(out_item + 32, w);
 }
+template <int BLOCK = BJJ_EPI_BLOCK>
 __device__ __forceinline__ void epilogue_run(Fr run, size_t n, size_t tid, size_t nthreads, uint8_t* out, u32* scratch,
                                              u32* lds) {
-  Fr inv = fr_mul(block_invert<BJJ_EPI_BLOCK>(run, lds), fr_one_plain());  // out of Montgomery form once per lane
+  Fr inv = fr_mul(block_invert<BLOCK>(run, lds), fr_one_plain());  // out of Montgomery form once per lane
   if (tid >= n) return;
   size_t cnt = (n - tid + nthreads - 1) / nthreads;
 #pragma unroll 1

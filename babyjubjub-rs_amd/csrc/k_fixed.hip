@@ -2,6 +2,18 @@
 // (src/lib.rs:149-164 with self = B8, src/lib.rs:37-46; the engine of PrivateKey::public, :304-306).
 #include "k_common.hpp"
 
+// workgroup size / resident workgroups per CU / staging areas per wave of K1 (A/B knobs; default: one 512-lane workgroup
+// per CU = 2 waves per SIMD, two 8 KB staging areas per wave)
+#ifndef BJJ_K1_BLOCK
+#define BJJ_K1_BLOCK BJJ_EPI_BLOCK
+#endif
+#ifndef BJJ_K1_MIN_BLOCKS
+#define BJJ_K1_MIN_BLOCKS 1
+#endif
+#ifndef BJJ_K1_NBUF
+#define BJJ_K1_NBUF 2
+#endif
+
 // ---------------------------------------------------------------------------
 // init: fixed-base table (layout and recoding: bjj_device.hpp "fixed base").
 //   bases:  one thread per window j -> P_j = 2^(W j) * B8 (ladder + inversion; nwin threads)
@@ -36,15 +48,15 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_check_fixed_table(const u32* 
 }
 
 
-__global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
+__global__ void __launch_bounds__(BJJ_K1_BLOCK, BJJ_K1_MIN_BLOCKS) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
                                                                   const uint8_t* __restrict__ scalars, size_t n,
                                                                   uint8_t* __restrict__ out, u32* __restrict__ scratch) {
   __shared__ u32 lds[NL * 64];
-  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_EPI_BLOCK / 64) * 2 * FB_STAGE_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_K1_BLOCK / 64) * BJJ_K1_NBUF * FB_STAGE_WORDS];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   const int lane = threadIdx.x & 63;
-  const GatherCoopLds<2> fb = {table, stage + (threadIdx.x >> 6) * 2 * FB_STAGE_WORDS, lane};
+  const GatherCoopLds<BJJ_K1_NBUF> fb = {table, stage + (threadIdx.x >> 6) * BJJ_K1_NBUF * FB_STAGE_WORDS, lane};
   Fr run = fr_one();
 #pragma unroll 1
   for (size_t i = tid; i - lane < n; i += nthreads) {  // wave-uniform trip count: the gathers are cooperative
@@ -54,12 +66,12 @@ __global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_fixed_base(const u32*
     Ext p = fixed_base_mul(fb, W, nwin, sc, c_K);
     if (valid) epilogue_stash(p, run, out + i * 64, scratch + i * 16);
   }
-  epilogue_run(run, n, tid, nthreads, out, scratch, lds);
+  epilogue_run<BJJ_K1_BLOCK>(run, n, tid, nthreads, out, scratch, lds);
 }
 
 // ---- launchers (declared in bjj_launch.hpp) ------------------------------------------------------------
 namespace bjjk {
-int occ_fixed_base() { return occupancy_of(bjj_k_mul_fixed_base, BJJ_EPI_BLOCK); }
+int fixed_base_lanes_per_cu() { return occupancy_of(bjj_k_mul_fixed_base, BJJ_K1_BLOCK) * BJJ_K1_BLOCK; }
 hipError_t build_fixed_table(hipStream_t st, u32* table, u32* bases, int W, int nwin) {
   const size_t entries = fixed_stride(W) * (size_t)nwin;
   // chain length: long enough to amortise the start ladder and the inversion, short enough to fill the GPU
@@ -76,9 +88,11 @@ hipError_t check_fixed_table(hipStream_t st, int grid, const u32* table, const u
   hipLaunchKernelGGL(bjj_k_check_fixed_table, dim3((unsigned)grid), dim3(BJJ_BLOCK), 0, st, table, bases, W, nwin, d_bad);
   return hipGetLastError();
 }
-hipError_t mul_fixed_base(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* scalars, size_t n,
+hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, const u32* table, int W, int nwin, const uint8_t* scalars, size_t n,
                           uint8_t* out, u32* scratch) {
-  hipLaunchKernelGGL(bjj_k_mul_fixed_base, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
+  const size_t want = (n + BJJ_K1_BLOCK - 1) / BJJ_K1_BLOCK, cap = (size_t)cus * (size_t)(lanes_per_cu / BJJ_K1_BLOCK);
+  const int grid = (int)(want < cap ? (want ? want : 1) : cap);
+  hipLaunchKernelGGL(bjj_k_mul_fixed_base, dim3(grid), dim3(BJJ_K1_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
   return hipGetLastError();
 }
 }  // namespace bjjk

@@ -2,6 +2,17 @@
 // PointProjective::add / affine (src/lib.rs:88-131, 70-85).
 #include "k_common.hpp"
 
+// Workgroup size / resident workgroups per CU of K2.  Three 256-lane workgroups per CU = 3 waves per SIMD at 168 VGPRs
+// (+112 B of scratch per lane) issue 1.2-2.5 % more than one 512-lane workgroup = 2 waves per SIMD at 229 VGPRs, although
+// 2^20 items no longer divide evenly over the 196 608 resident lanes; 4 waves per SIMD (128 VGPRs, 400 B of scratch) lose
+// 2 % (profiles/r02_ab_occupancy.txt).  K1 and the verify kernel were measured the same way and stay at 2 waves per SIMD.
+#ifndef BJJ_K2_BLOCK
+#define BJJ_K2_BLOCK 256
+#endif
+#ifndef BJJ_K2_MIN_BLOCKS
+#define BJJ_K2_MIN_BLOCKS 3
+#endif
+
 // (n >> 3) mod l of a little-endian integer of nw words, as 8 words -> n mod 8l = 8*that + (n & 7) < 2^254.
 // Horner over 261-bit chunks, most significant first: acc <- acc * 2^261 + chunk (mod l), with the mod-l Montgomery
 // products of the signer row (fl_mul(acc, 2^522) = acc * 2^261, fl_mul(chunk, 2^261) = chunk; each < 2l).
@@ -57,16 +68,16 @@ __device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, c
     }
     epilogue_stash(p, run, out + i * 64, scratch + i * 16);
   }
-  epilogue_run(run, n, tid, nthreads, out, scratch, lds);
+  epilogue_run<BJJ_K2_BLOCK>(run, n, tid, nthreads, out, scratch, lds);
 }
-__global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
+__global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
                                                                 const uint8_t* __restrict__ scalars, size_t n,
                                                                 uint8_t* __restrict__ out, u32* __restrict__ scratch,
                                                                 u32* __restrict__ vb_tables, u32* __restrict__ slow) {
   __shared__ u32 lds[NL * 64];
   var_base_body<false>(pts, scalars, 8, n, out, scratch, vb_tables, slow, lds);
 }
-__global__ void __launch_bounds__(BJJ_EPI_BLOCK) bjj_k_mul_var_base_wide(const uint8_t* __restrict__ pts,
+__global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_wide(const uint8_t* __restrict__ pts,
                                                                      const uint8_t* __restrict__ scalars, int sc_words, size_t n,
                                                                      uint8_t* __restrict__ out, u32* __restrict__ scratch,
                                                                      u32* __restrict__ vb_tables, u32* __restrict__ slow) {
@@ -149,23 +160,25 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_proj_affine(const uint8_t* __
 }
 
 namespace bjjk {
-int occ_var_base() {
-  const int a = occupancy_of(bjj_k_mul_var_base, BJJ_EPI_BLOCK), b = occupancy_of(bjj_k_mul_var_base_wide, BJJ_EPI_BLOCK);
-  return a < b ? a : b;   // one grid size (and one per-lane table allocation) serves both
+int var_base_lanes_per_cu() {   // resident lanes of K2 per CU (sizes the per-lane table scratch and the grid)
+  const int a = occupancy_of(bjj_k_mul_var_base, BJJ_K2_BLOCK), b = occupancy_of(bjj_k_mul_var_base_wide, BJJ_K2_BLOCK);
+  return (a < b ? a : b) * BJJ_K2_BLOCK;   // one grid size (and one per-lane table allocation) serves both kernels
 }
 int occ_point_add() {
   const int a = occupancy_of(bjj_k_point_add, BJJ_BLOCK), b = occupancy_of(bjj_k_proj_add, BJJ_BLOCK),
             c = occupancy_of(bjj_k_proj_affine, BJJ_BLOCK);
   return a < b ? (a < c ? a : c) : (b < c ? b : c);
 }
-hipError_t mul_var_base(hipStream_t st, int grid, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
+hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
                         uint8_t* out, u32* scratch, u32* vb_tables, u32* slow) {
   hipError_t e = hipMemsetAsync(slow, 0, 8 * sizeof(u32), st);
   if (e != hipSuccess) return e;
+  const size_t want = (n + BJJ_K2_BLOCK - 1) / BJJ_K2_BLOCK, cap = (size_t)cus * (size_t)(lanes_per_cu / BJJ_K2_BLOCK);
+  const int grid = (int)(want < cap ? (want ? want : 1) : cap);
   if (sc_words == 8)
-    hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow);
+    hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow);
   else
-    hipLaunchKernelGGL(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
+    hipLaunchKernelGGL(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
                        vb_tables, slow);
   e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -1,6 +1,11 @@
 // libbjj_hip.so, kernel unit 4: K4, verify(pk, sig, msg) (src/lib.rs:395-412) and verify_schnorr (:375-385).
 #include "k_common.hpp"
 
+// resident workgroups per CU the verify kernels are compiled for (A/B knob): 2 = 256 VGPRs, 3 = 168 VGPRs and more scratch
+#ifndef BJJ_VERIFY_MIN_BLOCKS
+#define BJJ_VERIFY_MIN_BLOCKS 2
+#endif
+
 // ---------------------------------------------------------------------------
 // K4: EdDSA-Poseidon verify, two launches:
 //  (1) bjj_k_eddsa_verify_scan: on-curve tests only (14 multiplications per item); items whose
@@ -63,7 +68,7 @@ __device__ __forceinline__ void verify_kernel_body(const u32* __restrict__ table
   }
 }
 // verify_schnorr (src/lib.rs:375-385): same structure, verdict 2 = Err (msg > Q)
-__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_schnorr_verify(const u32* __restrict__ table, int W, int nwin,
+__global__ void __launch_bounds__(BJJ_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k_schnorr_verify(const u32* __restrict__ table, int W, int nwin,
                                                                      const uint8_t* __restrict__ pk,
                                                                      const uint8_t* __restrict__ rb8,
                                                                      const uint8_t* __restrict__ s,
@@ -72,7 +77,7 @@ __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_schnorr_verify(const u32* 
                                                                      u32* __restrict__ wl) {
   verify_kernel_body<true>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
 }
-__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
+__global__ void __launch_bounds__(BJJ_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
                                                                    const uint8_t* __restrict__ pk,
                                                                    const uint8_t* __restrict__ rb8,
                                                                    const uint8_t* __restrict__ s,
