@@ -2,10 +2,15 @@
 // (src/lib.rs:166-224, 260-268) and PrivateKey::scalar_key (src/lib.rs:284-302).
 #include "k_common.hpp"
 
+// resident 256-lane workgroups per CU the Poseidon kernel is compiled for (A/B knob)
+#ifndef BJJ_POSEIDON_MIN_BLOCKS
+#define BJJ_POSEIDON_MIN_BLOCKS 2
+#endif
+
 // ---------------------------------------------------------------------------
 // K3: Poseidon, 5 inputs
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_poseidon5(const uint8_t* __restrict__ in, size_t n,
+__global__ void __launch_bounds__(BJJ_BLOCK, BJJ_POSEIDON_MIN_BLOCKS) bjj_k_poseidon5(const uint8_t* __restrict__ in, size_t n,
                                                              uint8_t* __restrict__ out) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
