@@ -15,9 +15,9 @@
 //                                               K4  verify / verify_schnorr        src/lib.rs:395-412, 375-385
 //   k_sign.hip        bjj_k_sign / bjj_k_sign_schnorr                              src/lib.rs:308-361
 // K5 (batched affine conversion) is the epilogue of K1/K2 (k_common.hpp: block_invert).
-// Multi-GPU: bjj_multi_* at the end of this file -- one context per device, contiguous
-// ceil(n/G) blocks, RCCL (loaded with dlopen, only when a multi handle spans more than ... any devices) for the
-// scatter of inputs / gather of results of the device-resident form.
+// Multi-GPU: bjj_multi_* (bjj_multi.inc, included at the end of this file) -- one context per device,
+// contiguous ceil(n/G) blocks; the device-resident form scatters inputs / gathers results with RCCL (bound with dlopen on
+// first use) or with peer copies.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdio.h>
@@ -63,9 +63,11 @@ struct bjj_ctx {
   int cus = 0;
   int W = 16, nwin = 16;
   double init_ms = 0.0;
-  // resident workgroups per CU of each kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor):
-  // grids are sized to exactly one resident wave of workgroups, items are grid-strided
-  int occ_fixed = 1, occ_var = 1, occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
+  // residency of each kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor): grids are sized to exactly one resident set
+  // of workgroups, items are grid-strided.  K1 / K2: resident LANES per CU (their workgroup size is the kernel unit's
+  // business); the others: resident 256-lane workgroups per CU
+  int lanes_fixed = 512, lanes_var = 512;
+  int occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
   int occ_decomp = 1, occ_sign = 1, occ_sign_schnorr = 1;
   hipStream_t stream = nullptr;
   u32* table = nullptr;      // [window][digit 0 .. 2^(W-1)] x 128 B
@@ -125,7 +127,7 @@ static int ensure_scratch(bjj_ctx* c, size_t n) {
     HIPCK(hipMalloc((void**)&c->slow, (n + 16) * sizeof(u32)));
     c->slow_items = n;
   }
-  size_t tv = (size_t)c->occ_var, te = (size_t)c->occ_verify * BJJ_BLOCK * 2;  // lanes per CU; verify: 2 tables per lane
+  size_t tv = (size_t)c->lanes_var, te = (size_t)c->occ_verify * BJJ_BLOCK * 2;  // lanes per CU; verify: 2 tables per lane
   size_t threads = (size_t)c->cus * (tv > te ? tv : te);
   if (threads > c->vb_threads) {
     if (c->vb_tables) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->vb_tables)); c->vb_tables = nullptr; }
@@ -317,8 +319,8 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   }
   c->W = W;
   c->nwin = fixed_nwin(W);
-  c->occ_fixed = bjjk::fixed_base_lanes_per_cu();   // resident LANES per CU, like occ_var
-  c->occ_var = bjjk::var_base_lanes_per_cu();   // resident LANES per CU (the other occ_* are workgroups per CU)
+  c->lanes_fixed = bjjk::fixed_base_lanes_per_cu();
+  c->lanes_var = bjjk::var_base_lanes_per_cu();
   c->occ_poseidon = bjjk::occ_poseidon5();
   c->occ_verify = bjjk::occ_verify();
   c->occ_scan = bjjk::occ_verify_scan();
@@ -436,7 +438,7 @@ int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_
   CHECK_PTR(d_scalars, "bjj_mul_fixed_base_dev"); CHECK_PTR(d_out, "bjj_mul_fixed_base_dev");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   DEV_ENTER(c, stream);
-  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->occ_fixed, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
+  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->lanes_fixed, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
                                 (uint8_t*)d_out, c->scratch), "bjj_mul_fixed_base_dev");
   DEV_LEAVE(c);
 }
@@ -451,7 +453,7 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   int rc = ensure_scratch(c, n); if (rc) return rc;
   DEV_ENTER(c, stream);
-  LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->occ_var, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
+  LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
                               (int)(scalar_bytes / 4), n, (uint8_t*)d_out, c->scratch, c->vb_tables, c->slow), "bjj_mul_var_base_dev");
   DEV_LEAVE(c);
 }
@@ -587,7 +589,7 @@ int bjj_public_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy
   // B8.mul_scalar(&self.scalar_key()), src/lib.rs:304-306; the scalar keys live in the codec scratch only for the
   // duration of the multiplication and are wiped on the same stream right behind it
   LAUNCHCK(bjjk::scalar_keys(st, grid_for(c, n, 4), (const uint8_t*)d_keys, n, c->codec), "scalar_keys");
-  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->occ_fixed, c->table, c->W, c->nwin, c->codec, n, (uint8_t*)d_out_xy,
+  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->lanes_fixed, c->table, c->W, c->nwin, c->codec, n, (uint8_t*)d_out_xy,
                                 c->scratch), "mul_fixed_base");
   HIPCK(hipMemsetAsync(c->codec, 0, n * 32, st));
   DEV_LEAVE(c);

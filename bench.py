@@ -122,13 +122,12 @@ class Batch:
 class Workload:
     """Device-resident synthetic inputs for one rank (`nb` distinct batches), and the launch closure."""
 
-    def __init__(self, ctx, kind, n, offset, dev, stream, nb=1, stride=None):
+    def __init__(self, ctx, kind, n, offset, dev, stream, nb=1):
         from babyjubjub_rs_amd import workload as w
         self.kind, self.n, self.ctx, self.stream, self.dev = kind, n, ctx, stream, dev
         self.batches = []
-        stride = stride if stride is not None else n
         for b in range(nb):
-            self.batches.append(self._make(w, offset + b * stride * 1009))   # distinct SplitMix64 windows per batch
+            self.batches.append(self._make(w, offset + b * n * 1009))   # distinct SplitMix64 windows per batch
         self.last = 0
 
     def _up(self, a):
