@@ -253,24 +253,32 @@ BJJ_HD void vb_build_table(const Ext& P, u32* tbl, const Consts& K) {
 // nwin windows of 4 bits, most significant first; needs sc < 2^(4*nwin - 2) so that the
 // signed recoding (add 0x88..8, digit = nibble - 8) cannot carry out of the top window: the top
 // nibble plus an incoming carry must stay below 8 (callers pass nwin = 64 with sc < 2^254).
-BJJ_HD Ext vb_mul_windowed(const u32* tbl, const u32 sc[8], int nwin) {
+// The T coordinate of an addition is only read by a following ADDITION: every addition here is followed by the four
+// doublings of the next window (which never read T), so it is computed only for the very last one, and only when the caller
+// goes on adding (final_t).  The top window is peeled off the loop -- inside the loop the compiler cannot see that the
+// "no doublings yet" case never recurs, and would keep every T alive.
+BJJ_HD Ext vb_mul_windowed(const u32* tbl, const u32 sc[8], int nwin, bool final_t = false) {
   u32 t[8];
   u64 c = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) { c += (u64)sc[i] + 0x88888888u; t[i] = (u32)c; c >>= 32; }
-  Ext acc = ext_identity();
+  Ext acc;
+  {
+    const int j = nwin - 1;
+    const int d = (int)((t[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
+    const PNiels e = vb_table_load(tbl, (u32)(d < 0 ? -d : d));
+    acc = ext_add_pn(ext_identity(), pniels_cneg(e, d < 0), final_t && nwin == 1);
+  }
 #pragma unroll 1
-  for (int j = nwin - 1; j >= 0; j--) {
+  for (int j = nwin - 2; j >= 0; j--) {
     int d = (int)((t[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
     bool neg = d < 0;
     u32 idx = (u32)(neg ? -d : d);
     PNiels e = vb_table_load(tbl, idx);  // issued ahead of the doublings
-    if (j != nwin - 1) {
 #pragma unroll 1
-      for (int k = 0; k < 3; k++) acc = ext_dbl<false>(acc);
-      acc = ext_dbl<true>(acc);
-    }
-    acc = ext_add_pn(acc, pniels_cneg(e, neg));
+    for (int k = 0; k < 3; k++) acc = ext_dbl<false>(acc);
+    acc = ext_dbl<true>(acc);
+    acc = ext_add_pn(acc, pniels_cneg(e, neg), final_t && j == 0);
   }
   return acc;
 }
@@ -738,20 +746,27 @@ BJJ_HD Ext joint_mul_windowed(const u32* tbl1, const u32* tbl2, const Fr& u, con
   u32 tu[8], tv[8];
   recode_signed4(u, tu);
   recode_signed4(vmag, tv);
-  Ext acc = ext_identity();
+  Ext acc;
+  {  // top window, peeled (see vb_mul_windowed): two additions to the identity, no doublings
+    const int j = nwin - 1;
+    const int du = (int)((tu[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
+    const int dv = (int)((tv[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
+    const PNiels e1 = vb_table_load(tbl1, (u32)(du < 0 ? -du : du));
+    const PNiels e2 = vb_table_load(tbl2, (u32)(dv < 0 ? -dv : dv));
+    acc = ext_add_pn(ext_identity(), pniels_cneg(e1, du < 0));
+    acc = ext_add_pn(acc, pniels_cneg(e2, dv < 0), nwin == 1);
+  }
 #pragma unroll 1
-  for (int j = nwin - 1; j >= 0; j--) {
+  for (int j = nwin - 2; j >= 0; j--) {
     const int du = (int)((tu[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
     const int dv = (int)((tv[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
     PNiels e1 = vb_table_load(tbl1, (u32)(du < 0 ? -du : du));
     PNiels e2 = vb_table_load(tbl2, (u32)(dv < 0 ? -dv : dv));
-    if (j != nwin - 1) {
 #pragma unroll 1
-      for (int k = 0; k < 3; k++) acc = ext_dbl<false>(acc);
-      acc = ext_dbl<true>(acc);
-    }
+    for (int k = 0; k < 3; k++) acc = ext_dbl<false>(acc);
+    acc = ext_dbl<true>(acc);
     acc = ext_add_pn(acc, pniels_cneg(e1, du < 0));
-    acc = ext_add_pn(acc, pniels_cneg(e2, dv < 0));
+    acc = ext_add_pn(acc, pniels_cneg(e2, dv < 0), j == 0);   // T only for the caller's next addition (the fixed-base part)
   }
   return acc;
 }
@@ -792,7 +807,7 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* 
     fr_to_words(hm_plain, kw);
     Ext negA = ext_from_ref_affine(fr_neg(ax), ay, K);
     vb_build_table(negA, vb_tbl, K);
-    Ext q = vb_mul_windowed(vb_tbl, kw, 64);                    // scalar < 2^254
+    Ext q = vb_mul_windowed(vb_tbl, kw, 64, true);              // scalar < 2^254; T for the addition chain that follows
     u32 sl[8];
     scalar_mod_l(sw, sl, K);                                    // B8 has order l
     q = fixed_base_accumulate(q, fb, W, nwin, sl, K);           // + s*B8   (:377)

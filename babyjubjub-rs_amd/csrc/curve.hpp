@@ -77,8 +77,9 @@ BJJ_HD Ext ext_madd(const Ext& p, const Niels& q) {
   if (NEED_T) r.T = fr_mul(e, h); else r.T = fr_zero();
   return r;
 }
-// P + Q, Q projective-precomputed (entries carried).  8M.
-BJJ_HD Ext ext_add_pn(const Ext& p, const PNiels& q) {
+// P + Q, Q projective-precomputed (entries carried).  8M; 7M when the caller does not need T (need_t is wave-uniform in
+// the kernels: a doubling follows, which never reads T).
+BJJ_HD Ext ext_add_pn(const Ext& p, const PNiels& q, bool need_t = true) {
   Fr a = fr_mul(fr_sub_lazy(p.Y, p.X), q.ymx);
   Fr b = fr_mul(fr_add_lazy(p.Y, p.X), q.ypx);
   Fr c = fr_mul(p.T, q.t2d);
@@ -88,7 +89,9 @@ BJJ_HD Ext ext_add_pn(const Ext& p, const PNiels& q) {
   Fr g = fr_add_lazy(d, c);                      // limbs < 2^30
   Fr h = fr_add_lazy(b, a);                      // limbs < 2^30
   Ext r;
-  r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.T = fr_mul(e, h); r.Z = fr_mul(f, g);
+  r.X = fr_mul(e, f); r.Y = fr_mul(g, h); r.Z = fr_mul(f, g);
+  r.T = fr_zero();
+  if (need_t) r.T = fr_mul(e, h);
   return r;
 }
 // 2P (dbl-2008-hwcd with a = -1; all four outputs negated, which is the same
