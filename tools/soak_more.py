@@ -9,7 +9,7 @@ import babyjubjub_rs_amd as bjj
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 orc = conftest.Oracle()
-ctx = bjj.Context(0, 0)
+ctx = bjj.Context(0, int(os.environ.get("W", "0")))   # default table (23 bits); W=28 for the benchmark table
 bad = 0
 for seed in range(first, first + count):
     try:
