@@ -36,6 +36,17 @@ def test_bench_gpus_2_self_launch_shared_gpu():
     assert s["verify_total"]["total_items"] == 1 << 18 and s["verify_total"]["rank0_resident"]["gathered_verdicts_ok"]
 
 
+def test_bench_gpus_3_ragged_strong_total():
+    """three ranks and a total that does not divide: exact-size blocks out, verdicts back, every verdict checked on rank 0"""
+    r, j = _run(["--gpus", "3", "--steps", "2", "--warmup", "1", "--warmup-seconds", "0", "--batch", "20000", "--batches", "1",
+                 "--window-bits", "12", "--strong-total", "100003", "--no-cpu-baseline", "--no-also"],
+                {"BJJ_BENCH_SHARE_GPU": "1", "BJJ_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert j["n_gpus"] == 3 and j["parity_sample_ok"] is True and len(j["devices"]) == 3
+    v = j["strong"]["verify_total"]
+    assert v["total_items"] == 100003 and v["rank0_resident"]["gathered_verdicts_ok"]
+
+
 def test_bench_rejects_world_size_mismatch():
     r, j = _run(["--gpus", "2", "--no-also", "--no-strong"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, 300)
     assert r.returncode != 0 and j is None and "WORLD_SIZE=1 but --gpus 2" in r.stderr
