@@ -112,9 +112,29 @@ static void test_batch() {
   for (size_t i = 0; i < n.size(); i++) ASSERT_TRUE(a[i].equals(b[i]));
   ASSERT_TRUE(a[0].equals(B8()));  // n = 1
 }
+static void test_multi() {  // the single-process multi-GPU handle (bjj_multi_*) from a compiled-language host: two contexts on device 0
+  MultiContext m({0, 0}, 12);
+  ASSERT_EQ(m.size(), 2);
+  std::vector<uint8_t> kb(32); for (int i = 0; i < 32; i++) kb[i] = (uint8_t)(3 * i + 5);
+  PrivateKey sk = PrivateKey::import(kb);
+  Point pk = sk.public_key();
+  std::vector<Point> pks; std::vector<Signature> sigs; std::vector<U256> msgs;
+  for (uint64_t i = 0; i < 101; i++) {   // odd count: ragged blocks of 51 and 50
+    U256 msg(1000 + i);
+    Signature sg = sk.sign(msg);
+    if (i % 7 == 3) sg.s.le[1] ^= 4;    // corrupt some
+    pks.push_back(pk); sigs.push_back(sg); msgs.push_back(msg);
+  }
+  std::vector<uint8_t> got = m.verify_batch(pks, sigs, msgs), want = verify_batch(pks, sigs, msgs);
+  ASSERT_TRUE(got == want);
+  for (size_t i = 0; i < got.size(); i++) ASSERT_EQ((int)got[i], (i % 7 == 3) ? 0 : 1);
+  std::vector<U256> n; for (uint64_t i = 0; i < 77; i++) n.push_back(U256(i * 0x9E3779B97F4A7C15ULL + 3));
+  std::vector<Point> a = m.mul_fixed_base_batch(n), b = mul_fixed_base_batch(n);
+  for (size_t i = 0; i < n.size(); i++) ASSERT_TRUE(a[i].equals(b[i]));
+}
 int main() {
   try {
-    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_point_compress_decompress(); test_schnorr_signature(); test_batch();
+    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_point_compress_decompress(); test_schnorr_signature(); test_batch(); test_multi();
   } catch (const std::exception& e) { printf("EXCEPTION %s\n", e.what()); return 2; }
   printf(failures ? "FAILED %d\n" : "ok (reference tests re-stated in C++)\n", failures);
   return failures ? 1 : 0;
