@@ -239,16 +239,31 @@ BJJ_HD Ext fixed_base_mul(const u32* table, int W, int nwin, const u32 raw[8], c
 // signed 4-bit windows, per-lane table tbl[0..8] = {0, P, .., 8P} in thread-private
 // memory (global scratch on the GPU).
 // =============================================================================
-BJJ_HD void vb_build_table(const Ext& P, u32* tbl, const Consts& K) {
+// affine_base: P has Z == 1 (it came from ext_from_ref_affine): k*P = (k-1)*P + P is then a MIXED addition (7M, the 2Z
+// term is an addition) instead of the general one (8M).
+BJJ_HD void vb_build_table(const Ext& P, u32* tbl, const Consts& K, bool affine_base = false) {
   vb_table_store_identity(tbl);
   PNiels p1 = ext_to_pniels(P, K);
   vb_table_store(tbl, 1, p1);
+  const Niels p1a = {p1.ymx, p1.ypx, p1.t2d};
   Ext cur = P;
 #pragma unroll 1
   for (int k = 2; k <= 8; k++) {
-    cur = ext_add_pn(cur, p1);
+    cur = affine_base ? ext_madd(cur, p1a) : ext_add_pn(cur, p1);
     vb_table_store(tbl, (u32)k, ext_to_pniels(cur, K));
   }
+}
+// A table entry as an extended point (all four coordinates doubled: the same projective point):
+// (Y+X) - (Y-X) = 2X, (Y+X) + (Y-X) = 2Y, 2Z, and 2T = (2D'T) / D'.  Replaces "identity + entry" (8M) at the top
+// window of a windowed loop by one multiplication -- none when T is not needed.
+BJJ_HD Ext pniels_to_ext(const PNiels& e, const Consts& K, bool need_t) {
+  Ext r;
+  r.X = fr_reduce_weak(fr_sub8(e.ypx, e.ymx));     // entries: ymx < 8r, ypx < 4r
+  r.Y = fr_reduce_weak(fr_add(e.ypx, e.ymx));
+  r.Z = fr_reduce_weak(e.z2);
+  r.T = fr_zero();
+  if (need_t) r.T = fr_mul(e.t2d, K.DPINV);
+  return r;
 }
 // nwin windows of 4 bits, most significant first; needs sc < 2^(4*nwin - 2) so that the
 // signed recoding (add 0x88..8, digit = nibble - 8) cannot carry out of the top window: the top
@@ -257,7 +272,7 @@ BJJ_HD void vb_build_table(const Ext& P, u32* tbl, const Consts& K) {
 // doublings of the next window (which never read T), so it is computed only for the very last one, and only when the caller
 // goes on adding (final_t).  The top window is peeled off the loop -- inside the loop the compiler cannot see that the
 // "no doublings yet" case never recurs, and would keep every T alive.
-BJJ_HD Ext vb_mul_windowed(const u32* tbl, const u32 sc[8], int nwin, bool final_t = false) {
+BJJ_HD Ext vb_mul_windowed(const u32* tbl, const u32 sc[8], int nwin, const Consts& K, bool final_t = false) {
   u32 t[8];
   u64 c = 0;
 #pragma unroll
@@ -267,7 +282,7 @@ BJJ_HD Ext vb_mul_windowed(const u32* tbl, const u32 sc[8], int nwin, bool final
     const int j = nwin - 1;
     const int d = (int)((t[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
     const PNiels e = vb_table_load(tbl, (u32)(d < 0 ? -d : d));
-    acc = ext_add_pn(ext_identity(), pniels_cneg(e, d < 0), final_t && nwin == 1);
+    acc = pniels_to_ext(pniels_cneg(e, d < 0), K, final_t && nwin == 1);
   }
 #pragma unroll 1
   for (int j = nwin - 2; j >= 0; j--) {
@@ -436,8 +451,8 @@ BJJ_HD Ext var_base_fast(const Fr& x, const Fr& y, const u32 sc[8], u32* tbl, co
   u32 red[8];
   scalar_mod_order(sc, red, K);
   Ext P = ext_from_ref_affine(x, y, K);
-  vb_build_table(P, tbl, K);
-  return vb_mul_windowed(tbl, red, 64);
+  vb_build_table(P, tbl, K, true);
+  return vb_mul_windowed(tbl, red, 64, K);
 }
 // exact replay of the reference's bit-serial loop; result mapped onto the a'=-1 curve with
 // Z = 1 so that the shared affine epilogue maps it back unchanged.
@@ -742,7 +757,7 @@ BJJ_HD void recode_signed4(const Fr& sc, u32 t[8]) {
   for (int i = 0; i < 8; i++) { c += (u64)w[i] + 0x88888888u; t[i] = (u32)c; c >>= 32; }
 }
 // W = acc0 + u*P1 + |v|*P2 with per-lane tables tbl1 / tbl2 ({0..8}*P in PNiels form)
-BJJ_HD Ext joint_mul_windowed(const u32* tbl1, const u32* tbl2, const Fr& u, const Fr& vmag, int nwin) {
+BJJ_HD Ext joint_mul_windowed(const u32* tbl1, const u32* tbl2, const Fr& u, const Fr& vmag, int nwin, const Consts& K) {
   u32 tu[8], tv[8];
   recode_signed4(u, tu);
   recode_signed4(vmag, tv);
@@ -753,7 +768,7 @@ BJJ_HD Ext joint_mul_windowed(const u32* tbl1, const u32* tbl2, const Fr& u, con
     const int dv = (int)((tv[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
     const PNiels e1 = vb_table_load(tbl1, (u32)(du < 0 ? -du : du));
     const PNiels e2 = vb_table_load(tbl2, (u32)(dv < 0 ? -dv : dv));
-    acc = ext_add_pn(ext_identity(), pniels_cneg(e1, du < 0));
+    acc = pniels_to_ext(pniels_cneg(e1, du < 0), K, true);
     acc = ext_add_pn(acc, pniels_cneg(e2, dv < 0), nwin == 1);
   }
 #pragma unroll 1
@@ -806,8 +821,8 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* 
     u32 kw[8];
     fr_to_words(hm_plain, kw);
     Ext negA = ext_from_ref_affine(fr_neg(ax), ay, K);
-    vb_build_table(negA, vb_tbl, K);
-    Ext q = vb_mul_windowed(vb_tbl, kw, 64, true);              // scalar < 2^254; T for the addition chain that follows
+    vb_build_table(negA, vb_tbl, K, true);
+    Ext q = vb_mul_windowed(vb_tbl, kw, 64, K, true);           // scalar < 2^254; T for the addition chain that follows
     u32 sl[8];
     scalar_mod_l(sw, sl, K);                                    // B8 has order l
     q = fixed_base_accumulate(q, fb, W, nwin, sl, K);           // + s*B8   (:377)
@@ -830,13 +845,13 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* 
   p1 = ext_dbl<false>(p1); p1 = ext_dbl<false>(p1); p1 = ext_dbl<true>(p1);
   Ext p2 = ext_from_ref_affine(vneg ? rx : fr_neg(rx), ry, K);
   u32* tbl2 = vb_tbl + VB_TABLE_WORDS;
-  vb_build_table(p1, vb_tbl, K);
-  vb_build_table(p2, tbl2, K);
+  vb_build_table(p1, vb_tbl, K);             // -8A: three doublings, Z != 1
+  vb_build_table(p2, tbl2, K, true);         // -+R: affine
   const int ub = limbs_bits(u), vb = limbs_bits(vmag);
   // signed recoding needs top nibble + carry < 8, i.e. scalars < 2^(4*jw - 2): 34 windows cover 134 bits
   // (all but ~2e-5 of the pairs); the rest -- e.g. kappa = (l+1)/2 gives u of 250 bits -- take 64 windows
   const int jw = ((ub > vb ? ub : vb) <= 134) ? 34 : 64;
-  Ext q = joint_mul_windowed(vb_tbl, tbl2, u, vmag, jw);
+  Ext q = joint_mul_windowed(vb_tbl, tbl2, u, vmag, jw, K);
   q = fixed_base_accumulate(q, fb, W, nwin, cw, K);             // + (v s mod l)*B8
   verdict = (fr_is_zero(q.X) && fr_eq(q.Y, q.Z)) ? 1 : 0;       // projective identity (0 : z : z)
   return msg_gt ? 0 : verdict;
@@ -883,8 +898,8 @@ BJJ_HD int verify_exact_t(const VerifyIn& in, const u32* fb_table, int W, int nw
 #pragma unroll
       for (int i = 1; i < 8; i++) kw[i] = (kp[i] << 3) | (kp[i - 1] >> 29);   // 8 (hm mod l) < 8 l < 2^254
     }
-    vb_build_table(ext_from_ref_affine(ax, ay, K), vb_tbl, K);
-    Ext T = vb_mul_windowed(vb_tbl, kw, 64);
+    vb_build_table(ext_from_ref_affine(ax, ay, K), vb_tbl, K, true);
+    Ext T = vb_mul_windowed(vb_tbl, kw, 64, K);
     zi = fr_inv(fr_mul(L.Z, T.Z));
     const Fr zt = fr_mul(zi, L.Z);
     tx = fr_mul(fr_mul(T.X, zt), K.FINV); ty = fr_mul(T.Y, zt);

@@ -57,8 +57,8 @@ __device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, c
       if (WIDE) {
         wide_scalar_mod_order((const u32*)(scalars + i * (size_t)sc_words * 4), sc_words, sc);
         Ext P = ext_from_ref_affine(x, y, c_K);
-        vb_build_table(P, tbl, c_K);
-        p = vb_mul_windowed(tbl, sc, 64);
+        vb_build_table(P, tbl, c_K, true);
+        p = vb_mul_windowed(tbl, sc, 64, c_K);
       } else {
         load_w8(scalars + i * 32, sc);
         p = var_base_fast(x, y, sc, tbl, c_K);
