@@ -242,8 +242,9 @@ int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
  *                        its block, a second group gathers the results (ncclGather) into the
  *                        caller's output array.  Synchronous; the input arrays must be complete
  *                        when the call is made (no pending writes on other streams).  RCCL is loaded
- *                        with dlopen on the first such call (single process, ncclCommInitAll);
- *                        BJJ_E_RCCL if absent. */
+ *                        with dlopen on the first such call (single process, ncclCommInitAll;
+ *                        "librccl.so.1", or the library named by the environment variable
+ *                        BJJ_RCCL_LIBRARY); BJJ_E_RCCL if absent. */
 typedef struct bjj_multi bjj_multi;
 /* devices: n_devices HIP device indices (NULL = 0 .. n_devices-1; NULL and 0 = all visible devices).  A device may be
  * named more than once (several contexts on one GPU; how the G > 1 block arithmetic is tested on a one-GPU box) -- the

@@ -261,6 +261,75 @@ def test_multi_block_arithmetic_with_several_contexts_on_one_gpu(oracle, g):
         m.close()
 
 
+_FAKE_RCCL_SCRIPT = r"""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["BJJ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["BJJ_ROOT"], "tests"))
+import babyjubjub_rs_amd as bjj
+from babyjubjub_rs_amd import workload as w
+from conftest import Oracle
+orc = Oracle()
+fake = ctypes.CDLL(os.environ["BJJ_RCCL_LIBRARY"])
+cnt = (ctypes.c_long * 5)()
+dev = torch.device("cuda", 0)
+up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)
+for g in (2, 3, 8):
+    m = bjj.MultiContext([0] * g, 8)            # default transport: RCCL -- here the test double
+    for n in (g * 640, g * 640 + 5, 3, g):
+        even = n % g == 0
+        sc = w.scalars_254(n, offset=3 * n + g)
+        want = orc.mul_fixed_base(sc)
+        d_sc, d_out = up(sc), torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        fake.fake_rccl_counters(cnt)
+        m.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out.data_ptr())
+        fake.fake_rccl_counters(cnt)
+        groups, scatter, gather, send, recv = list(cnt)
+        assert groups == 2, (g, n, list(cnt))                       # one group out, one group back
+        if even:
+            assert (scatter, gather, send, recv) == (g, g, 0, 0), (g, n, list(cnt))
+        else:
+            peers = sum(1 for r in range(1, g) if m.shard_bounds(n, r)[1] > m.shard_bounds(n, r)[0])
+            assert (scatter, gather, send, recv) == (0, 0, 2 * peers, 2 * peers), (g, n, list(cnt))
+        fb = d_out.cpu().numpy().reshape(n, 64)
+        assert (fb == want).all(), (g, n)
+        A, R, S, msg = w.make_signatures(orc.mul_fixed_base, orc.poseidon5, n, offset=n)
+        bad = w.corrupt(A, R, S, msg, n, offset=n)
+        t = [up(x) for x in (A, R, S, msg)]
+        d_ok = torch.full((((n + 15) // 16) * 16,), 9, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        fake.fake_rccl_counters(cnt)
+        m.eddsa_verify_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), n, d_ok.data_ptr())
+        fake.fake_rccl_counters(cnt)
+        assert cnt[0] == 2 and (cnt[1] == 4 * g if even else cnt[3] > 0), (g, n, list(cnt))    # four input arrays in ONE group
+        got = d_ok.cpu().numpy()
+        assert (got[:n] == (~bad).astype(np.uint8)).all() and (got[n:] == 9).all(), (g, n)
+    assert m.last_timing()["rccl_version"] == 99999
+    m.close()
+print("fake-rccl ok")
+"""
+
+
+def test_multi_rccl_call_sequence_against_a_test_double():
+    """The RCCL branch of bjj_multi_* for G = 2, 3, 8 on the one-GPU box: BJJ_RCCL_LIBRARY points the library at an in-process
+    test double (tests/fake_rccl) that executes ncclScatter / ncclGather / ncclSend / ncclRecv with device copies and rejects what
+    real RCCL would reject or hang on (a rank missing from a collective, unmatched send / receive, calls outside a group).
+    Checks the buffers, offsets, counts and grouping the library hands to RCCL; every output against the oracle."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    d = os.path.join(ROOT, "tests", "fake_rccl")
+    so = os.path.join(d, "libfake_rccl.so")
+    if not os.path.exists(so) or os.path.getmtime(os.path.join(d, "fake_rccl.cpp")) > os.path.getmtime(so):
+        r = subprocess.run(["make", "-s"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+    env = dict(os.environ, BJJ_RCCL_LIBRARY=so, BJJ_ROOT=ROOT)
+    r = subprocess.run([sys.executable, "-c", _FAKE_RCCL_SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "fake-rccl ok" in r.stdout, r.stdout[-4000:]
+
+
 def test_multi_all_devices_scatter_gather(oracle):
     """every visible device (the driver's 8-GPU box; skipped on a 1-GPU box): ragged and even batches through both forms"""
     import torch
