@@ -37,12 +37,13 @@ EXPORTED_SYMBOLS = (
     "bjj_multi_init", "bjj_multi_free", "bjj_multi_size", "bjj_multi_ctx", "bjj_multi_device", "bjj_shard_bounds",
     "bjj_mul_fixed_base_multi", "bjj_mul_var_base_multi", "bjj_eddsa_verify_multi",
     "bjj_mul_fixed_base_multi_dev", "bjj_mul_var_base_multi_dev", "bjj_eddsa_verify_multi_dev",
-    "bjj_multi_last_timing", "bjj_multi_set_transport",
+    "bjj_multi_last_timing", "bjj_multi_set_transport", "bjj_multi_set_chunks", "bjj_multi_last_overlap",
 )
 
 
 class BjjInfo(ctypes.Structure):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32),
         ("device", ctypes.c_int),
         ("compute_units", ctypes.c_int),
         ("window_bits", ctypes.c_int),
@@ -160,4 +161,6 @@ def load():
     lib.bjj_eddsa_verify_multi_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp]
     lib.bjj_multi_last_timing.argtypes = [vp, pd, pd, pd, ctypes.POINTER(ci)]
     lib.bjj_multi_set_transport.argtypes = [vp, ci]
+    lib.bjj_multi_set_chunks.argtypes = [vp, ci, sz]
+    lib.bjj_multi_last_overlap.argtypes = [vp, pd, pd, ctypes.POINTER(ci)]
     return lib

@@ -106,6 +106,7 @@ class Context:
 
     def info(self):
         i = _lib.BjjInfo()
+        i.struct_size = ctypes.sizeof(_lib.BjjInfo)
         self._ck(self.lib.bjj_get_info(self.handle, ctypes.byref(i)), "bjj_get_info")
         return i
 
@@ -370,6 +371,10 @@ class MultiContext:
         t = {"rccl": _lib.BJJ_TRANSPORT_RCCL, "peer": _lib.BJJ_TRANSPORT_PEER_COPY}[transport]
         self._ck(self.lib.bjj_multi_set_transport(self.handle, t), "bjj_multi_set_transport")
 
+    def set_chunks(self, chunks, min_chunk_items=1 << 15):
+        """pipeline depth of the *_dev form: pieces per peer block (1 = serial scatter -> kernels -> gather)"""
+        self._ck(self.lib.bjj_multi_set_chunks(self.handle, int(chunks), int(min_chunk_items)), "bjj_multi_set_chunks")
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.bjj_multi_free(self.handle)
@@ -404,7 +409,11 @@ class MultiContext:
         s, c, g, v = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
         self._ck(self.lib.bjj_multi_last_timing(self.handle, ctypes.byref(s), ctypes.byref(c), ctypes.byref(g), ctypes.byref(v)),
                  "bjj_multi_last_timing")
-        return {"scatter_ms": s.value, "compute_ms": c.value, "gather_ms": g.value, "rccl_version": v.value}
+        tot, wall, ch = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        self._ck(self.lib.bjj_multi_last_overlap(self.handle, ctypes.byref(tot), ctypes.byref(wall), ctypes.byref(ch)),
+                 "bjj_multi_last_overlap")
+        return {"scatter_ms": s.value, "compute_ms": c.value, "gather_ms": g.value, "rccl_version": v.value,
+                "total_ms": tot.value, "wall_ms": wall.value, "chunks": ch.value}
 
     def mul_fixed_base(self, scalars):
         s = _as_u8(scalars, 32, "scalars")

@@ -292,6 +292,10 @@ class MultiContext {
   MultiContext& operator=(const MultiContext&) = delete;
   bjj_multi* handle() const { return h_; }
   int size() const { return bjj_multi_size(h_); }
+  // pipeline depth of the device-resident form (bjj_multi_set_chunks): pieces per peer block, 1 = serial schedule
+  void set_chunks(int chunks, size_t min_chunk_items = (size_t)1 << 15) {
+    check(bjj_multi_set_chunks(h_, chunks, min_chunk_items), "bjj_multi_set_chunks");
+  }
   std::vector<uint8_t> verify_batch(const std::vector<Point>& pk, const std::vector<Signature>& sig, const std::vector<U256>& msg) {
     size_t n = pk.size();
     if (sig.size() != n || msg.size() != n) throw std::runtime_error("verify_batch: length mismatch");

@@ -43,19 +43,28 @@ BJJ_HD void store_niels(u32* p, const Niels& n) {
   q[7] = U4{0, 0, 0, 0};
 }
 // ---- per-lane variable-base table -------------------------------------------------------------------
-// {0..8} * P in projective-Niels form, an entry = the raw 4 x 9 limb words (144 B, nine 16-byte quarters).
-// -DBJJ_PNIELS_PACKED=1 is the measured-and-rejected alternative: four 256-bit integers per entry (128 B = one cache
-// line; Y-X weakly reduced first so that every component is below 2^256) and no stored identity (digit 0 selects the
-// constant (1, 1, 0, 2)): 1 KB instead of 1 296 B per lane and table, 40-47 % less HBM-side traffic -- for a result within
-// +-3 % whose sign depends on the chip (slower under the bench protocol on one box, faster in sustained loops on a more
-// power-limited one): the unpacking costs ~100 plain instructions per entry in kernels that are bound by VALU issue, not by
-// bytes (profiles/r02_ab_pniels_packed.txt).
-#if !defined(BJJ_PNIELS_PACKED)
-constexpr int PNIELS_WORDS = 36;
-constexpr int VB_TABLE_ENTRIES = 9;  // 0*P .. 8*P
-#else
+// {0..8} * P in projective-Niels form, one table per lane in global scratch.  BJJ_PNIELS_LAYOUT selects the entry format
+// per translation unit (the host side allocates VB_TABLE_WORDS_MAX words per table, which serves either):
+//   0  raw:    the 4 x 9 limb words as they are (144 B, nine 16-byte quarters), 9 entries incl. a stored identity
+//              (1 296 B per table); no packing arithmetic, entries straddle cache lines
+//   1  packed: four 256-bit integers per entry (128 B = one cache line; Y-X weakly reduced first so that every component
+//              is below 2^256), digit 0 selects the constant identity (1, 1, 0, 2): 8 entries, 1 KB per table
+//   2  packed entries at the raw stride (36 words, 9 slots) -- what rounds 1-2 shipped by accident of two disagreeing
+//              guards; kept so that the round-3 A/B has the old build as its control
+// Interleaved A/B of the three on one MI355X (profiles/r03_ab_pniels_layout_verify_block.txt): the verify kernel is 3.7-5 %
+// faster with raw entries than with either packed form (two tables per lane, 68 entry loads per item: the ~100 plain
+// instructions of an unpack cost more than the bytes), the variable-base kernel 0.5-0.9 % faster with packed than with raw
+// entries and 1.5-2.2 % faster than with the old hybrid.  So: k_verify.hip = raw, k_var.hip = packed, default = raw.
+#ifndef BJJ_PNIELS_LAYOUT
+#define BJJ_PNIELS_LAYOUT 0
+#endif
+constexpr int VB_TABLE_WORDS_MAX = 36 * 9;   // the largest layout: what the host allocates per table
+#if BJJ_PNIELS_LAYOUT == 1
 constexpr int PNIELS_WORDS = 32;
 constexpr int VB_TABLE_ENTRIES = 8;  // 1*P .. 8*P
+#else
+constexpr int PNIELS_WORDS = 36;
+constexpr int VB_TABLE_ENTRIES = 9;  // 0*P .. 8*P
 #endif
 constexpr int VB_TABLE_WORDS = PNIELS_WORDS * VB_TABLE_ENTRIES;
 constexpr int VB_VERIFY_WORDS = 2 * VB_TABLE_WORDS;  // verify keeps two per-lane tables (-8A and -+R)
@@ -63,7 +72,7 @@ BJJ_HD PNiels pniels_identity() {
   PNiels id; id.ymx = fr_one(); id.ypx = fr_one(); id.t2d = fr_zero(); id.z2 = fr_dbl(fr_one());
   return id;
 }
-#if defined(BJJ_PNIELS_RAW)
+#if BJJ_PNIELS_LAYOUT == 0
 BJJ_HD PNiels load_pniels_raw(const u32* p) {
   const U4* q = (const U4*)p;
   U4 t[9];

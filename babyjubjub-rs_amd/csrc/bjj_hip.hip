@@ -35,7 +35,7 @@
 
 using namespace bjj;
 
-#define BJJ_VERSION_STRING "bjj-hip 0.2.0 gfx950"
+#define BJJ_VERSION_STRING "bjj-hip 0.3.0 gfx950"
 // Fixed-base window width.  window_bits = 0 (default) is a modest 23 bits = 11 signed digits, 5.9 GB: a library that
 // is linked into a process with other tenants of the GPU must not take half of the HBM unasked.  The wide tables are
 // opt-in: an explicit width (28 bits = 9 digits, 9 x (2^27 + 1) entries = 154.6 GB of the 288 GB; 26 = 10 digits,
@@ -58,6 +58,48 @@ static int set_err(int code, const std::string& msg) { g_err = msg; return code;
       return set_err(BJJ_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                  \
   } while (0)
 
+// Every entry point runs on its context's device and leaves the calling thread's current HIP device as it found it (a host
+// that shares the thread with torch or another HIP user must not find its default device changed).
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev == dev) prev = -1; else err = hipSetDevice(dev);
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ENTER_DEVICE(dev)                                                                                       \
+  DeviceGuard dg_(dev);                                                                                         \
+  if (dg_.err != hipSuccess) return set_err(BJJ_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(dg_.err))
+
+#define BJJ_SCRATCH_SETS 2
+#define BJJ_STREAM_MARKS 8
+struct ScratchSet {
+  u32* scratch = nullptr;      // n * 64 B (Z, prefix)
+  size_t scratch_items = 0;
+  u32* vb_tables = nullptr;    // grid threads * VB_TABLE_WORDS * 4 B
+  size_t vb_threads = 0;
+  u32* slow = nullptr;         // [0] = count, [1..] item indices deferred to the exact-path kernels
+  size_t slow_items = 0;
+  uint8_t* codec = nullptr;    // verify_compressed: n * (64 pk + 64 R + 32 s + 2 flags) bytes; public_keys: the scalar keys
+  size_t codec_items = 0;
+  // Ordering of the set: every call that uses it records `ev_last` on its stream after enqueueing, and a call on a
+  // DIFFERENT stream first makes its stream wait for it.  Calls return before the work runs, so "serialised by the
+  // caller" alone would not order execution.
+  hipEvent_t ev_last = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool have_last = false;
+  uint64_t last_use = 0;
+};
+struct StreamMark {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;
+  bool used = false;
+  uint64_t last_use = 0;
+};
 struct bjj_ctx {
   int device = 0;
   int cus = 0;
@@ -73,20 +115,15 @@ struct bjj_ctx {
   u32* table = nullptr;      // [window][digit 0 .. 2^(W-1)] x 128 B
   u32* bases = nullptr;      // P_j = 2^(W j) * B8, one Niels entry per window
   size_t table_bytes = 0;
-  u32* scratch = nullptr;      // n * 64 B (Z, prefix)
-  size_t scratch_items = 0;
-  u32* vb_tables = nullptr;    // grid threads * VB_TABLE_WORDS * 4 B
-  size_t vb_threads = 0;
-  u32* slow = nullptr;         // [0] = count, [1..] item indices deferred to the exact-path kernels
-  size_t slow_items = 0;
-  uint8_t* codec = nullptr;    // verify_compressed: n * (64 pk + 64 R + 32 s + 2 flags) bytes
-  size_t codec_items = 0;
-  // Cross-stream ordering of the context's shared scratch (scratch / slow / vb_tables / codec): every *_dev call records
-  // `ev_last` on its stream after enqueueing, and a call on a DIFFERENT stream first makes its stream wait for it.  Calls
-  // return before the work runs, so "serialised by the caller" alone would not order execution.
-  hipEvent_t ev_last = nullptr;
-  hipStream_t last_stream = nullptr;
-  bool have_last = false;
+  // Scratch is kept in BJJ_SCRATCH_SETS independent sets so that calls on two streams can be in flight at once
+  // (pick_set): a launch whose last wave-round is only partly filled -- 2^20 verifications are 8.1 rounds of the 2 048
+  // resident waves, 2^20 variable-base multiplications 5.3 rounds of the 196 608 resident lanes -- then shares the chip
+  // with the head of the next launch instead of idling it.  A single-stream caller only ever touches (and allocates) set 0.
+  ScratchSet set[BJJ_SCRATCH_SETS];
+  uint64_t use_counter = 0;
+  // calls that use no scratch (Poseidon, point add, codec, sign) are not ordered behind anything; their completion
+  // events are only kept so that bjj_sync can wait for them: one slot per distinct caller stream
+  StreamMark marks[BJJ_STREAM_MARKS];
   // host-pointer API: chunked pipeline  user memory -> pinned[b] -H2D-> dstage[b] -kernel-> dstage[b] -D2H-> pinned[b] -> user
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
@@ -102,37 +139,64 @@ static int grid_for(const bjj_ctx* c, size_t n, int blocks_per_cu, int block = B
   return (int)(want < cap ? want : cap);
 }
 
-// Makes `st` safe to touch the context's scratch: waits (on the device) for the last call if that ran on another stream.
-static int stream_enter(bjj_ctx* c, hipStream_t st) {
-  HIPCK(hipSetDevice(c->device));
-  if (c->have_last && c->last_stream != st) HIPCK(hipStreamWaitEvent(st, c->ev_last, 0));
+// Which scratch set a call on stream `st` uses:
+//  (1) the set this stream used last -- calls of one stream are ordered by the stream itself, nothing to wait for;
+//  (2) else a set that was never used;  (3) else the least recently used one (the caller then waits for its last call).
+// Two streams that alternate therefore settle on one set each and overlap; one stream never leaves set 0.
+static ScratchSet* pick_set(bjj_ctx* c, hipStream_t st) {
+  for (ScratchSet& S : c->set) if (S.have_last && S.last_stream == st) return &S;
+  for (ScratchSet& S : c->set) if (!S.have_last) return &S;
+  ScratchSet* lru = &c->set[0];
+  for (ScratchSet& S : c->set) if (S.last_use < lru->last_use) lru = &S;
+  return lru;
+}
+// Makes `st` safe to touch set S: waits (on the device) for the set's last call if that ran on another stream.
+static int set_enter(bjj_ctx* c, ScratchSet* S, hipStream_t st) {
+  if (!S->ev_last) HIPCK(hipEventCreateWithFlags(&S->ev_last, hipEventDisableTiming));
+  if (S->have_last && S->last_stream != st) HIPCK(hipStreamWaitEvent(st, S->ev_last, 0));
   return BJJ_OK;
 }
-static int stream_leave(bjj_ctx* c, hipStream_t st) {
-  HIPCK(hipEventRecord(c->ev_last, st));
-  c->last_stream = st;
-  c->have_last = true;
+static int set_leave(bjj_ctx* c, ScratchSet* S, hipStream_t st) {
+  HIPCK(hipEventRecord(S->ev_last, st));
+  S->last_stream = st;
+  S->have_last = true;
+  S->last_use = ++c->use_counter;
+  return BJJ_OK;
+}
+// completion mark of a call that used no scratch (bjj_sync waits for these)
+static int mark_stream(bjj_ctx* c, hipStream_t st) {
+  if (st == c->stream) return BJJ_OK;   // bjj_sync synchronises the context's own stream anyway
+  StreamMark* m = nullptr;
+  for (StreamMark& k : c->marks) if (k.used && k.stream == st) { m = &k; break; }
+  if (!m) for (StreamMark& k : c->marks) if (!k.used) { m = &k; break; }
+  if (!m) {   // more caller streams than slots: retire the oldest mark (wait for it, then reuse the slot)
+    m = &c->marks[0];
+    for (StreamMark& k : c->marks) if (k.last_use < m->last_use) m = &k;
+    HIPCK(hipEventSynchronize(m->ev));
+  }
+  if (!m->ev) HIPCK(hipEventCreateWithFlags(&m->ev, hipEventDisableTiming));
+  HIPCK(hipEventRecord(m->ev, st));
+  m->stream = st; m->used = true; m->last_use = ++c->use_counter;
   return BJJ_OK;
 }
 
-static int ensure_scratch(bjj_ctx* c, size_t n) {
-  HIPCK(hipSetDevice(c->device));
-  if (n > c->scratch_items) {
-    if (c->scratch) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->scratch)); c->scratch = nullptr; }
-    HIPCK(hipMalloc((void**)&c->scratch, n * 64));
-    c->scratch_items = n;
+static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
+  if (n > S->scratch_items) {
+    if (S->scratch) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->scratch)); S->scratch = nullptr; S->scratch_items = 0; }
+    HIPCK(hipMalloc((void**)&S->scratch, n * 64));
+    S->scratch_items = n;
   }
-  if (n > c->slow_items) {
-    if (c->slow) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->slow)); c->slow = nullptr; }
-    HIPCK(hipMalloc((void**)&c->slow, (n + 16) * sizeof(u32)));
-    c->slow_items = n;
+  if (n > S->slow_items) {
+    if (S->slow) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->slow)); S->slow = nullptr; S->slow_items = 0; }
+    HIPCK(hipMalloc((void**)&S->slow, (n + 16) * sizeof(u32)));
+    S->slow_items = n;
   }
-  size_t tv = (size_t)c->lanes_var, te = (size_t)c->occ_verify * BJJ_BLOCK * 2;  // lanes per CU; verify: 2 tables per lane
+  size_t tv = (size_t)c->lanes_var, te = (size_t)c->occ_verify * BJJ_VERIFY_BLOCK * 2;  // lanes per CU; verify: 2 tables per lane
   size_t threads = (size_t)c->cus * (tv > te ? tv : te);
-  if (threads > c->vb_threads) {
-    if (c->vb_tables) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->vb_tables)); c->vb_tables = nullptr; }
-    HIPCK(hipMalloc((void**)&c->vb_tables, threads * VB_TABLE_WORDS * sizeof(u32)));
-    c->vb_threads = threads;
+  if (threads > S->vb_threads) {
+    if (S->vb_tables) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->vb_tables)); S->vb_tables = nullptr; S->vb_threads = 0; }
+    HIPCK(hipMalloc((void**)&S->vb_tables, threads * VB_TABLE_WORDS_MAX * sizeof(u32)));
+    S->vb_threads = threads;
   }
   return BJJ_OK;
 }
@@ -176,7 +240,7 @@ static void secure_bzero(void* p, size_t n) {
   __asm__ __volatile__("" : : "r"(p) : "memory");   // the stores must not be elided as dead
 }
 static int ensure_pipe(bjj_ctx* c, size_t bytes) {
-  HIPCK(hipSetDevice(c->device));
+  ENTER_DEVICE(c->device);
   if (!c->s_in) {
     HIPCK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
     HIPCK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
@@ -201,6 +265,7 @@ static int ensure_pipe(bjj_ctx* c, size_t bytes) {
 // launch(d_in[], d_out[], count, stream) enqueues the kernels of one chunk on `stream`
 template <typename Launch>
 static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch) {
+  ENTER_DEVICE(c->device);
   const size_t chunk = n < BJJ_PIPE_CHUNK ? n : BJJ_PIPE_CHUNK;
   size_t off_in[4], off_out[4], tot = 0, in_bytes = 0;
   for (int i = 0; i < sp.n_in; i++) { off_in[i] = tot; tot += up16(chunk * sp.in_stride[i]); }
@@ -247,27 +312,30 @@ static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch
   }
   return rc;
 }
-static int ensure_codec(bjj_ctx* c, size_t n) {  // 162 bytes per item of intermediate records
-  HIPCK(hipSetDevice(c->device));
-  if (n > c->codec_items) {
-    if (c->codec) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->codec)); c->codec = nullptr; }
-    HIPCK(hipMalloc((void**)&c->codec, n * 162 + 64));
-    c->codec_items = n;
+static int ensure_codec(bjj_ctx* c, ScratchSet* S, size_t n) {  // 162 bytes per item of intermediate records
+  if (n > S->codec_items) {
+    if (S->codec) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->codec)); S->codec = nullptr; S->codec_items = 0; }
+    HIPCK(hipMalloc((void**)&S->codec, n * 162 + 64));
+    S->codec_items = n;
   }
   return BJJ_OK;
 }
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static void ctx_destroy(bjj_ctx* c) {
-  hipSetDevice(c->device);
+  DeviceGuard dg_(c->device);
   hipDeviceSynchronize();
   // key-derived material may sit in the codec scratch (scalar keys) and in the staging buffers: zero before release
-  if (c->codec) { hipMemset(c->codec, 0, c->codec_items * 162 + 64); hipFree(c->codec); }
+  for (ScratchSet& S : c->set) {
+    if (S.codec) { hipMemset(S.codec, 0, S.codec_items * 162 + 64); hipFree(S.codec); }
+    if (S.scratch) hipFree(S.scratch);
+    if (S.vb_tables) hipFree(S.vb_tables);
+    if (S.slow) hipFree(S.slow);
+    if (S.ev_last) hipEventDestroy(S.ev_last);
+  }
+  for (StreamMark& k : c->marks) if (k.ev) hipEventDestroy(k.ev);
   if (c->table) hipFree(c->table);
   if (c->bases) hipFree(c->bases);
-  if (c->scratch) hipFree(c->scratch);
-  if (c->vb_tables) hipFree(c->vb_tables);
-  if (c->slow) hipFree(c->slow);
   for (int b = 0; b < 2; b++) {
     if (c->pinned[b]) { secure_bzero(c->pinned[b], c->pipe_bytes); hipHostFree(c->pinned[b]); }
     if (c->dstage[b]) { hipMemset(c->dstage[b], 0, c->pipe_bytes); hipFree(c->dstage[b]); }
@@ -275,7 +343,6 @@ static void ctx_destroy(bjj_ctx* c) {
     if (c->ev_k[b]) hipEventDestroy(c->ev_k[b]);
     if (c->ev_out[b]) hipEventDestroy(c->ev_out[b]);
   }
-  if (c->ev_last) hipEventDestroy(c->ev_last);
   if (c->s_in) hipStreamDestroy(c->s_in);
   if (c->s_out) hipStreamDestroy(c->s_out);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -298,7 +365,7 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   if (e != hipSuccess || ndev <= 0)
     return set_err(BJJ_E_NO_DEVICE, "bjj_init: no HIP device available (this library has no CPU fallback)");
   if (device < 0 || device >= ndev) return set_err(BJJ_E_INVALID, "bjj_init: device index out of range");
-  HIPCK(hipSetDevice(device));
+  ENTER_DEVICE(device);
   const auto t0 = std::chrono::steady_clock::now();
   hipDeviceProp_t prop;
   HIPCK(hipGetDeviceProperties(&prop, device));
@@ -329,7 +396,6 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->occ_sign = bjjk::occ_sign();
   c->occ_sign_schnorr = bjjk::occ_sign_schnorr();
   hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
   if (se != hipSuccess) { ctx_destroy(c); return set_err(BJJ_E_HIP, std::string("bjj_init: stream/event: ") + hipGetErrorString(se)); }
   for (;;) {
     c->table_bytes = fixed_stride(c->W) * (size_t)c->nwin * NIELS_WORDS * sizeof(u32);
@@ -368,8 +434,11 @@ void bjj_free(bjj_ctx* c) {
 
 int bjj_sync(bjj_ctx* c) {
   if (!c) return set_err(BJJ_E_INVALID, "bjj_sync: ctx is NULL");
-  HIPCK(hipSetDevice(c->device));
-  if (c->have_last && c->last_stream != c->stream) HIPCK(hipEventSynchronize(c->ev_last));   // work enqueued on a caller's stream
+  ENTER_DEVICE(c->device);
+  for (ScratchSet& S : c->set)      // work enqueued on a caller's stream
+    if (S.have_last && S.last_stream != c->stream) HIPCK(hipEventSynchronize(S.ev_last));
+  for (StreamMark& k : c->marks)
+    if (k.used) HIPCK(hipEventSynchronize(k.ev));
   HIPCK(hipStreamSynchronize(c->stream));
   return BJJ_OK;
 }
@@ -377,30 +446,45 @@ void* bjj_stream(bjj_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int bjj_reserve(bjj_ctx* c, size_t n) {
   if (!c) return set_err(BJJ_E_INVALID, "bjj_reserve: ctx is NULL");
-  int rc = ensure_scratch(c, n ? n : 1); if (rc) return rc;
-  return ensure_codec(c, n ? n : 1);
+  ENTER_DEVICE(c->device);
+  for (ScratchSet& S : c->set) {   // set 0, and every further set a second stream has already brought into use
+    if (&S != &c->set[0] && !S.have_last) continue;
+    int rc = ensure_scratch(c, &S, n ? n : 1); if (rc) return rc;
+    rc = ensure_codec(c, &S, n ? n : 1); if (rc) return rc;
+  }
+  return BJJ_OK;
 }
 
-int bjj_get_info(bjj_ctx* c, bjj_info* info) {
-  if (!c || !info) return set_err(BJJ_E_INVALID, "bjj_get_info: NULL argument");
+int bjj_get_info(bjj_ctx* c, bjj_info* out) {
+  if (!c || !out) return set_err(BJJ_E_INVALID, "bjj_get_info: NULL argument");
+  const size_t cap = out->struct_size;
+  if (cap < 8) return set_err(BJJ_E_INVALID, "bjj_get_info: set info.struct_size = sizeof(bjj_info) before the call");
+  bjj_info full;
+  memset(&full, 0, sizeof(full));
+  bjj_info* info = &full;
   info->device = c->device;
   info->compute_units = c->cus;
   info->window_bits = c->W;
   info->n_windows = c->nwin;
   info->table_bytes = c->table_bytes;
-  info->scratch_bytes = c->scratch_items * 64 + c->vb_threads * VB_TABLE_WORDS * sizeof(u32) + c->slow_items * 4 +
-                        (c->codec_items ? c->codec_items * 162 + 64 : 0) + 2 * c->pipe_bytes;
+  info->scratch_bytes = 2 * c->pipe_bytes;
+  for (const ScratchSet& S : c->set)
+    info->scratch_bytes += S.scratch_items * 64 + S.vb_threads * VB_TABLE_WORDS_MAX * sizeof(u32) + S.slow_items * 4 +
+                           (S.codec_items ? S.codec_items * 162 + 64 : 0);
   info->kernel_fixed_base = "bjj_k_mul_fixed_base";
   info->kernel_var_base = "bjj_k_mul_var_base";
   info->kernel_poseidon5 = "bjj_k_poseidon5";
   info->kernel_verify = "bjj_k_eddsa_verify";
   info->init_ms = c->init_ms;
+  const size_t fill = cap < sizeof(full) ? cap : sizeof(full);   // never past the caller's struct
+  full.struct_size = (uint32_t)fill;
+  memcpy(out, &full, fill);
   return BJJ_OK;
 }
 
 int bjj_check_table(bjj_ctx* c, uint64_t* n_bad) {
   if (!c || !n_bad) return set_err(BJJ_E_INVALID, "bjj_check_table: NULL argument");
-  HIPCK(hipSetDevice(c->device));
+  ENTER_DEVICE(c->device);
   unsigned long long* d_bad = nullptr;
   HIPCK(hipMalloc((void**)&d_bad, sizeof(unsigned long long)));
   hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), c->stream);
@@ -419,12 +503,22 @@ int bjj_check_table(bjj_ctx* c, uint64_t* n_bad) {
 #define CHECK_N(n) if ((n) >> 32) return set_err(BJJ_E_INVALID, "batches are limited to 2^32 - 1 items per call")
 #define CHECK_CTX(c, name) if (!(c)) return set_err(BJJ_E_INVALID, name ": ctx is NULL")
 #define CHECK_PTR(p, name) if (!(p) || !aligned16(p)) return set_err(BJJ_E_INVALID, name ": NULL or not 16-byte aligned device pointer")
-// Every *_dev entry: select the context's device (a second context on another GPU of the same process must not launch
-// on a foreign device), order this stream behind the previous call's stream, launch, record.
+// Every *_dev entry selects the context's device (a second context on another GPU of the same process must not launch
+// on a foreign device).  Entries that use scratch (SET_ENTER / SET_LEAVE) pick a scratch set for their stream, size it,
+// order themselves behind the set's previous user and record; the others (DEV_ENTER / DEV_LEAVE) only leave a completion
+// mark for bjj_sync.
 #define DEV_ENTER(c, stream)                                              \
   hipStream_t st = (stream) ? (hipStream_t)(stream) : (c)->stream;        \
-  { int rc_ = stream_enter((c), st); if (rc_) return rc_; }
-#define DEV_LEAVE(c) return stream_leave((c), st)
+  ENTER_DEVICE((c)->device)
+#define DEV_LEAVE(c) return mark_stream((c), st)
+#define SET_ENTER(c, stream, n, with_codec)                               \
+  hipStream_t st = (stream) ? (hipStream_t)(stream) : (c)->stream;        \
+  ENTER_DEVICE((c)->device);                                              \
+  ScratchSet* S = pick_set((c), st);                                      \
+  { int rc_ = ensure_scratch((c), S, (n)); if (rc_) return rc_;           \
+    if (with_codec) { rc_ = ensure_codec((c), S, (n)); if (rc_) return rc_; } \
+    rc_ = set_enter((c), S, st); if (rc_) return rc_; }
+#define SET_LEAVE(c) return set_leave((c), S, st)
 #define LAUNCHCK(expr, name)                                                                        \
   do {                                                                                              \
     hipError_t e_ = (expr);                                                                         \
@@ -436,11 +530,10 @@ int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_
   if (n == 0) return BJJ_OK;
   CHECK_N(n);
   CHECK_PTR(d_scalars, "bjj_mul_fixed_base_dev"); CHECK_PTR(d_out, "bjj_mul_fixed_base_dev");
-  int rc = ensure_scratch(c, n); if (rc) return rc;
-  DEV_ENTER(c, stream);
+  SET_ENTER(c, stream, n, false);
   LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->lanes_fixed, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
-                                (uint8_t*)d_out, c->scratch), "bjj_mul_fixed_base_dev");
-  DEV_LEAVE(c);
+                                (uint8_t*)d_out, S->scratch), "bjj_mul_fixed_base_dev");
+  SET_LEAVE(c);
 }
 static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t scalar_bytes, size_t n, void* d_out,
                            void* stream, const char* who) {
@@ -451,11 +544,10 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
   CHECK_N(n);
   if (!d_pts || !d_scalars || !d_out || !aligned16(d_pts) || !aligned16(d_scalars) || !aligned16(d_out))
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
-  int rc = ensure_scratch(c, n); if (rc) return rc;
-  DEV_ENTER(c, stream);
+  SET_ENTER(c, stream, n, false);
   LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
-                              (int)(scalar_bytes / 4), n, (uint8_t*)d_out, c->scratch, c->vb_tables, c->slow), "bjj_mul_var_base_dev");
-  DEV_LEAVE(c);
+                              (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow), "bjj_mul_var_base_dev");
+  SET_LEAVE(c);
 }
 int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* stream) {
   return var_base_launch(c, d_pts, d_scalars, 32, n, d_out, stream, "bjj_mul_var_base_dev");
@@ -481,12 +573,11 @@ static int verify_launch(bjj_ctx* c, bool schnorr, const void* d_pk, const void*
   if (!d_pk || !d_r || !d_s || !d_msg || !aligned16(d_pk) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_msg))
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   if (!d_ok) return set_err(BJJ_E_INVALID, std::string(who) + ": d_ok is NULL");
-  int rc = ensure_scratch(c, n); if (rc) return rc;
-  DEV_ENTER(c, stream);
-  LAUNCHCK(bjjk::verify(st, grid_for(c, n, c->occ_scan), grid_for(c, n, c->occ_verify), schnorr, c->table, c->W, c->nwin,
+  SET_ENTER(c, stream, n, false);
+  LAUNCHCK(bjjk::verify(st, grid_for(c, n, c->occ_scan), grid_for(c, n, c->occ_verify, BJJ_VERIFY_BLOCK), schnorr, c->table, c->W, c->nwin,
                         (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n, (uint8_t*)d_ok,
-                        c->vb_tables, c->slow), "verify");
-  DEV_LEAVE(c);
+                        S->vb_tables, S->slow), "verify");
+  SET_LEAVE(c);
 }
 int bjj_eddsa_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
                          void* d_ok, void* stream) {
@@ -552,21 +643,19 @@ int bjj_eddsa_verify_compressed_dev(bjj_ctx* c, const void* d_pk32, const void* 
   CHECK_PTR(d_pk32, "bjj_eddsa_verify_compressed_dev"); CHECK_PTR(d_sig64, "bjj_eddsa_verify_compressed_dev");
   CHECK_PTR(d_msg, "bjj_eddsa_verify_compressed_dev");
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_eddsa_verify_compressed_dev: d_ok is NULL");
-  int rc0 = ensure_codec(c, n); if (rc0) return rc0;
-  rc0 = ensure_scratch(c, n); if (rc0) return rc0;
-  uint8_t* pk_xy = c->codec;
+  SET_ENTER(c, stream, n, true);
+  uint8_t* pk_xy = S->codec;
   uint8_t* r_xy = pk_xy + n * 64;
   uint8_t* s32 = r_xy + n * 64;
   uint8_t* f_pk = s32 + n * 32;
   uint8_t* f_r = f_pk + n;
-  DEV_ENTER(c, stream);
   const int g = grid_for(c, n, c->occ_decomp);
   LAUNCHCK(bjjk::decompress_points(st, g, (const uint8_t*)d_pk32, 32, n, pk_xy, f_pk, nullptr), "decompress(pk)");
   LAUNCHCK(bjjk::decompress_points(st, g, (const uint8_t*)d_sig64, 64, n, r_xy, f_r, s32), "decompress(sig)");
-  LAUNCHCK(bjjk::verify(st, grid_for(c, n, c->occ_scan), grid_for(c, n, c->occ_verify), false, c->table, c->W, c->nwin, pk_xy, r_xy, s32,
-                        (const uint8_t*)d_msg, n, (uint8_t*)d_ok, c->vb_tables, c->slow), "verify");
+  LAUNCHCK(bjjk::verify(st, grid_for(c, n, c->occ_scan), grid_for(c, n, c->occ_verify, BJJ_VERIFY_BLOCK), false, c->table, c->W, c->nwin, pk_xy, r_xy, s32,
+                        (const uint8_t*)d_msg, n, (uint8_t*)d_ok, S->vb_tables, S->slow), "verify");
   LAUNCHCK(bjjk::merge_codec_flags(st, grid_for(c, n, 8), (uint8_t*)d_ok, f_pk, f_r, n), "merge_codec_flags");
-  DEV_LEAVE(c);
+  SET_LEAVE(c);
 }
 
 int bjj_scalar_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out, void* stream) {
@@ -583,16 +672,14 @@ int bjj_public_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy
   if (n == 0) return BJJ_OK;
   CHECK_N(n);
   CHECK_PTR(d_keys, "bjj_public_keys_dev"); CHECK_PTR(d_out_xy, "bjj_public_keys_dev");
-  int rc = ensure_codec(c, n); if (rc) return rc;
-  rc = ensure_scratch(c, n); if (rc) return rc;
-  DEV_ENTER(c, stream);
+  SET_ENTER(c, stream, n, true);
   // B8.mul_scalar(&self.scalar_key()), src/lib.rs:304-306; the scalar keys live in the codec scratch only for the
   // duration of the multiplication and are wiped on the same stream right behind it
-  LAUNCHCK(bjjk::scalar_keys(st, grid_for(c, n, 4), (const uint8_t*)d_keys, n, c->codec), "scalar_keys");
-  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->lanes_fixed, c->table, c->W, c->nwin, c->codec, n, (uint8_t*)d_out_xy,
-                                c->scratch), "mul_fixed_base");
-  HIPCK(hipMemsetAsync(c->codec, 0, n * 32, st));
-  DEV_LEAVE(c);
+  LAUNCHCK(bjjk::scalar_keys(st, grid_for(c, n, 4), (const uint8_t*)d_keys, n, S->codec), "scalar_keys");
+  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->lanes_fixed, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy,
+                                S->scratch), "mul_fixed_base");
+  HIPCK(hipMemsetAsync(S->codec, 0, n * 32, st));
+  SET_LEAVE(c);
 }
 int bjj_sign_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, void* d_out_r, void* d_out_s, void* d_ok,
                  void* stream) {

@@ -10,6 +10,13 @@
 // inversion (executed by one wave) is amortised over the whole workgroup.
 #define BJJ_EPI_BLOCK 512
 
+// Workgroup size of the verify kernels.  Their waves never cooperate beyond the wave (per-wave staging rows, atomic work
+// cursors), so a workgroup is ONE wave: a wave that runs out of work retires its slot at once instead of waiting for the
+// slowest of four, which is what lets the head of the next launch (second scratch set, second stream) fill a tail round.
+#ifndef BJJ_VERIFY_BLOCK
+#define BJJ_VERIFY_BLOCK 64
+#endif
+
 namespace bjjk {
 
 template <typename K>

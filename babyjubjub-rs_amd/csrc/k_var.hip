@@ -1,5 +1,10 @@
 // libbjj_hip.so, kernel unit 2: K2 / K6 Point::mul_scalar for arbitrary points (src/lib.rs:149-164) and the raw
 // PointProjective::add / affine (src/lib.rs:88-131, 70-85).
+// per-lane table entries of this unit: packed, 128 B (bjj_device.hpp "per-lane variable-base table")
+#ifndef BJJ_K2_PNIELS_LAYOUT
+#define BJJ_K2_PNIELS_LAYOUT 1
+#endif
+#define BJJ_PNIELS_LAYOUT BJJ_K2_PNIELS_LAYOUT
 #include "k_common.hpp"
 
 // Workgroup size / resident workgroups per CU of K2.  Three 256-lane workgroups per CU = 3 waves per SIMD at 168 VGPRs

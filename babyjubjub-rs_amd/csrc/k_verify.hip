@@ -1,7 +1,14 @@
 // libbjj_hip.so, kernel unit 4: K4, verify(pk, sig, msg) (src/lib.rs:395-412) and verify_schnorr (:375-385).
+// per-lane table entries of this unit: raw, 144 B (bjj_device.hpp "per-lane variable-base table")
+#ifndef BJJ_VERIFY_PNIELS_LAYOUT
+#define BJJ_VERIFY_PNIELS_LAYOUT 0
+#endif
+#define BJJ_PNIELS_LAYOUT BJJ_VERIFY_PNIELS_LAYOUT
 #include "k_common.hpp"
 
-// resident workgroups per CU the verify kernels are compiled for (A/B knob): 2 = 256 VGPRs, 3 = 168 VGPRs and more scratch
+// Waves per SIMD the verify kernels are compiled for (the second __launch_bounds__ argument of HIP is the minimum number of
+// waves per execution unit; A/B knob): 2 = 256 VGPRs; 3 (168 VGPRs, more scratch) was measured slower
+// (profiles/r02_ab_occupancy.txt).
 #ifndef BJJ_VERIFY_MIN_BLOCKS
 #define BJJ_VERIFY_MIN_BLOCKS 2
 #endif
@@ -40,7 +47,7 @@ __device__ __forceinline__ void verify_kernel_body(const u32* __restrict__ table
                                                    const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg, size_t n,
                                                    uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
                                                    u32* __restrict__ wl) {
-  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_BLOCK / 64) * FB_STAGE_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_VERIFY_BLOCK / 64) * FB_STAGE_WORDS];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const GatherCoopLds<1> fb = {table, stage + (threadIdx.x >> 6) * FB_STAGE_WORDS, lane};
@@ -68,7 +75,7 @@ __device__ __forceinline__ void verify_kernel_body(const u32* __restrict__ table
   }
 }
 // verify_schnorr (src/lib.rs:375-385): same structure, verdict 2 = Err (msg > Q)
-__global__ void __launch_bounds__(BJJ_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k_schnorr_verify(const u32* __restrict__ table, int W, int nwin,
+__global__ void __launch_bounds__(BJJ_VERIFY_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k_schnorr_verify(const u32* __restrict__ table, int W, int nwin,
                                                                      const uint8_t* __restrict__ pk,
                                                                      const uint8_t* __restrict__ rb8,
                                                                      const uint8_t* __restrict__ s,
@@ -77,7 +84,7 @@ __global__ void __launch_bounds__(BJJ_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k_schnor
                                                                      u32* __restrict__ wl) {
   verify_kernel_body<true>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
 }
-__global__ void __launch_bounds__(BJJ_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
+__global__ void __launch_bounds__(BJJ_VERIFY_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k_eddsa_verify(const u32* __restrict__ table, int W, int nwin,
                                                                    const uint8_t* __restrict__ pk,
                                                                    const uint8_t* __restrict__ rb8,
                                                                    const uint8_t* __restrict__ s,
@@ -88,7 +95,10 @@ __global__ void __launch_bounds__(BJJ_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k_eddsa_
 }
 
 namespace bjjk {
-int occ_verify() { return occupancy_of(bjj_k_eddsa_verify, BJJ_BLOCK); }
+int occ_verify() {   // resident workgroups per CU; one grid size (and one per-lane table allocation) serves both kernels
+  const int a = occupancy_of(bjj_k_eddsa_verify, BJJ_VERIFY_BLOCK), b = occupancy_of(bjj_k_schnorr_verify, BJJ_VERIFY_BLOCK);
+  return a < b ? a : b;
+}
 int occ_verify_scan() { return occupancy_of(bjj_k_eddsa_verify_scan, BJJ_BLOCK); }
 hipError_t verify(hipStream_t st, int grid_scan, int grid, bool schnorr, const u32* table, int W, int nwin, const uint8_t* pk,
                   const uint8_t* rb8, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok, u32* vb_tables, u32* wl) {
@@ -98,9 +108,9 @@ hipError_t verify(hipStream_t st, int grid_scan, int grid, bool schnorr, const u
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (schnorr)
-    hipLaunchKernelGGL(bjj_k_schnorr_verify, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+    hipLaunchKernelGGL(bjj_k_schnorr_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
   else
-    hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+    hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
   return hipGetLastError();
 }
 }  // namespace bjjk

@@ -212,8 +212,11 @@ int bjj_reserve(bjj_ctx* ctx, size_t n);
  * limbs): *n_bad = number of violated conditions (0 for a sound table). */
 int bjj_check_table(bjj_ctx* ctx, uint64_t* n_bad);
 
-/* Introspection for benchmarks / profiling reports. */
+/* Introspection for benchmarks / profiling reports.  The caller sets struct_size = sizeof(bjj_info) of ITS build before
+ * the call; the library fills at most that many bytes, so the struct can grow at its end without overrunning a caller that
+ * was compiled against an older header (a struct_size below 8 -- e.g. an uninitialised struct -- is BJJ_E_INVALID). */
 typedef struct {
+  uint32_t struct_size;     /* IN: sizeof(bjj_info) as the caller knows it */
   int device;
   int compute_units;
   int window_bits;          /* fixed-base W */
@@ -236,24 +239,35 @@ int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
  *   host-pointer form    arrays in host memory; one host thread per device drives that device's
  *                        pinned-staging pipeline over its block.  No inter-GPU traffic.
  *   *_multi_dev form     arrays resident in the HBM of the handle's FIRST device (rank 0 holds all
- *                        inputs, as in BASELINE cfg 5): RCCL over xGMI scatters the input blocks in
- *                        one ncclGroup (ncclScatter, in place at the root; exact-count ncclSend /
- *                        ncclRecv pairs when G does not divide n), every device runs the kernels on
- *                        its block, a second group gathers the results (ncclGather) into the
- *                        caller's output array.  Synchronous; the input arrays must be complete
- *                        when the call is made (no pending writes on other streams).  RCCL is loaded
- *                        with dlopen on the first such call (single process, ncclCommInitAll;
- *                        "librccl.so.1", or the library named by the environment variable
- *                        BJJ_RCCL_LIBRARY); BJJ_E_RCCL if absent. */
+ *                        inputs, as in BASELINE cfg 5).  Transfers over xGMI and kernels are pipelined:
+ *                        the root's block is processed in place from t = 0 while its sends run on a
+ *                        separate transfer stream; every peer's block travels in up to `chunks` pieces
+ *                        (bjj_multi_set_chunks), piece c of all peers and all input arrays in ONE
+ *                        ncclGroup of exact-count ncclSend / ncclRecv pairs; a peer computes piece c
+ *                        as soon as it has arrived, while piece c+1 is in flight, and returns its
+ *                        results piece by piece.  chunks = 1 with G | n is the serial schedule: one
+ *                        grouped ncclScatter (in place at the root), the kernels, one grouped
+ *                        ncclGather.  Synchronous; the input arrays must be complete when the call is
+ *                        made (no pending writes on other streams).  RCCL is loaded with dlopen on the
+ *                        first such call (single process, ncclCommInitAll; "librccl.so.1", or the
+ *                        library named by the environment variable BJJ_RCCL_LIBRARY); BJJ_E_RCCL if
+ *                        absent.  If a transfer fails after the call has started to enqueue, the handle
+ *                        aborts its communicators and becomes unusable (every later *_multi_dev call
+ *                        returns BJJ_E_INVALID): release it with bjj_multi_free. */
 typedef struct bjj_multi bjj_multi;
 /* devices: n_devices HIP device indices (NULL = 0 .. n_devices-1; NULL and 0 = all visible devices).  A device may be
  * named more than once (several contexts on one GPU; how the G > 1 block arithmetic is tested on a one-GPU box) -- the
  * host-pointer form and BJJ_TRANSPORT_PEER_COPY accept that, RCCL does not (BJJ_E_RCCL). */
 int bjj_multi_init(const int* devices, int n_devices, int window_bits, bjj_multi** out);
-/* Transport of the *_multi_dev form: BJJ_TRANSPORT_RCCL (default: grouped ncclScatter / ncclGather over xGMI) or
- * BJJ_TRANSPORT_PEER_COPY (hipMemcpyPeerAsync of the same blocks on the peers' streams; needs no RCCL). */
+/* Transport of the *_multi_dev form: BJJ_TRANSPORT_RCCL (default: grouped ncclSend / ncclRecv, resp. ncclScatter /
+ * ncclGather, over xGMI) or BJJ_TRANSPORT_PEER_COPY (hipMemcpyPeerAsync of the same pieces on the peers' transfer
+ * streams: copy engines, no compute units, no RCCL). */
 enum { BJJ_TRANSPORT_RCCL = 0, BJJ_TRANSPORT_PEER_COPY = 1 };
 int bjj_multi_set_transport(bjj_multi* m, int transport);
+/* Pipeline depth of the *_multi_dev form: a peer's block is cut into at most `chunks` pieces (1..16; default 4, or the
+ * environment variable BJJ_MULTI_CHUNKS at bjj_multi_init) of at least min_chunk_items items each (default 32768; pieces
+ * are multiples of 64 items).  chunks = 1 restores the serial scatter -> kernels -> gather schedule. */
+int bjj_multi_set_chunks(bjj_multi* m, int chunks, size_t min_chunk_items);
 void bjj_multi_free(bjj_multi* m);
 int bjj_multi_size(const bjj_multi* m);
 bjj_ctx* bjj_multi_ctx(bjj_multi* m, int rank);     /* the per-device context (owned by the handle) */
@@ -268,8 +282,15 @@ int bjj_mul_fixed_base_multi_dev(bjj_multi* m, const void* d_scalars, size_t n, 
 int bjj_mul_var_base_multi_dev(bjj_multi* m, const void* d_pts_xy, const void* d_scalars, size_t n, void* d_out_xy);
 int bjj_eddsa_verify_multi_dev(bjj_multi* m, const void* d_pk_xy, const void* d_r_xy, const void* d_s, const void* d_msg,
                                size_t n, void* d_ok /* 16-byte aligned */);
-/* Phase times of the last *_multi_dev call (HIP events, max over devices), and the RCCL version in use. */
+/* Phase spans of the last *_multi_dev call (HIP events, each device against its own start; maximum over the devices):
+ * scatter = until a peer's last input piece has arrived, compute = first kernel start to last kernel end on a device,
+ * gather = last kernel end to last result piece delivered; and the RCCL version in use.  In the pipelined schedule
+ * the spans overlap; their sum is what the serial schedule costs. */
 int bjj_multi_last_timing(bjj_multi* m, double* scatter_ms, double* compute_ms, double* gather_ms, int* rccl_version);
+/* ... and what the call took as a whole: total_ms = start to last event on any device (HIP events), wall_ms = host
+ * clock around the call, chunks = pieces per peer block actually used.  Compare total_ms with scatter + compute + gather
+ * of bjj_multi_last_timing, or with total_ms of the same call after bjj_multi_set_chunks(m, 1, ..). */
+int bjj_multi_last_overlap(bjj_multi* m, double* total_ms, double* wall_ms, int* chunks);
 
 #ifdef __cplusplus
 }

@@ -563,7 +563,7 @@ EXPORT int bjjref_verify_schnorr(const uint8_t *pk, const uint8_t *msg, const ui
 
 /* ---- threaded batch drivers (CPU baseline + bulk expected values) ------ */
 typedef struct {
-  int kind; /* 0 fixed-base, 1 var-base, 2 poseidon5, 3 verify, 4 decompress, 5 compress, 6 verify-compressed, 7 sign, 8 public, 9 verify_schnorr */
+  int kind; /* 0 fixed-base, 1 var-base, 2 poseidon5, 3 verify, 4 decompress, 5 compress, 6 verify-compressed, 7 sign, 8 public, 9 verify_schnorr, 10 point add */
   const uint8_t *a, *b, *c, *d; uint8_t *out; size_t lo, hi;
 } job_t;
 static void *worker(void *arg) {
@@ -580,6 +580,13 @@ static void *worker(void *arg) {
       case 7: ((uint8_t *)j->d)[i] = (uint8_t)bjjref_sign(j->a + 32 * i, j->b + 32 * i, j->out + 64 * i, (uint8_t *)j->c + 32 * i); break;
       case 8: bjjref_public(j->a + 32 * i, j->out + 64 * i); break;
       case 9: j->out[i] = (uint8_t)verify_schnorr1(j->a + 64 * i, j->d + 32 * i, j->b + 64 * i, j->c + 32 * i); break;
+      case 10: {  /* p.projective().add(&q.projective()).affine(): the criterion case `add` of benches/bench_babyjubjub.rs:26-31 */
+        uint8_t pa[96] = {0}, qa[96] = {0}, sum[96];
+        memcpy(pa, j->a + 64 * i, 64); pa[64] = 1;   /* Point::projective: z = 1, src/lib.rs:141-147 */
+        memcpy(qa, j->b + 64 * i, 64); qa[64] = 1;
+        bjjref_proj_add(pa, qa, sum);
+        bjjref_proj_affine(sum, j->out + 64 * i);
+      } break;
     }
   }
   return NULL;
@@ -631,4 +638,7 @@ EXPORT void bjjref_public_batch(const uint8_t *keys, size_t n, uint8_t *out_xy, 
 EXPORT void bjjref_verify_schnorr_batch(const uint8_t *pk, const uint8_t *rb, const uint8_t *s, const uint8_t *msg,
                                         size_t n, uint8_t *ok, int nthreads) {
   run_batch(9, pk, rb, s, msg, ok, n, nthreads);
+}
+EXPORT void bjjref_point_add_batch(const uint8_t *p_xy, const uint8_t *q_xy, size_t n, uint8_t *out_xy, int nthreads) {
+  run_batch(10, p_xy, q_xy, NULL, NULL, out_xy, n, nthreads);
 }

@@ -14,9 +14,10 @@ pub struct BjjMulti {
     _private: [u8; 0],
 }
 
-/// `bjj_info` (include/bjj_hip.h)
+/// `bjj_info` (include/bjj_hip.h): set `struct_size = size_of::<BjjInfo>()` before `bjj_get_info`
 #[repr(C)]
 pub struct BjjInfo {
+    pub struct_size: u32,
     pub device: c_int,
     pub compute_units: c_int,
     pub window_bits: c_int,
@@ -87,6 +88,7 @@ extern "C" {
     pub fn bjj_get_info(ctx: *mut BjjCtx, info: *mut BjjInfo) -> c_int;
     pub fn bjj_multi_init(devices: *const c_int, n_devices: c_int, window_bits: c_int, out: *mut *mut BjjMulti) -> c_int;
     pub fn bjj_multi_set_transport(m: *mut BjjMulti, transport: c_int) -> c_int;
+    pub fn bjj_multi_set_chunks(m: *mut BjjMulti, chunks: c_int, min_chunk_items: usize) -> c_int;
     pub fn bjj_multi_free(m: *mut BjjMulti);
     pub fn bjj_multi_size(m: *const BjjMulti) -> c_int;
     pub fn bjj_multi_ctx(m: *mut BjjMulti, rank: c_int) -> *mut BjjCtx;
@@ -99,4 +101,5 @@ extern "C" {
     pub fn bjj_mul_var_base_multi_dev(m: *mut BjjMulti, d_pts_xy: *const c_void, d_scalars: *const c_void, n: usize, d_out_xy: *mut c_void) -> c_int;
     pub fn bjj_eddsa_verify_multi_dev(m: *mut BjjMulti, d_pk_xy: *const c_void, d_r_xy: *const c_void, d_s: *const c_void, d_msg: *const c_void, n: usize, d_ok: *mut c_void) -> c_int;
     pub fn bjj_multi_last_timing(m: *mut BjjMulti, scatter_ms: *mut f64, compute_ms: *mut f64, gather_ms: *mut f64, rccl_version: *mut c_int) -> c_int;
+    pub fn bjj_multi_last_overlap(m: *mut BjjMulti, total_ms: *mut f64, wall_ms: *mut f64, chunks: *mut c_int) -> c_int;
 }

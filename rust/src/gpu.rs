@@ -41,9 +41,10 @@ impl Gpu {
     }
 
     pub fn info(&self) -> Result<ffi::BjjInfo, String> {
-        let mut i = std::mem::MaybeUninit::<ffi::BjjInfo>::zeroed();
-        check(unsafe { ffi::bjj_get_info(self.ctx, i.as_mut_ptr()) }, "bjj_get_info")?;
-        Ok(unsafe { i.assume_init() })
+        let mut i: ffi::BjjInfo = unsafe { std::mem::zeroed() };
+        i.struct_size = std::mem::size_of::<ffi::BjjInfo>() as u32;   // the library fills at most this many bytes
+        check(unsafe { ffi::bjj_get_info(self.ctx, &mut i) }, "bjj_get_info")?;
+        Ok(i)
     }
 
     /// `B8.mul_scalar(n)` for every 32-byte scalar (reference src/lib.rs:149-164 with self = B8).

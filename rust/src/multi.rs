@@ -1,6 +1,6 @@
 //! All GPUs of the node from one process: `bjj_multi_*` (BASELINE configs[4]).  The batch is cut into
-//! contiguous ceil(n/G) blocks; host slices go through one pipeline thread per device, device-resident arrays through
-//! RCCL scatter / kernels / gather inside libbjj_hip.so.
+//! contiguous ceil(n/G) blocks; host slices go through one pipeline thread per device, device-resident arrays through a
+//! pipelined RCCL scatter / kernels / gather inside libbjj_hip.so (peer blocks travel in pieces; `set_chunks`).
 use crate::ffi;
 use crate::gpu::{check, Gpu};
 use std::os::raw::{c_int, c_void};
@@ -15,6 +15,11 @@ pub struct PhaseTimes {
     pub compute_ms: f64,
     pub gather_ms: f64,
     pub rccl_version: i32,
+    /// start to last event on any device: what the (overlapped) call took; compare with the sum of the three spans
+    pub total_ms: f64,
+    pub wall_ms: f64,
+    /// pieces per peer block actually used
+    pub chunks: i32,
 }
 
 impl MultiGpu {
@@ -89,10 +94,18 @@ impl MultiGpu {
         check(ffi::bjj_eddsa_verify_multi_dev(self.m, d_pk, d_r, d_s, d_msg, n, d_ok), "bjj_eddsa_verify_multi_dev")
     }
 
+    /// Pipeline depth of the device-resident form: at most `chunks` (1..=16) pieces per peer block, none smaller than
+    /// `min_chunk_items`; 1 = the serial scatter -> kernels -> gather schedule.
+    pub fn set_chunks(&self, chunks: i32, min_chunk_items: usize) -> Result<(), String> {
+        check(unsafe { ffi::bjj_multi_set_chunks(self.m, chunks as c_int, min_chunk_items) }, "bjj_multi_set_chunks")
+    }
+
     pub fn last_timing(&self) -> Result<PhaseTimes, String> {
         let (mut s, mut c, mut g, mut v) = (0f64, 0f64, 0f64, 0 as c_int);
         check(unsafe { ffi::bjj_multi_last_timing(self.m, &mut s, &mut c, &mut g, &mut v) }, "bjj_multi_last_timing")?;
-        Ok(PhaseTimes { scatter_ms: s, compute_ms: c, gather_ms: g, rccl_version: v as i32 })
+        let (mut tot, mut wall, mut ch) = (0f64, 0f64, 0 as c_int);
+        check(unsafe { ffi::bjj_multi_last_overlap(self.m, &mut tot, &mut wall, &mut ch) }, "bjj_multi_last_overlap")?;
+        Ok(PhaseTimes { scatter_ms: s, compute_ms: c, gather_ms: g, rccl_version: v as i32, total_ms: tot, wall_ms: wall, chunks: ch as i32 })
     }
 }
 

@@ -115,18 +115,13 @@ class Oracle:
         return out.reshape(n, 64)
 
     def point_add(self, p, q):
-        p = np.ascontiguousarray(p, dtype=np.uint8).reshape(-1, 64)
-        q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 64)
-        one = np.zeros(32, np.uint8)
-        one[0] = 1
-        out = np.empty((p.shape[0], 64), np.uint8)
-        for i in range(p.shape[0]):
-            a = np.concatenate([p[i], one])
-            b = np.concatenate([q[i], one])
-            s = np.empty(96, np.uint8)
-            self.lib.bjjref_proj_add(self._p(a), self._p(b), self._p(s))
-            self.lib.bjjref_proj_affine(self._p(s), self._p(out[i]))
-        return out
+        """p.projective().add(&q.projective()).affine() per item (src/lib.rs:141-147, 88-131, 70-85)"""
+        p = np.ascontiguousarray(p, dtype=np.uint8).reshape(-1)
+        q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1)
+        n = p.size // 64
+        out = np.empty(n * 64, np.uint8)
+        self.lib.bjjref_point_add_batch(self._p(p), self._p(q), ctypes.c_size_t(n), self._p(out), self.threads)
+        return out.reshape(n, 64)
 
 
 @pytest.fixture(scope="session")
@@ -150,27 +145,67 @@ def golden():
 
 
 # ---- CPU emulation of the kernel bodies (debug harness, see tests/emul) ----------
-@pytest.fixture(scope="session")
-def emul():
+@pytest.fixture(scope="session", params=[0, 1], ids=["raw_per_lane_tables", "packed_per_lane_tables"])
+def emul(request):
+    """the kernel bodies compiled for the CPU with bound assertions -- once per per-lane table layout that ships
+    (BJJ_PNIELS_LAYOUT: 0 = raw entries, the verify unit; 1 = packed entries, the variable-base unit)"""
     d = os.path.join(ROOT, "tests", "emul")
-    so = os.path.join(d, "libbjj_emul.so")
+    layout = request.param
+    so = os.path.join(d, "libbjj_emul_l%d.so" % layout)
     srcs = [os.path.join(d, "emul_bodies.cpp")] + [
         os.path.join(ROOT, "babyjubjub-rs_amd", "csrc", f)
         for f in ("fr.hpp", "curve.hpp", "poseidon.hpp", "bjj_device.hpp", "bjj_constants.inc")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        _sh(["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-o", so, srcs[0]], d)
+        _sh(["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-DBJJ_PNIELS_LAYOUT=%d" % layout, "-o", so, srcs[0]], d)
     return ctypes.CDLL(so)
 
 
 # ---- the product on a GPU ---------------------------------------------------------
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    """The session's context: EXPLICITLY the 28-bit table (154.6 GB), the configuration bench.py measures.  Only when that
+    table cannot be allocated (the GPU has other tenants) does the session fall back to the widest that fits -- and then
+    `ctx_w28` skips, so no test silently claims W = 28.  Raises loudly if the library or the GPU is missing: no fallback."""
     import babyjubjub_rs_amd as bjj
-    # the widest fixed-base table that fits (28 bits = 154.6 GB on an empty MI355X: the configuration bench.py measures);
-    # raises loudly if the library or the GPU is missing: no fallback
-    ctx = bjj.Context(0, bjj.WINDOW_AUTO)
+    try:
+        ctx = bjj.Context(0, 28)
+    except bjj.BjjError as e:
+        if "cannot allocate the fixed-base table" not in str(e):
+            raise
+        ctx = bjj.Context(0, bjj.WINDOW_AUTO)
+    print("\n[gpu_ctx] fixed-base window_bits = %d (%.1f GB table)" % (ctx.info().window_bits, ctx.info().table_bytes / 1e9))
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_w28(gpu_ctx):
+    """the headline configuration, asserted: 28-bit windows, 9 digits"""
+    info = gpu_ctx.info()
+    if info.window_bits != 28:
+        pytest.skip("bjj_init(window_bits=28) reported NOMEM on this box; the session runs with %d bits" % info.window_bits)
+    assert info.n_windows == 9 and info.table_bytes == 9 * ((1 << 27) + 1) * 128
+    return gpu_ctx
+
+
+@pytest.fixture(scope="session")
+def ctx_w23():
+    """the library's default configuration (bjj_init(.., 0, ..)): 23-bit windows, 11 digits, 5.9 GB"""
+    import babyjubjub_rs_amd as bjj
+    ctx = bjj.Context(0, 0)
+    info = ctx.info()
+    assert info.window_bits == 23 and info.n_windows == 11 and info.table_bytes == 11 * ((1 << 22) + 1) * 128
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture
+def ctx_for_window(request):
+    """indirect parametrisation: the context whose table has exactly `request.param` window bits"""
+    ctx = request.getfixturevalue({23: "ctx_w23", 28: "ctx_w28"}[request.param])
+    assert ctx.info().window_bits == request.param
+    print("[window_bits = %d]" % ctx.info().window_bits)
+    return ctx
 
 
 # ---- helpers shared by tests ---------------------------------------------------------

@@ -159,7 +159,100 @@ def test_calls_on_two_streams_share_scratch_safely(gpu_ctx, oracle):
     assert (d_out2.cpu().numpy().reshape(n, 64)[idx] == oracle.mul_fixed_base(sc[idx])).all()
 
 
+def test_overlapping_launches_on_two_and_three_streams_use_separate_scratch_sets(oracle):
+    """The context keeps two scratch sets (per-lane tables, work lists, epilogue scratch): launches that alternate over two
+    streams get one set each and run CONCURRENTLY (the head of one fills the tail of the other) -- what bench.py's two-stream
+    protocol times.  Different batches per stream, every verdict / point checked, several rounds so that each set is reused
+    while the other stream's launch is still running; a third stream has to take over the least recently used set and wait
+    for it.  Runs on its own context so that the scratch accounting starts from zero."""
+    import torch
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    dev = torch.device("cuda", 0)
+    ctx = bjj.Context(0, 16)
+    try:
+        n = (1 << 17) + 77                                  # ragged: partially filled last wave and last chunk
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)  # noqa: E731
+        batches = []
+        for b in range(3):
+            keys = w.random_u256(w.SEED_KEYS, n, offset=b * n)
+            msg = w.random_u256(w.SEED_MSGS, n, offset=b * n, top_bits_cleared=3)
+            A = ctx.public_keys(keys)
+            R, S, okf = ctx.sign(keys, msg)
+            assert okf.all()
+            bad = w.corrupt(A, R, S, msg, n, offset=b * n)
+            sc = w.scalars_254(n, offset=17 + b * n)
+            batches.append(dict(A=A, sc=sc, bad=bad, d=[up(A), up(R), up(S), up(msg)], d_sc=up(sc),
+                                d_ok=torch.zeros(n, dtype=torch.uint8, device=dev),
+                                d_out=torch.zeros(n * 64, dtype=torch.uint8, device=dev)))
+        streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        torch.cuda.synchronize()
+        before = ctx.info().scratch_bytes
+        for ns in (2, 3):
+            for B in batches:
+                B["d_ok"].zero_(); B["d_out"].zero_()
+            torch.cuda.synchronize()
+            for rnd in range(4):
+                for b in range(ns):
+                    B, st = batches[b], streams[b].cuda_stream
+                    ctx.eddsa_verify_dev(*[t.data_ptr() for t in B["d"]], n, B["d_ok"].data_ptr(), st)
+                    ctx.mul_var_base_dev(B["d"][0].data_ptr(), B["d_sc"].data_ptr(), n, B["d_out"].data_ptr(), st)
+            ctx.sync()                                       # waits for every caller stream the context has work on
+            for b in range(ns):
+                B = batches[b]
+                assert (B["d_ok"].cpu().numpy() == (~B["bad"]).astype(np.uint8)).all(), (ns, b)
+                idx = np.arange(b, n, 257)
+                got = B["d_out"].cpu().numpy().reshape(n, 64)[idx]
+                assert (got == oracle.mul_var_base(B["A"][idx], B["sc"][idx])).all(), (ns, b)
+        assert ctx.info().scratch_bytes > before            # the second set came into being with the second stream
+        # a single-stream caller never leaves set 0: a fresh context's footprint does not depend on this feature
+        c1 = bjj.Context(0, 16)
+        try:
+            B = batches[0]
+            for _ in range(3):
+                c1.eddsa_verify_dev(*[t.data_ptr() for t in B["d"]], n, B["d_ok"].data_ptr(), streams[0].cuda_stream)
+            c1.sync()
+            one_set = c1.info().scratch_bytes
+            c1.eddsa_verify_dev(*[t.data_ptr() for t in B["d"]], n, B["d_ok"].data_ptr(), streams[1].cuda_stream)
+            c1.sync()
+            assert c1.info().scratch_bytes >= 2 * one_set - 64 > one_set
+        finally:
+            c1.close()
+    finally:
+        ctx.close()
+
+
+def test_entry_points_leave_the_callers_current_device_alone(oracle):
+    """every entry point selects its context's device and restores the calling thread's current device on return"""
+    import torch
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    if torch.cuda.device_count() < 2:
+        # one GPU: the guard has nothing to restore; still run the calls with the device current
+        torch.cuda.set_device(0)
+    other = torch.cuda.device_count() - 1
+    torch.cuda.set_device(other)
+    ctx = bjj.Context(0, 16)
+    try:
+        sc = w.scalars_254(100, offset=1)
+        assert (ctx.mul_fixed_base(sc) == oracle.mul_fixed_base(sc)).all()
+        ctx.sync()
+        assert torch.cuda.current_device() == other
+    finally:
+        ctx.close()
+        torch.cuda.set_device(0)
+
+
 # ---------------------------------------------------------------- multi-GPU handle
+def _pieces(cnt, chunks, min_chunk):
+    """sizes of the pieces bjj_multi_* cuts a peer's block of `cnt` items into (csrc/bjj_multi.inc: chunk geometry)"""
+    if cnt == 0:
+        return []
+    c = max(1, min(chunks, cnt // min_chunk if min_chunk else chunks))
+    csz = (-(-cnt // c) + 63) & ~63
+    return [min(csz, cnt - lo) for lo in range(0, cnt, csz)]
+
+
 def _multi(devs):
     import babyjubjub_rs_amd as bjj
     return bjj.MultiContext(devs, 16)       # a small table per device keeps the test light
@@ -184,7 +277,8 @@ def test_multi_host_form_one_device(oracle, n):
 
 def test_multi_dev_form_rccl_one_device(oracle):
     """G = 1 through the device-resident entry points: RCCL is loaded (dlopen), ncclCommInitAll creates the clique, the
-    grouped ncclScatter / ncclGather run in place at the root, the kernels run on the caller's buffers."""
+    grouped ncclScatter / ncclGather of the serial schedule run in place at the root (on the root's transfer stream), the
+    kernels run on the caller's buffers."""
     import torch
     from babyjubjub_rs_amd import workload as w
     dev = torch.device("cuda", 0)
@@ -231,7 +325,8 @@ def test_multi_block_arithmetic_with_several_contexts_on_one_gpu(oracle, g):
         with pytest.raises(bjj.BjjError, match="distinct devices"):
             m.mul_fixed_base_dev(d0.data_ptr(), 16, o0.data_ptr())          # default transport = RCCL
         m.set_transport("peer")
-        for n in (g * 512, g * 512 + 5, 3, 1, g):
+        for n, chunks in ((g * 512, 1), (g * 512, 4), (g * 512 + 5, 3), (g * 1000 + 77, 16), (3, 4), (1, 4), (g, 2)):
+            m.set_chunks(chunks, 64)        # pieces of >= 64 items, so that these small blocks really are cut up
             sc = w.scalars_254(n, offset=7 * n)
             want = oracle.mul_fixed_base(sc)
             assert (m.mul_fixed_base(sc) == want).all()                      # host-pointer form, g threads
@@ -255,6 +350,10 @@ def test_multi_block_arithmetic_with_several_contexts_on_one_gpu(oracle, g):
             m.eddsa_verify_dev(t_A.data_ptr(), t_R.data_ptr(), t_S.data_ptr(), t_m.data_ptr(), n, d_ok.data_ptr())
             got = d_ok.cpu().numpy()
             assert (got[:n] == (~bad).astype(np.uint8)).all() and (got[n:] == 7).all(), n   # nothing written past n
+            t = m.last_timing()
+            per = -(-n // g)
+            want_pieces = len(_pieces(min(per, max(0, n - per)), chunks, 64)) or 1      # rank 1 holds the largest peer block
+            assert t["chunks"] == want_pieces and t["total_ms"] > 0 and t["wall_ms"] >= t["total_ms"] * 0.5, (n, chunks, t)
         t = m.last_timing()
         assert t["compute_ms"] > 0 and t["rccl_version"] == 0
     finally:
@@ -305,6 +404,45 @@ for g in (2, 3, 8):
         got = d_ok.cpu().numpy()
         assert (got[:n] == (~bad).astype(np.uint8)).all() and (got[n:] == 9).all(), (g, n)
     assert m.last_timing()["rccl_version"] == 99999
+    # ---- the pipelined schedule: every peer block in up to `chunks` pieces, piece c of all peers and arrays in ONE group
+    #      of exact-count send / receive pairs, results back piece by piece
+    def pieces(cnt, chunks, min_chunk):
+        if cnt == 0:
+            return []
+        c = max(1, min(chunks, cnt // min_chunk))
+        csz = (-(-cnt // c) + 63) & ~63
+        return [min(csz, cnt - lo) for lo in range(0, cnt, csz)]
+    for chunks, n in ((4, g * 640), (3, g * 640 + 5), (16, g * 2000 + 1), (2, g + 1)):
+        m.set_chunks(chunks, 64)
+        per_peer = [pieces(m.shard_bounds(n, r)[1] - m.shard_bounds(n, r)[0], chunks, 64) for r in range(1, g)]
+        rounds = max(len(p) for p in per_peer)
+        A, R, S, msg = w.make_signatures(orc.mul_fixed_base, orc.poseidon5, n, offset=5 * n)
+        bad = w.corrupt(A, R, S, msg, n, offset=5 * n)
+        if n > 700:
+            A[700, 3] ^= 2; bad[700] = True                      # an off-curve key inside a later piece
+        t = [up(x) for x in (A, R, S, msg)]
+        d_ok = torch.full((((n + 15) // 16) * 16,), 9, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        fake.fake_rccl_counters(cnt)
+        m.eddsa_verify_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), n, d_ok.data_ptr())
+        fake.fake_rccl_counters(cnt)
+        groups, scatter, gather, send, recv = list(cnt)
+        total = sum(len(p) for p in per_peer)
+        assert (groups, scatter, gather, send, recv) == (2 * rounds, 0, 0, 5 * total, 5 * total), (g, n, chunks, list(cnt), per_peer)
+        got = d_ok.cpu().numpy()
+        assert (got[:n] == (~bad).astype(np.uint8)).all() and (got[n:] == 9).all(), (g, n, chunks)
+        lt = m.last_timing()
+        assert lt["chunks"] == max(rounds, 1) and lt["total_ms"] > 0, lt
+        sc = w.scalars_254(n, offset=n + chunks)
+        d_sc, d_out = up(sc), torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        m.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out.data_ptr())
+        fb = d_out.cpu().numpy().reshape(n, 64)
+        assert (fb == orc.mul_fixed_base(sc)).all(), (g, n, chunks)
+        d_out2 = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+        m.mul_var_base_dev(d_out.data_ptr(), d_sc.data_ptr(), n, d_out2.data_ptr())
+        idx = np.arange(0, n, 37)
+        assert (d_out2.cpu().numpy().reshape(n, 64)[idx] == orc.mul_var_base(fb[idx], sc[idx])).all(), (g, n, chunks)
     m.close()
 print("fake-rccl ok")
 """

@@ -7,8 +7,8 @@ import subprocess
 
 from conftest import ROOT
 
-KIND_C = {"int": "int", "size_t": "usize", "uint64_t": "u64", "double": "f64"}
-KIND_RS = {"c_int": "int", "usize": "usize", "u64": "u64", "f64": "f64"}
+KIND_C = {"int": "int", "size_t": "usize", "uint32_t": "u32", "uint64_t": "u64", "double": "f64"}
+KIND_RS = {"c_int": "int", "usize": "usize", "u32": "u32", "u64": "u64", "f64": "f64"}
 
 
 def c_functions():
