@@ -36,6 +36,11 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_eddsa_verify_scan(const uint8
     if (verify_needs_exact(in, c_K)) wl[WL_HDR + atomicAdd(&wl[0], 1u)] = (u32)i;
   }
 }
+// NOTE on this cursor idiom (`if (lane == 0) c = atomicAdd(..); c = __shfl(c, 0);`): it is safe in the two loops below,
+// whose bodies contain no other `if (lane == 0)` block.  In a loop whose body ENDS with such a block hipcc threads lanes
+// 1..63 from the end of the body straight into the next iteration's cross-lane read while lane 0 is still away -- they read
+// an inactive lane, get 0 and never leave (round 3, profiles/r03_ab_inkernel_scan_rejected.txt).  The branch-free form --
+// every lane issues the atomic, lane 0 adds the step and the others 0, v_readfirstlane for the result -- is immune.
 __device__ __forceinline__ unsigned long long wave_grab(u32* cursor_words, int lane) {
   unsigned long long c = 0;
   if (lane == 0) c = atomicAdd((unsigned long long*)cursor_words, 64ULL);

@@ -7,6 +7,8 @@
 //!
 //! NOT COMPILED in this repository's build image (no Rust toolchain there): see README.md.
 extern crate ff;
+#[macro_use]
+extern crate lazy_static;
 extern crate num_bigint;
 extern crate num_traits;
 extern crate poseidon_rs;
@@ -15,6 +17,7 @@ extern crate rand;
 pub mod ffi;
 pub mod gpu;
 pub mod multi;
+pub mod utils; // lib.rs:24
 
 use ff::{Field, PrimeField};
 use gpu::with_gpu;
@@ -56,19 +59,33 @@ fn bigint_from_le(b: &[u8]) -> BigInt {
     BigInt::from_bytes_le(Sign::Plus, b)
 }
 
-fn q() -> BigInt {
-    BigInt::parse_bytes(b"21888242871839275222246405745257275088548364400416034343698204186575808495617", 10).unwrap() // lib.rs:33-36
-}
-
-fn order() -> BigInt {
-    BigInt::parse_bytes(b"21888242871839275222246405745257275088614511777268538073601725287587578984328", 10).unwrap() // lib.rs:48-52
-}
-
-fn b8() -> Point {
-    Point {
-        x: Fr::from_str("5299619240641551281634865583518297030282874472190772894086521144482721001553").unwrap(), // lib.rs:37-46
+lazy_static! {
+    /// The field modulus r -- the reference's one public constant (lib.rs:33-36; D, A, B8, ORDER, SUBORDER are private there).
+    pub static ref Q: BigInt =
+        BigInt::parse_bytes(b"21888242871839275222246405745257275088548364400416034343698204186575808495617", 10).unwrap();
+    /// group order 8 l (lib.rs:48-52)
+    static ref ORDER: BigInt =
+        BigInt::parse_bytes(b"21888242871839275222246405745257275088614511777268538073601725287587578984328", 10).unwrap();
+    /// generator of the prime-order subgroup (lib.rs:37-46)
+    static ref B8: Point = Point {
+        x: Fr::from_str("5299619240641551281634865583518297030282874472190772894086521144482721001553").unwrap(),
         y: Fr::from_str("16950150798460657717958625567821834550301663161624707787222815936182638968203").unwrap(),
+    };
+}
+
+/// `Fr::from_str(&msg.to_string()).unwrap()` of the reference (lib.rs:321, 368, 399) panics on a negative integer -- the
+/// range test before it only rejects msg > Q.  The 32-byte records of the C ABI cannot carry a sign, so the wrappers
+/// reproduce the panic here instead of silently verifying / signing |msg|.
+fn non_negative(msg: &BigInt) {
+    if msg.sign() == Sign::Minus {
+        panic!("called `Option::unwrap()` on a `None` value: Fr::from_str of a negative msg");
     }
+}
+
+/// |n| mod 8l: what `B8.mul_scalar(&n)` depends on (the reference drops the sign, lib.rs:156; B8 has order dividing 8l)
+fn b8_scalar(n: &BigInt) -> BigInt {
+    let (_, mag) = n.clone().into_parts();
+    BigInt::from(mag) % &*ORDER
 }
 
 fn point_bytes(p: &Point) -> [u8; 64] {
@@ -218,9 +235,10 @@ impl PrivateKey {
 
     pub fn sign(&self, msg: BigInt) -> Result<Signature, String> {
         // lib.rs:308-342
-        if msg > q() || msg.sign() == Sign::Minus {
+        if msg > *Q {
             return Err("msg outside the Finite Field".to_string());
         }
+        non_negative(&msg); // lib.rs:321
         let (r, s, ok) = with_gpu(|g| g.sign(&self.key, &bigint_to_le(&msg, 32)))?;
         if ok[0] == 0 {
             return Err("msg outside the Finite Field".to_string());
@@ -230,10 +248,11 @@ impl PrivateKey {
 
     pub fn sign_schnorr(&self, m: BigInt) -> Result<(Point, BigInt), String> {
         // lib.rs:344-361; the 1024-bit nonce is drawn here (lib.rs:347-348) and handed to the device
-        if m > q() || m.sign() == Sign::Minus {
-            return Err("msg outside the Finite Field".to_string());
+        let k = BigInt::from(rand::thread_rng().gen_biguint(1024)); // drawn first, as at lib.rs:347-348
+        if m > *Q {
+            return Err("msg outside the Finite Field".to_string()); // schnorr_hash's Err, lib.rs:365-367 via :353
         }
-        let k = BigInt::from(rand::thread_rng().gen_biguint(1024));
+        non_negative(&m); // lib.rs:368
         let (r, s, ok) = with_gpu(|g| g.sign_schnorr(&self.key, &bigint_to_le(&m, 32), &bigint_to_le(&k, ffi::BJJ_SCHNORR_NONCE_BYTES)))?;
         if ok[0] == 0 {
             return Err("msg outside the Finite Field".to_string());
@@ -244,9 +263,10 @@ impl PrivateKey {
 
 pub fn schnorr_hash(pk: &Point, msg: BigInt, c: &Point) -> Result<BigInt, String> {
     // lib.rs:364-373: Poseidon([pk.x, pk.y, c.x, c.y, msg])
-    if msg > q() {
+    if msg > *Q {
         return Err("msg outside the Finite Field".to_string());
     }
+    non_negative(&msg); // lib.rs:368
     let mut input = Vec::with_capacity(160);
     input.extend_from_slice(&point_bytes(pk));
     input.extend_from_slice(&point_bytes(c));
@@ -256,10 +276,12 @@ pub fn schnorr_hash(pk: &Point, msg: BigInt, c: &Point) -> Result<BigInt, String
 
 pub fn verify_schnorr(pk: Point, m: BigInt, r: Point, s: BigInt) -> Result<bool, String> {
     // lib.rs:375-385; s only multiplies B8, so it is reduced mod the group order 8l into the 32-byte record (exact)
-    if m > q() {
+    // sl = B8.mul_scalar(&s) comes first in the reference (:377) and uses |s|; the hash's Err / panic follow (:379)
+    if m > *Q {
         return Err("msg outside the Finite Field".to_string());
     }
-    let s_red = ((s % order()) + order()) % order();
+    non_negative(&m);
+    let s_red = b8_scalar(&s);
     let ok = with_gpu(|g| g.schnorr_verify(&point_bytes(&pk), &point_bytes(&r), &bigint_to_le(&s_red, 32), &bigint_to_le(&m, 32)))?;
     match ok[0] {
         2 => Err("msg outside the Finite Field".to_string()),
@@ -276,6 +298,10 @@ pub fn new_key() -> PrivateKey {
 
 pub fn verify(pk: Point, sig: Signature, msg: BigInt) -> bool {
     // lib.rs:395-412
+    if msg > *Q {
+        return false; // :396-398
+    }
+    non_negative(&msg); // :399
     verify_batch(&[pk], &[sig], &[msg])[0]
 }
 
@@ -290,8 +316,7 @@ pub fn mul_scalar_batch(points: &[Point], scalars: &[BigInt]) -> Vec<Point> {
         return Vec::new();
     }
     let width = scalars.iter().map(|n| ((n.bits() as usize + 255) / 256).max(1) * 32).max().unwrap();
-    let g = b8();
-    let all_b8 = points.iter().all(|p| p.x == g.x && p.y == g.y);
+    let all_b8 = points.iter().all(|p| p.x == B8.x && p.y == B8.y);
     let mut sc = Vec::with_capacity(scalars.len() * width);
     for n in scalars {
         sc.extend_from_slice(&bigint_to_le(n, width));
@@ -311,31 +336,31 @@ pub fn mul_scalar_batch(points: &[Point], scalars: &[BigInt]) -> Vec<Point> {
 
 /// `B8.mul_scalar(&n)` for every n (the engine of `PrivateKey::public`, lib.rs:304-306)
 pub fn mul_fixed_base_batch(scalars: &[BigInt]) -> Vec<Point> {
-    let l8 = order();
     let mut sc = Vec::with_capacity(scalars.len() * 32);
     for n in scalars {
         // B8 is on the curve: n * B8 == (|n| mod 8l) * B8 exactly, which also brings any n into the 32-byte record
-        let (_, mag) = n.clone().into_parts();
-        sc.extend_from_slice(&bigint_to_le(&(BigInt::from(mag) % &l8), 32));
+        sc.extend_from_slice(&bigint_to_le(&b8_scalar(n), 32));
     }
     let out = with_gpu(|g| g.mul_fixed_base(&sc)).expect("mul_fixed_base_batch");
     out.chunks(64).map(point_from_bytes).collect()
 }
 
-/// `verify(pks[i], sigs[i], msgs[i])` for all i
+/// `verify(pks[i], sigs[i], msgs[i])` for all i.  A batch cannot panic for one item: a NEGATIVE msg -- where the
+/// reference's single-item `verify` panics (lib.rs:399), and so does `verify` above -- yields `false` here.
 pub fn verify_batch(pks: &[Point], sigs: &[Signature], msgs: &[BigInt]) -> Vec<bool> {
     assert!(pks.len() == sigs.len() && sigs.len() == msgs.len());
     let n = pks.len();
-    let qq = q();
+    let qq = &*Q;
     let (mut pk, mut r, mut s, mut m) = (Vec::with_capacity(n * 64), Vec::with_capacity(n * 64), Vec::with_capacity(n * 32), Vec::with_capacity(n * 32));
     let mut early_false = vec![false; n];
     for i in 0..n {
         pk.extend_from_slice(&point_bytes(&pks[i]));
         r.extend_from_slice(&point_bytes(&sigs[i].r_b8));
         // msg > Q is `false` before anything else (lib.rs:396-398); s wider than 256 bits only multiplies B8: reduce mod 8l
-        early_false[i] = msgs[i] > qq || msgs[i].sign() == Sign::Minus;
+        early_false[i] = msgs[i] > *qq || msgs[i].sign() == Sign::Minus;
         let msg = if early_false[i] { BigInt::zero() } else { msgs[i].clone() };
-        let sv = if sigs[i].s.bits() > 256 { &sigs[i].s % order() } else { sigs[i].s.clone() };
+        // s only multiplies B8 (:405) and its sign is dropped there: any s, of any width, as |s| mod 8l
+        let sv = if sigs[i].s.bits() > 256 { b8_scalar(&sigs[i].s) } else { sigs[i].s.clone() };
         s.extend_from_slice(&bigint_to_le(&sv, 32));
         m.extend_from_slice(&bigint_to_le(&msg, 32));
     }
@@ -355,12 +380,13 @@ pub fn public_batch(keys: &[PrivateKey]) -> Vec<Point> {
 /// `keys[i].sign(msgs[i])` for all i
 pub fn sign_batch(keys: &[PrivateKey], msgs: &[BigInt]) -> Vec<Result<Signature, String>> {
     assert_eq!(keys.len(), msgs.len());
-    let qq = q();
+    let qq = &*Q;
+    // msg > Q is the reference's Err; a negative msg (its panic, lib.rs:321) becomes an Err of this item as well
+    let bad: Vec<bool> = msgs.iter().map(|m| m > qq || m.sign() == Sign::Minus).collect();
     let (mut kb, mut mb) = (Vec::with_capacity(keys.len() * 32), Vec::with_capacity(keys.len() * 32));
-    let bad: Vec<bool> = msgs.iter().map(|m| *m > qq || m.sign() == Sign::Minus).collect();
     for (i, k) in keys.iter().enumerate() {
         kb.extend_from_slice(&k.key);
-        mb.extend_from_slice(&bigint_to_le(if bad[i] { &qq } else { &msgs[i] }, 32));
+        mb.extend_from_slice(&bigint_to_le(if bad[i] { qq } else { &msgs[i] }, 32));
     }
     let (r, s, ok) = with_gpu(|g| g.sign(&kb, &mb)).expect("sign_batch");
     (0..keys.len())
