@@ -94,3 +94,16 @@ def corrupt(A, R, S, msg, n, offset=0):
             ci = torch.from_numpy(cols).to(arr.device)
             arr[ri, ci] = arr[ri, ci] ^ torch.from_numpy(mask).to(arr.device)
     return bad
+
+
+def piece_bounds(cnt, pieces=4, min_piece=1 << 15):
+    """How a peer's block of `cnt` items is cut for the pipelined scatter -> kernels -> gather schedule: at most `pieces`
+    pieces, none smaller than min_piece items (except that a block below 2 * min_piece stays whole), every piece a multiple
+    of 64 items but the last.  The SAME geometry as bjj_multi_* inside libbjj_hip.so (csrc/bjj_multi.inc: chunk geometry).
+    Returns [(lo, hi), ...] relative to the block."""
+    if cnt <= 0:
+        return []
+    c = max(1, min(int(pieces), cnt // min_piece if min_piece else int(pieces)))
+    csz = (-(-cnt // c) + 63) & ~63
+    return [(lo, min(cnt, lo + csz)) for lo in range(0, cnt, csz)]
+

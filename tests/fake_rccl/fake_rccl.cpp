@@ -14,6 +14,7 @@
 // A violated rule makes the call return ncclInvalidUsage (5) and the message is kept for ncclGetErrorString.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -38,8 +39,15 @@ ncclResult_t copy(void* dst, const void* src, size_t bytes, ncclComm_t on, hipSt
   if (hipSetDevice(on->device) != hipSuccess) return ncclUnhandledCudaError;
   return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
+// failure injection (tests of the library's error path): FAKE_RCCL_FAIL_AT = k makes the k-th posted operation (1-based,
+// counted over the life of the process) fail synchronously, the way a real RCCL call rejects a bad argument.  Like real RCCL
+// the double then discards the whole group: its GroupEnd reports the error and launches nothing.
+long g_posted = 0;
+bool g_group_failed = false;
+long fail_at() { const char* e = getenv("FAKE_RCCL_FAIL_AT"); return e && *e ? atol(e) : 0; }
 ncclResult_t post(const Op& op) {
   if (g_depth == 0) return fail("collective / p2p call outside ncclGroupStart/End in a single-process multi-rank clique");
+  if (++g_posted == fail_at()) { g_group_failed = true; return fail("injected failure of a posted operation"); }
   g_ops.push_back(op);
   return ncclSuccess;
 }
@@ -115,12 +123,16 @@ API ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist)
   for (int i = 0; i < ndev; i++) comm[i] = new ncclComm{i, ndev, devlist ? devlist[i] : i};
   return ncclSuccess;
 }
+long g_aborted = 0;
 API ncclResult_t ncclCommDestroy(ncclComm_t c) { delete c; return ncclSuccess; }
+API ncclResult_t ncclCommAbort(ncclComm_t c) { g_aborted++; delete c; return ncclSuccess; }
+API long fake_rccl_aborted(void) { return g_aborted; }
 API ncclResult_t ncclGroupStart() { g_depth++; return ncclSuccess; }
 API ncclResult_t ncclGroupEnd() {
   if (g_depth <= 0) return fail("ncclGroupEnd without ncclGroupStart");
   if (--g_depth) return ncclSuccess;
   g_groups++;
+  if (g_group_failed) { g_group_failed = false; g_ops.clear(); return fail("group discarded: a call inside it had failed"); }
   return run_group();
 }
 API ncclResult_t ncclScatter(const void* s, void* r, size_t n, ncclDataType_t t, int root, ncclComm_t c, hipStream_t st) {

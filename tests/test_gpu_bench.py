@@ -33,7 +33,10 @@ def test_bench_gpus_2_self_launch_shared_gpu():
     assert j["also"]["verify"]["parity_sample_ok"] and j["also"]["var_base"]["parity_sample_ok"]
     s = j["strong"]
     assert s["fixed_base_1M_total"]["total_items"] == 1 << 20
-    assert s["verify_total"]["total_items"] == 1 << 18 and s["verify_total"]["rank0_resident"]["gathered_verdicts_ok"]
+    rr = s["verify_total"]["rank0_resident"]
+    assert s["verify_total"]["total_items"] == 1 << 18 and rr["gathered_verdicts_ok"]
+    # the pipelined schedule is the reported one, the serial one is timed next to it; 2^17 items per peer block = 4 pieces
+    assert rr["pieces_per_peer_block"] == 4 and rr["serial_schedule"]["ms_per_step"] > 0 and rr["ms_per_step"] > 0
 
 
 def test_bench_gpus_3_ragged_strong_total():
@@ -58,7 +61,19 @@ def test_bench_one_gpu_line_has_every_block():
     assert r.returncode == 0, r.stderr[-3000:]
     assert j["n_gpus"] == 1 and j["parity_sample_ok"] and j["roofline"]["frac"] > 0 and j["cpu_baseline"]["value"] > 0
     assert j["rotating_batches"] == 4 and j["single_batch_kernel_ms"] > 0
+    assert j["streams"] == 1 and j["per_launch_event_ms"]["median_ms"] > 0 and j["per_launch_event_ms"]["value_from_median"] > 0
     for k in ("verify", "var_base"):
         assert j["also"][k]["roofline"]["kernel_ms_avg"] > 0 and j["also"][k]["cpu_baseline"]["cores"] >= 1
+        # two-stream protocol for the kernels whose launch is a non-integral number of rounds, one-stream control next to it
+        assert j["also"][k]["streams"] == 2 and j["also"][k]["single_stream"]["kernel_ms_avg"] > 0
+
+
+def test_bench_point_add_and_compress_workloads():
+    """the reference's remaining criterion cases (benches/bench_babyjubjub.rs:26-31, 40-41) as bench workloads"""
+    for wl, unit in (("point_add", "point additions/s"), ("compress", "points/s")):
+        r, j = _run(["--workload", wl, "--steps", "10", "--warmup", "2", "--warmup-seconds", "0.1", "--batch", str(1 << 16), "--window-bits", "16",
+                     "--no-also", "--no-strong"])
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert j["parity_sample_ok"] and j["unit"] == unit and j["roofline"]["achieved"] > 0 and j["cpu_baseline"]["value"] > 0
     assert j["also"]["fixed_base_window_bits_23"]["parity_sample_ok"]
     assert j["config"]["init_ms"] > 0 and j["config"]["table_bytes"] > 0

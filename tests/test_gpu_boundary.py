@@ -468,6 +468,66 @@ def test_multi_rccl_call_sequence_against_a_test_double():
     assert r.returncode == 0 and "fake-rccl ok" in r.stdout, r.stdout[-4000:]
 
 
+_FAKE_RCCL_FAILURE_SCRIPT = r"""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["BJJ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["BJJ_ROOT"], "tests"))
+import babyjubjub_rs_amd as bjj
+from babyjubjub_rs_amd import workload as w
+from conftest import Oracle
+orc = Oracle()
+fake = ctypes.CDLL(os.environ["BJJ_RCCL_LIBRARY"])
+fake.fake_rccl_aborted.restype = ctypes.c_long
+dev = torch.device("cuda", 0)
+up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)
+g, n = 3, 3 * 640 + 5
+m = bjj.MultiContext([0] * g, 8)
+m.set_chunks(4, 64)
+sc = w.scalars_254(n, offset=1)
+d_sc, d_out = up(sc), torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+torch.cuda.synchronize()
+try:
+    m.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out.data_ptr())       # FAKE_RCCL_FAIL_AT: a send of the second piece fails
+    raise SystemExit("the injected failure was not reported")
+except bjj.BjjError as e:
+    assert "injected failure" in str(e) and "unusable" in str(e), str(e)
+assert fake.fake_rccl_aborted() == g, fake.fake_rccl_aborted()         # every communicator aborted, none destroyed twice
+try:
+    m.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out.data_ptr())
+    raise SystemExit("a retired handle accepted another call")
+except bjj.BjjError as e:
+    assert "unusable" in str(e), str(e)
+assert (m.mul_fixed_base(sc) == orc.mul_fixed_base(sc)).all()          # the host-pointer form needs no communicator
+m.close()                                                              # must return (no hang on half-posted transfers)
+os.environ["FAKE_RCCL_FAIL_AT"] = "0"
+m2 = bjj.MultiContext([0] * g, 8)                                      # a fresh handle works
+m2.mul_fixed_base_dev(d_sc.data_ptr(), n, d_out.data_ptr())
+assert (d_out.cpu().numpy().reshape(n, 64) == orc.mul_fixed_base(sc)).all()
+m2.close()
+print("fake-rccl failure path ok")
+"""
+
+
+def test_multi_rccl_failure_retires_the_handle_without_hanging():
+    """a transfer that fails after the call has started to enqueue must not leave a half-posted group behind.
+    The test double rejects the 7th posted operation (a send of the second piece): the library stops posting, the double --
+    like real RCCL -- discards that group, the handle aborts its communicators (ncclCommAbort), reports the first error and
+    refuses further device-resident calls; freeing it returns."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    d = os.path.join(ROOT, "tests", "fake_rccl")
+    so = os.path.join(d, "libfake_rccl.so")
+    if not os.path.exists(so) or os.path.getmtime(os.path.join(d, "fake_rccl.cpp")) > os.path.getmtime(so):
+        r = subprocess.run(["make", "-s"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+    env = dict(os.environ, BJJ_RCCL_LIBRARY=so, BJJ_ROOT=ROOT, FAKE_RCCL_FAIL_AT="7")
+    r = subprocess.run([sys.executable, "-c", _FAKE_RCCL_FAILURE_SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "fake-rccl failure path ok" in r.stdout, r.stdout[-4000:]
+
+
 def test_multi_all_devices_scatter_gather(oracle):
     """every visible device (the driver's 8-GPU box; skipped on a 1-GPU box): ragged and even batches through both forms"""
     import torch

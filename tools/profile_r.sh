@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 python3 bench.py --workload $WL --no-also --no-strong > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; tail -c 3000 $OUT/bench_$WL.json
 export TMPDIR=/tmp
-ARGS="bench.py --workload $WL --no-cpu-baseline --no-also --no-strong"   # same steps / warm-up as the default bench line
+ARGS="bench.py --workload $WL --streams 1 --no-cpu-baseline --no-also --no-strong"   # same steps / warm-up as the default bench line; ONE stream: the profiler serialises launches anyway, and per-launch counters / durations mean one thing
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_$WL -o trace -- python3 $ARGS > $OUT/trace_$WL.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$WL -o pmc -- python3 $ARGS > $OUT/pmc_fetch_$WL.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$WL -o pmc -- python3 $ARGS > $OUT/pmc_write_$WL.log 2>&1

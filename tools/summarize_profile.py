@@ -31,7 +31,18 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
                                       "Accum_VGPR_Count", "SGPR_Count")}
     for k, v in agg.items():
         counters[k] = (sum(v) / len(v), len(v))
-out += ["## dispatch", "", "```", json.dumps(meta), "```", "", "## PMC counters of `%s` (mean per launch)" % KERNEL, "",
+alloc = ""
+try:   # the compiler's own allocation for this kernel (profiles/<round>_resource_usage.txt from `make resource-usage`)
+    ru = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_resource_usage.txt"))[-1]
+    for line in open(os.path.join(ROOT, "profiles", ru)):
+        f = line.split()
+        if f and f[0] == KERNEL:
+            alloc = ("Allocated by the compiler (profiles/%s): **%s VGPRs**, %s SGPRs, %s B scratch per lane, %s waves per SIMD, %s B LDS per "
+                     "workgroup.  rocprofv3's `VGPR_Count` below is about half of the allocated VGPRs on gfx950 -- do not size occupancy from it."
+                     % (ru, f[1], f[2], f[3], f[4], f[7]))
+except Exception:
+    pass
+out += ["## dispatch", ""] + ([alloc, ""] if alloc else []) + ["```", json.dumps(meta), "```", "", "## PMC counters of `%s` (mean per launch)" % KERNEL, "",
         "| counter | mean | launches |", "|---|---|---|"]
 for k in sorted(counters):
     out.append("| %s | %.6g | %d |" % (k, counters[k][0], counters[k][1]))
