@@ -84,6 +84,13 @@ struct ScratchSet {
   size_t vb_threads = 0;
   u32* slow = nullptr;         // [0] = count, [1..] item indices deferred to the exact-path kernels
   size_t slow_items = 0;
+  // verify: the on-curve scan of a call is routed through this stream of the HIGHEST priority, so that while another launch
+  // of the context fills the chip its few light waves get the next slots that free up instead of queueing behind that
+  // launch's pending workgroups for a whole launch (profiles/r03_ab_verify_group_dispatch.txt)
+  hipStream_t scan_stream = nullptr;
+  hipEvent_t ev_scan_in = nullptr, ev_scan_out = nullptr;
+  u32* slotq = nullptr;        // verify, one group per workgroup: per-XCD ring of free per-lane-table slots (k_verify.hip)
+  u32 slot_cap = 0;            // slots per XCD
   uint8_t* codec = nullptr;    // verify_compressed: n * (64 pk + 64 R + 32 s + 2 flags) bytes; public_keys: the scalar keys
   size_t codec_items = 0;
   // Ordering of the set: every call that uses it records `ev_last` on its stream after enqueueing, and a call on a
@@ -110,6 +117,7 @@ struct bjj_ctx {
   // business); the others: resident 256-lane workgroups per CU
   int lanes_fixed = 512, lanes_var = 512;
   int occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
+  int xccs = 1;                // XCDs of the device (probed at init; sizes the verify kernels' slot queues)
   int occ_decomp = 1, occ_sign = 1, occ_sign_schnorr = 1;
   hipStream_t stream = nullptr;
   u32* table = nullptr;      // [window][digit 0 .. 2^(W-1)] x 128 B
@@ -191,8 +199,23 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
     HIPCK(hipMalloc((void**)&S->slow, (n + 16) * sizeof(u32)));
     S->slow_items = n;
   }
-  size_t tv = (size_t)c->lanes_var, te = (size_t)c->occ_verify * BJJ_VERIFY_BLOCK * 2;  // lanes per CU; verify: 2 tables per lane
-  size_t threads = (size_t)c->cus * (tv > te ? tv : te);
+  // slots of per-lane tables: K2 needs its resident lanes; verify (2 tables per lane) the waves that can be resident, rounded
+  // up to a whole number per XCD (the slot queues are per XCD)
+  const size_t cu_per_xcc = ((size_t)c->cus + c->xccs - 1) / c->xccs;
+  const u32 cap = (u32)(cu_per_xcc * c->occ_verify * (BJJ_VERIFY_BLOCK / 64));
+  size_t tv = (size_t)c->cus * c->lanes_var, te = (size_t)c->xccs * cap * 64 * 2;
+  size_t threads = tv > te ? tv : te;
+  if (!S->slotq || S->slot_cap != cap) {
+    if (S->slotq) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->slotq)); S->slotq = nullptr; }
+    const size_t stride = 16 + cap;
+    std::vector<u32> h((size_t)c->xccs * stride, 0u);
+    for (int x = 0; x < c->xccs; x++)
+      for (u32 i = 0; i < cap; i++) h[(size_t)x * stride + 16 + i] = (u32)x * cap + i + 1u;   // slot id + 1
+    HIPCK(hipMalloc((void**)&S->slotq, h.size() * sizeof(u32)));
+    HIPCK(hipMemcpy(S->slotq, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice));
+    HIPCK(hipStreamSynchronize(nullptr));
+    S->slot_cap = cap;
+  }
   if (threads > S->vb_threads) {
     if (S->vb_tables) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->vb_tables)); S->vb_tables = nullptr; S->vb_threads = 0; }
     HIPCK(hipMalloc((void**)&S->vb_tables, threads * VB_TABLE_WORDS_MAX * sizeof(u32)));
@@ -331,6 +354,10 @@ static void ctx_destroy(bjj_ctx* c) {
     if (S.scratch) hipFree(S.scratch);
     if (S.vb_tables) hipFree(S.vb_tables);
     if (S.slow) hipFree(S.slow);
+    if (S.slotq) hipFree(S.slotq);
+    if (S.ev_scan_in) hipEventDestroy(S.ev_scan_in);
+    if (S.ev_scan_out) hipEventDestroy(S.ev_scan_out);
+    if (S.scan_stream) hipStreamDestroy(S.scan_stream);
     if (S.ev_last) hipEventDestroy(S.ev_last);
   }
   for (StreamMark& k : c->marks) if (k.ev) hipEventDestroy(k.ev);
@@ -397,6 +424,14 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->occ_sign_schnorr = bjjk::occ_sign_schnorr();
   hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (se != hipSuccess) { ctx_destroy(c); return set_err(BJJ_E_HIP, std::string("bjj_init: stream/event: ") + hipGetErrorString(se)); }
+  {  // XCDs of this device (the verify kernels keep one queue of table slots per XCD)
+    u32* d_word = nullptr;
+    if (hipMalloc((void**)&d_word, sizeof(u32)) == hipSuccess) {
+      const int x = bjjk::probe_xccs(c->stream, d_word);
+      hipFree(d_word);
+      c->xccs = x >= 1 && x <= 16 ? x : 1;
+    }
+  }
   for (;;) {
     c->table_bytes = fixed_stride(c->W) * (size_t)c->nwin * NIELS_WORDS * sizeof(u32);
     se = hipMalloc((void**)&c->table, c->table_bytes);
@@ -565,6 +600,26 @@ int bjj_poseidon5_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out, void*
   LAUNCHCK(bjjk::poseidon5(st, grid_for(c, n, c->occ_poseidon), (const uint8_t*)d_in, n, (uint8_t*)d_out), "bjj_poseidon5_dev");
   DEV_LEAVE(c);
 }
+// scan (priority stream) -> main kernel (the caller's stream), both ordered behind what `st` has queued so far
+static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s,
+                          const uint8_t* msg, size_t n, uint8_t* ok) {
+  if (!S->scan_stream) {
+    int least = 0, greatest = 0;
+    HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCK(hipStreamCreateWithPriority(&S->scan_stream, hipStreamNonBlocking, greatest));
+    HIPCK(hipEventCreateWithFlags(&S->ev_scan_in, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&S->ev_scan_out, hipEventDisableTiming));
+  }
+  const int scan_grid = grid_for(c, n, c->occ_scan, 64);   // occ_scan counts waves; the scan kernel's block is a launcher detail
+  HIPCK(hipEventRecord(S->ev_scan_in, st));
+  HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));
+  LAUNCHCK(bjjk::verify_scan(S->scan_stream, scan_grid * 64 / bjjk::verify_scan_block(), pk, r, msg, n, S->slow), "verify scan");
+  HIPCK(hipEventRecord(S->ev_scan_out, S->scan_stream));
+  HIPCK(hipStreamWaitEvent(st, S->ev_scan_out, 0));
+  LAUNCHCK(bjjk::verify_main(st, grid_for(c, n, c->occ_verify, BJJ_VERIFY_BLOCK), schnorr, c->table, c->W, c->nwin, pk, r, s, msg, n, ok,
+                             S->vb_tables, S->slow, S->slotq, S->slot_cap), "verify");
+  return BJJ_OK;
+}
 static int verify_launch(bjj_ctx* c, bool schnorr, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg,
                          size_t n, void* d_ok, void* stream, const char* who) {
   if (!c) return set_err(BJJ_E_INVALID, std::string(who) + ": ctx is NULL");
@@ -574,9 +629,8 @@ static int verify_launch(bjj_ctx* c, bool schnorr, const void* d_pk, const void*
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   if (!d_ok) return set_err(BJJ_E_INVALID, std::string(who) + ": d_ok is NULL");
   SET_ENTER(c, stream, n, false);
-  LAUNCHCK(bjjk::verify(st, grid_for(c, n, c->occ_scan), grid_for(c, n, c->occ_verify, BJJ_VERIFY_BLOCK), schnorr, c->table, c->W, c->nwin,
-                        (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n, (uint8_t*)d_ok,
-                        S->vb_tables, S->slow), "verify");
+  { int rc_ = enqueue_verify(c, S, st, schnorr, (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_msg, n,
+                             (uint8_t*)d_ok); if (rc_) return rc_; }
   SET_LEAVE(c);
 }
 int bjj_eddsa_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
@@ -652,8 +706,7 @@ int bjj_eddsa_verify_compressed_dev(bjj_ctx* c, const void* d_pk32, const void* 
   const int g = grid_for(c, n, c->occ_decomp);
   LAUNCHCK(bjjk::decompress_points(st, g, (const uint8_t*)d_pk32, 32, n, pk_xy, f_pk, nullptr), "decompress(pk)");
   LAUNCHCK(bjjk::decompress_points(st, g, (const uint8_t*)d_sig64, 64, n, r_xy, f_r, s32), "decompress(sig)");
-  LAUNCHCK(bjjk::verify(st, grid_for(c, n, c->occ_scan), grid_for(c, n, c->occ_verify, BJJ_VERIFY_BLOCK), false, c->table, c->W, c->nwin, pk_xy, r_xy, s32,
-                        (const uint8_t*)d_msg, n, (uint8_t*)d_ok, S->vb_tables, S->slow), "verify");
+  { int rc_ = enqueue_verify(c, S, st, false, pk_xy, r_xy, s32, (const uint8_t*)d_msg, n, (uint8_t*)d_ok); if (rc_) return rc_; }
   LAUNCHCK(bjjk::merge_codec_flags(st, grid_for(c, n, 8), (uint8_t*)d_ok, f_pk, f_r, n), "merge_codec_flags");
   SET_LEAVE(c);
 }

@@ -162,3 +162,28 @@ struct GatherCoopLds {
     return n;
   }
 };
+
+// ---------------------------------------------------------------------------
+// Slot queue (one per XCD: a table slot never migrates between XCDs, whose L2s are not coherent with each other inside a
+// kernel): words [0] head ticket, [1] tail ticket, [SLOTQ_HDR + i] = slot id + 1, or 0 while the slot is out.  Tickets make
+// it a ring: a pop takes entry (head++ mod cap), a push refills entry (tail++ mod cap).  There are exactly as many slots
+// per XCD as waves can be resident there, so a pop finds its entry full except for the instant in which the push that
+// refills it is still in flight (it then spins on that one word).  The tickets wrap at cap by themselves (atomicInc).
+#define SLOTQ_HDR 16
+__device__ __forceinline__ u32 xcc_id() { return (u32)__builtin_amdgcn_s_getreg(6164); }   // hwreg(HW_REG_XCC_ID, 0, 4)
+__global__ void bjj_k_probe_xcc(u32* out) {
+  if (threadIdx.x == 0) atomicMax(out, xcc_id() + 1u);
+}
+__device__ __forceinline__ u32 slot_pop(u32* q, u32 cap, int lane) {
+  u32 v = 0;
+  if (lane == 0) {
+    const u32 t = atomicInc(&q[0], cap - 1u);            // ticket in [0, cap): wraps by itself
+    do { v = atomicExch(&q[SLOTQ_HDR + t], 0u); } while (v == 0u);
+  }
+  return (u32)__builtin_amdgcn_readfirstlane((int)v) - 1u;
+}
+__device__ __forceinline__ void slot_push(u32* q, u32 cap, u32 slot, int lane) {
+  if (lane == 0) {
+    const u32 t = atomicInc(&q[1], cap - 1u);
+    while (atomicCAS(&q[SLOTQ_HDR + t], 0u, slot + 1u) != 0u) {}
+  }

@@ -25,7 +25,23 @@
 // [8..] exact item indices.
 // ---------------------------------------------------------------------------
 #define WL_HDR 8
-__global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_eddsa_verify_scan(const uint8_t* __restrict__ pk,
+// How the main kernel's work is handed out (A/B knob):
+//   0  persistent waves: the grid is one resident set, waves pull 64-item groups through atomic cursors (rounds 1-2);
+//   1  one group per 64-lane workgroup: the grid is (exact-list groups) + (batch chunks), the hardware's workgroup dispatcher
+//      does the scheduling, and a per-XCD queue hands every running workgroup a slot of the per-lane table scratch.
+// With persistent waves two launches that overlap (two streams, two scratch sets) split the chip half and half for their
+// whole life and each pays its own partly empty last round (profiles/r03_ab_inkernel_scan_rejected.txt); workgroups that
+// retire after one group give every freed slot to whichever launch has work pending, which is what makes the pair
+// work-conserving.  The exact-list groups have the lowest block indices, so they are still dispatched first.
+#ifndef BJJ_VERIFY_DISPATCH
+#define BJJ_VERIFY_DISPATCH 1
+#endif
+}
+// 64-lane workgroups: one light wave (73 VGPRs) fits into any slot a retiring wave of the main kernel frees.
+#ifndef BJJ_SCAN_BLOCK
+#define BJJ_SCAN_BLOCK 64
+#endif
+__global__ void __launch_bounds__(BJJ_SCAN_BLOCK) bjj_k_eddsa_verify_scan(const uint8_t* __restrict__ pk,
                                                                      const uint8_t* __restrict__ rb8,
                                                                      const uint8_t* __restrict__ msg, size_t n,
                                                                      u32* __restrict__ wl) {
@@ -99,23 +115,95 @@ __global__ void __launch_bounds__(BJJ_VERIFY_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k
   verify_kernel_body<false>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
 }
 
+// ---- dispatch mode 1: one 64-item group per workgroup --------------------------------------------------------------
+template <bool SCHNORR>
+__device__ __forceinline__ void verify_group_body(const u32* __restrict__ table, int W, int nwin,
+                                                  const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
+                                                  const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg, size_t n,
+                                                  uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
+                                                  const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap) {
+  static_assert(BJJ_VERIFY_DISPATCH == 0 || BJJ_VERIFY_BLOCK == 64, "one group per workgroup needs 64-lane workgroups");
+  __shared__ __attribute__((aligned(16))) u32 stage[FB_STAGE_WORDS];
+  const int lane = threadIdx.x & 63;
+  const size_t nchunks = (n + 63) / 64, b = blockIdx.x;
+  const bool exact = b < nchunks;                            // block indices [0, nchunks): groups of the exact list
+  const unsigned long long nexact = wl[0];
+  if (exact && b * 64 >= nexact) return;                     // wave-uniform: nothing on the list for this block
+  u32* q = slotq + (size_t)xcc_id() * (SLOTQ_HDR + cap);
+  const u32 slot = slot_pop(q, cap, lane);
+  u32* tbl = vb_tables + ((size_t)slot * 64 + lane) * VB_VERIFY_WORDS;
+  if (exact) {
+    const size_t c = b * 64;
+    if (c + lane < nexact) {
+      const size_t i = wl[WL_HDR + c + lane];
+      VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
+      ok[i] = (uint8_t)verify_exact_t<SCHNORR>(in, table, W, nwin, tbl, c_K);
+    }
+  } else {
+    const GatherCoopLds<1> fb = {table, stage, lane};
+    const size_t i = (b - nchunks) * 64 + lane, ic = i < n ? i : n - 1;   // every lane runs (cooperative gathers)
+    VerifyIn in = {pk + ic * 64, rb8 + ic * 64, s + ic * 32, msg + ic * 32};
+    bool need_exact;
+    const int v = verify_fast_t<SCHNORR>(in, fb, W, nwin, tbl, c_K, need_exact);
+    if (i < n && !need_exact) ok[i] = (uint8_t)v;
+  }
+  slot_push(q, cap, slot, lane);
+}
+__global__ void __launch_bounds__(64, BJJ_VERIFY_MIN_BLOCKS) bjj_k_schnorr_verify_groups(const u32* __restrict__ table, int W, int nwin,
+    const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8, const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg,
+    size_t n, uint8_t* __restrict__ ok, u32* __restrict__ vb_tables, const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap) {
+  verify_group_body<true>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, cap);
+}
+__global__ void __launch_bounds__(64, BJJ_VERIFY_MIN_BLOCKS) bjj_k_eddsa_verify_groups(const u32* __restrict__ table, int W, int nwin,
+    const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8, const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg,
+    size_t n, uint8_t* __restrict__ ok, u32* __restrict__ vb_tables, const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap) {
+  verify_group_body<false>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, cap);
+}
+
 namespace bjjk {
+int verify_dispatch_mode() { return BJJ_VERIFY_DISPATCH; }
+int probe_xccs(hipStream_t st, u32* d_word) {   // number of XCDs = highest XCC_ID seen by a few thousand workgroups + 1
+  if (hipMemsetAsync(d_word, 0, sizeof(u32), st) != hipSuccess) return 0;
+  hipLaunchKernelGGL(bjj_k_probe_xcc, dim3(4096), dim3(64), 0, st, d_word);
+  u32 h = 0;
+  if (hipMemcpyAsync(&h, d_word, sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
+  return (int)h;
+}
 int occ_verify() {   // resident workgroups per CU; one grid size (and one per-lane table allocation) serves both kernels
+#if BJJ_VERIFY_DISPATCH == 1
+  const int a = occupancy_of(bjj_k_eddsa_verify_groups, 64), b = occupancy_of(bjj_k_schnorr_verify_groups, 64);
+#else
   const int a = occupancy_of(bjj_k_eddsa_verify, BJJ_VERIFY_BLOCK), b = occupancy_of(bjj_k_schnorr_verify, BJJ_VERIFY_BLOCK);
+#endif
   return a < b ? a : b;
 }
-int occ_verify_scan() { return occupancy_of(bjj_k_eddsa_verify_scan, BJJ_BLOCK); }
-hipError_t verify(hipStream_t st, int grid_scan, int grid, bool schnorr, const u32* table, int W, int nwin, const uint8_t* pk,
-                  const uint8_t* rb8, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok, u32* vb_tables, u32* wl) {
+int occ_verify_scan() { return occupancy_of(bjj_k_eddsa_verify_scan, BJJ_SCAN_BLOCK) * BJJ_SCAN_BLOCK / 64; }   // resident scan WAVES per CU
+int verify_scan_block() { return BJJ_SCAN_BLOCK; }
+// The on-curve scan (memset of the list header + scan kernel) and the main kernel are launched separately so that the host
+// side can route the scan through a high-priority stream (bjj_hip.hip: verify_launch).
+hipError_t verify_scan(hipStream_t st, int grid_scan, const uint8_t* pk, const uint8_t* rb8, const uint8_t* msg, size_t n, u32* wl) {
   hipError_t e = hipMemsetAsync(wl, 0, WL_HDR * sizeof(u32), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_scan), dim3(BJJ_BLOCK), 0, st, pk, rb8, msg, n, wl);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_scan), dim3(BJJ_SCAN_BLOCK), 0, st, pk, rb8, msg, n, wl);
+  return hipGetLastError();
+}
+hipError_t verify_main(hipStream_t st, int grid, bool schnorr, const u32* table, int W, int nwin, const uint8_t* pk,
+                       const uint8_t* rb8, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok, u32* vb_tables, u32* wl,
+                       u32* slotq, u32 slot_cap) {
+#if BJJ_VERIFY_DISPATCH == 1
+  (void)grid;
+  const unsigned groups = (unsigned)(2 * ((n + 63) / 64));   // [0, n/64): exact-list groups (most exit at once), then the batch chunks
+  if (schnorr)
+    hipLaunchKernelGGL(bjj_k_schnorr_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap);
+  else
+    hipLaunchKernelGGL(bjj_k_eddsa_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap);
+#else
+  (void)slotq; (void)slot_cap;
   if (schnorr)
     hipLaunchKernelGGL(bjj_k_schnorr_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
   else
     hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+#endif
   return hipGetLastError();
 }
 }  // namespace bjjk
