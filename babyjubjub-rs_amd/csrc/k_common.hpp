@@ -187,3 +187,4 @@ __device__ __forceinline__ void slot_push(u32* q, u32 cap, u32 slot, int lane) {
     const u32 t = atomicInc(&q[1], cap - 1u);
     while (atomicCAS(&q[SLOTQ_HDR + t], 0u, slot + 1u) != 0u) {}
   }
+}

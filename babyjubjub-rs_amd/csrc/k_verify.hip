@@ -36,7 +36,6 @@
 #ifndef BJJ_VERIFY_DISPATCH
 #define BJJ_VERIFY_DISPATCH 1
 #endif
-}
 // 64-lane workgroups: one light wave (73 VGPRs) fits into any slot a retiring wave of the main kernel frees.
 #ifndef BJJ_SCAN_BLOCK
 #define BJJ_SCAN_BLOCK 64
