@@ -171,9 +171,6 @@ struct GatherCoopLds {
 // refills it is still in flight (it then spins on that one word).  The tickets wrap at cap by themselves (atomicInc).
 #define SLOTQ_HDR 16
 __device__ __forceinline__ u32 xcc_id() { return (u32)__builtin_amdgcn_s_getreg(6164); }   // hwreg(HW_REG_XCC_ID, 0, 4)
-__global__ void bjj_k_probe_xcc(u32* out) {
-  if (threadIdx.x == 0) atomicMax(out, xcc_id() + 1u);
-}
 __device__ __forceinline__ u32 slot_pop(u32* q, u32 cap, int lane) {
   u32 v = 0;
   if (lane == 0) {

@@ -114,6 +114,9 @@ __global__ void __launch_bounds__(BJJ_VERIFY_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k
   verify_kernel_body<false>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
 }
 
+__global__ void bjj_k_probe_xcc(u32* out) {
+  if (threadIdx.x == 0) atomicMax(out, xcc_id() + 1u);
+}
 // ---- dispatch mode 1: one 64-item group per workgroup --------------------------------------------------------------
 template <bool SCHNORR>
 __device__ __forceinline__ void verify_group_body(const u32* __restrict__ table, int W, int nwin,
