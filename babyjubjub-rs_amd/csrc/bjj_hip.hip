@@ -116,6 +116,8 @@ struct bjj_ctx {
   // of workgroups, items are grid-strided.  K1 / K2: resident LANES per CU (their workgroup size is the kernel unit's
   // business); the others: resident 256-lane workgroups per CU
   int lanes_fixed = 512, lanes_var = 512;
+  int lanes_fixed_2x256 = 512;   // resident lanes per CU of K1's two-workgroup shape
+  int k1_variant = -1;           // -1 = per call (two-workgroup shape while another launch of the context is in flight), 0 / 1 = forced (BJJ_K1_VARIANT)
   int occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
   int xccs = 1;                // XCDs of the device (probed at init; sizes the verify kernels' slot queues)
   int occ_decomp = 1, occ_sign = 1, occ_sign_schnorr = 1;
@@ -170,6 +172,19 @@ static int set_leave(bjj_ctx* c, ScratchSet* S, hipStream_t st) {
   S->have_last = true;
   S->last_use = ++c->use_counter;
   return BJJ_OK;
+}
+// Is a launch of this context that uses ANOTHER scratch set still queued or running?  (event query: no synchronisation)
+static bool other_launch_in_flight(bjj_ctx* c, const ScratchSet* mine) {
+  for (const ScratchSet& S : c->set)
+    if (&S != mine && S.have_last && hipEventQuery(S.ev_last) == hipErrorNotReady) return true;
+  (void)hipGetLastError();   // hipErrorNotReady is not an error
+  return false;
+}
+// K1 comes in two shapes (k_fixed.hip): one 512-lane workgroup per CU, or two of 256 lanes.  The second is for overlapping
+// launches: each launch then occupies one workgroup slot per CU and the other launch's main loop covers its inversion.
+static int fixed_base_variant(bjj_ctx* c, const ScratchSet* S) {
+  if (c->k1_variant >= 0) return c->k1_variant;
+  return other_launch_in_flight(c, S) ? 1 : 0;
 }
 // completion mark of a call that used no scratch (bjj_sync waits for these)
 static int mark_stream(bjj_ctx* c, hipStream_t st) {
@@ -413,7 +428,11 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   }
   c->W = W;
   c->nwin = fixed_nwin(W);
-  c->lanes_fixed = bjjk::fixed_base_lanes_per_cu();
+  c->lanes_fixed = bjjk::fixed_base_lanes_per_cu(0);
+  c->lanes_fixed_2x256 = bjjk::fixed_base_lanes_per_cu(1);
+  if (const char* e = getenv("BJJ_K1_VARIANT")) {   // tests / A-B: force one shape of the fixed-base kernel
+    if (e[0] == '0' || e[0] == '1') c->k1_variant = e[0] - '0';
+  }
   c->lanes_var = bjjk::var_base_lanes_per_cu();
   c->occ_poseidon = bjjk::occ_poseidon5();
   c->occ_verify = bjjk::occ_verify();
@@ -566,7 +585,8 @@ int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_
   CHECK_N(n);
   CHECK_PTR(d_scalars, "bjj_mul_fixed_base_dev"); CHECK_PTR(d_out, "bjj_mul_fixed_base_dev");
   SET_ENTER(c, stream, n, false);
-  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->lanes_fixed, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
+  const int kv = fixed_base_variant(c, S);
+  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, kv ? c->lanes_fixed_2x256 : c->lanes_fixed, kv, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
                                 (uint8_t*)d_out, S->scratch), "bjj_mul_fixed_base_dev");
   SET_LEAVE(c);
 }
@@ -610,12 +630,16 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
     HIPCK(hipEventCreateWithFlags(&S->ev_scan_in, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&S->ev_scan_out, hipEventDisableTiming));
   }
-  const int scan_grid = grid_for(c, n, c->occ_scan, 64);   // occ_scan counts waves; the scan kernel's block is a launcher detail
-  HIPCK(hipEventRecord(S->ev_scan_in, st));
-  HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));
-  LAUNCHCK(bjjk::verify_scan(S->scan_stream, scan_grid * 64 / bjjk::verify_scan_block(), pk, r, msg, n, S->slow), "verify scan");
-  HIPCK(hipEventRecord(S->ev_scan_out, S->scan_stream));
-  HIPCK(hipStreamWaitEvent(st, S->ev_scan_out, 0));
+  const int scan_grid = grid_for(c, n, c->occ_scan, 64) * 64 / bjjk::verify_scan_block();   // occ_scan counts waves
+  if (other_launch_in_flight(c, S)) {   // the chip is (about to be) full of another launch's workgroups: priority stream
+    HIPCK(hipEventRecord(S->ev_scan_in, st));
+    HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));
+    LAUNCHCK(bjjk::verify_scan(S->scan_stream, scan_grid, pk, r, msg, n, S->slow), "verify scan");
+    HIPCK(hipEventRecord(S->ev_scan_out, S->scan_stream));
+    HIPCK(hipStreamWaitEvent(st, S->ev_scan_out, 0));
+  } else {                              // nothing to compete with: in line, no event hops
+    LAUNCHCK(bjjk::verify_scan(st, scan_grid, pk, r, msg, n, S->slow), "verify scan");
+  }
   LAUNCHCK(bjjk::verify_main(st, grid_for(c, n, c->occ_verify, BJJ_VERIFY_BLOCK), schnorr, c->table, c->W, c->nwin, pk, r, s, msg, n, ok,
                              S->vb_tables, S->slow, S->slotq, S->slot_cap), "verify");
   return BJJ_OK;
@@ -729,7 +753,8 @@ int bjj_public_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy
   // B8.mul_scalar(&self.scalar_key()), src/lib.rs:304-306; the scalar keys live in the codec scratch only for the
   // duration of the multiplication and are wiped on the same stream right behind it
   LAUNCHCK(bjjk::scalar_keys(st, grid_for(c, n, 4), (const uint8_t*)d_keys, n, S->codec), "scalar_keys");
-  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, c->lanes_fixed, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy,
+  const int kv = fixed_base_variant(c, S);
+  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, kv ? c->lanes_fixed_2x256 : c->lanes_fixed, kv, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy,
                                 S->scratch), "mul_fixed_base");
   HIPCK(hipMemsetAsync(S->codec, 0, n * 32, st));
   SET_LEAVE(c);

@@ -27,7 +27,7 @@ static inline int occupancy_of(K kernel, int block) {
 }
 
 // resident workgroups per CU -- resident LANES per CU for K1 / K2 (queried on the current device)
-int fixed_base_lanes_per_cu();
+int fixed_base_lanes_per_cu(int variant);   // variant 0: one 512-lane workgroup per CU, 1: two 256-lane workgroups
 int var_base_lanes_per_cu();
 int occ_point_add();
 int occ_poseidon5();
@@ -44,8 +44,8 @@ int occ_sign_schnorr();
 hipError_t build_fixed_table(hipStream_t st, uint32_t* table, uint32_t* bases, int W, int nwin);
 hipError_t check_fixed_table(hipStream_t st, int grid, const uint32_t* table, const uint32_t* bases, int W, int nwin,
                              unsigned long long* d_bad);
-hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, const uint32_t* table, int W, int nwin, const uint8_t* scalars, size_t n,
-                          uint8_t* out, uint32_t* scratch);
+hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant, const uint32_t* table, int W, int nwin,
+                          const uint8_t* scalars, size_t n, uint8_t* out, uint32_t* scratch);
 // k_var.hip (sc_words: 32-bit words per scalar record, 8 for the 32-byte form)
 hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
                         uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow);

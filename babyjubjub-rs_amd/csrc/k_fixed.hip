@@ -48,15 +48,15 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_check_fixed_table(const u32* 
 }
 
 
-__global__ void __launch_bounds__(BJJ_K1_BLOCK, BJJ_K1_MIN_BLOCKS) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
-                                                                  const uint8_t* __restrict__ scalars, size_t n,
-                                                                  uint8_t* __restrict__ out, u32* __restrict__ scratch) {
+template <int BLOCK, int NBUF>
+__device__ __forceinline__ void mul_fixed_base_body(const u32* __restrict__ table, int W, int nwin, const uint8_t* __restrict__ scalars,
+                                                    size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch) {
   __shared__ u32 lds[NL * 64];
-  __shared__ __attribute__((aligned(16))) u32 stage[(BJJ_K1_BLOCK / 64) * BJJ_K1_NBUF * FB_STAGE_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 stage[(BLOCK / 64) * NBUF * FB_STAGE_WORDS];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   const int lane = threadIdx.x & 63;
-  const GatherCoopLds<BJJ_K1_NBUF> fb = {table, stage + (threadIdx.x >> 6) * BJJ_K1_NBUF * FB_STAGE_WORDS, lane};
+  const GatherCoopLds<NBUF> fb = {table, stage + (threadIdx.x >> 6) * NBUF * FB_STAGE_WORDS, lane};
   Fr run = fr_one();
 #pragma unroll 1
   for (size_t i = tid; i - lane < n; i += nthreads) {  // wave-uniform trip count: the gathers are cooperative
@@ -66,12 +66,33 @@ __global__ void __launch_bounds__(BJJ_K1_BLOCK, BJJ_K1_MIN_BLOCKS) bjj_k_mul_fix
     Ext p = fixed_base_mul(fb, W, nwin, sc, c_K);
     if (valid) epilogue_stash(p, run, out + i * 64, scratch + i * 16);
   }
-  epilogue_run<BJJ_K1_BLOCK>(run, n, tid, nthreads, out, scratch, lds);
+  epilogue_run<BLOCK>(run, n, tid, nthreads, out, scratch, lds);
+}
+// Two shapes of the same kernel:
+//  * bjj_k_mul_fixed_base: ONE workgroup of BJJ_K1_BLOCK = 512 lanes per CU (2 waves per SIMD, two staging areas per wave,
+//    150 KB of LDS): one workgroup-wide inversion per CU and launch.  Best when launches run one after the other.
+//  * bjj_k_mul_fixed_base_2x256: TWO workgroups of 256 lanes per CU (the same 2 waves per SIMD).  Alone it is ~2 % slower (two
+//    inversions per CU); but a launch only ever needs ONE of the two workgroup slots of a CU, so when a second launch of
+//    the context is in flight (another stream, the other scratch set) the hardware gives each launch one slot per CU, the
+//    two run half a period out of phase, and one launch's serial section -- the inversion by one wave while the other waves of
+//    its workgroup wait, then the epilogue -- is covered by the other launch's main loop: 1.84 vs 1.75 G mults/s on two streams
+//    (profiles/r03_ab_k1_2x256_two_streams.txt).  The host picks the shape per call (bjj_hip.hip: fixed_base_variant).
+__global__ void __launch_bounds__(BJJ_K1_BLOCK, BJJ_K1_MIN_BLOCKS) bjj_k_mul_fixed_base(const u32* __restrict__ table, int W, int nwin,
+                                                                  const uint8_t* __restrict__ scalars, size_t n,
+                                                                  uint8_t* __restrict__ out, u32* __restrict__ scratch) {
+  mul_fixed_base_body<BJJ_K1_BLOCK, BJJ_K1_NBUF>(table, W, nwin, scalars, n, out, scratch);
+}
+__global__ void __launch_bounds__(256, 2) bjj_k_mul_fixed_base_2x256(const u32* __restrict__ table, int W, int nwin,
+                                                                    const uint8_t* __restrict__ scalars, size_t n,
+                                                                    uint8_t* __restrict__ out, u32* __restrict__ scratch) {
+  mul_fixed_base_body<256, 2>(table, W, nwin, scalars, n, out, scratch);
 }
 
 // ---- launchers (declared in bjj_launch.hpp) ------------------------------------------------------------
 namespace bjjk {
-int fixed_base_lanes_per_cu() { return occupancy_of(bjj_k_mul_fixed_base, BJJ_K1_BLOCK) * BJJ_K1_BLOCK; }
+int fixed_base_lanes_per_cu(int variant) {
+  return variant ? occupancy_of(bjj_k_mul_fixed_base_2x256, 256) * 256 : occupancy_of(bjj_k_mul_fixed_base, BJJ_K1_BLOCK) * BJJ_K1_BLOCK;
+}
 hipError_t build_fixed_table(hipStream_t st, u32* table, u32* bases, int W, int nwin) {
   const size_t entries = fixed_stride(W) * (size_t)nwin;
   // chain length: long enough to amortise the start ladder and the inversion, short enough to fill the GPU
@@ -88,11 +109,15 @@ hipError_t check_fixed_table(hipStream_t st, int grid, const u32* table, const u
   hipLaunchKernelGGL(bjj_k_check_fixed_table, dim3((unsigned)grid), dim3(BJJ_BLOCK), 0, st, table, bases, W, nwin, d_bad);
   return hipGetLastError();
 }
-hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, const u32* table, int W, int nwin, const uint8_t* scalars, size_t n,
-                          uint8_t* out, u32* scratch) {
-  const size_t want = (n + BJJ_K1_BLOCK - 1) / BJJ_K1_BLOCK, cap = (size_t)cus * (size_t)(lanes_per_cu / BJJ_K1_BLOCK);
+hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant, const u32* table, int W, int nwin, const uint8_t* scalars,
+                          size_t n, uint8_t* out, u32* scratch) {
+  const int block = variant ? 256 : BJJ_K1_BLOCK;
+  const size_t want = (n + block - 1) / block, cap = (size_t)cus * (size_t)(lanes_per_cu / block);
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  hipLaunchKernelGGL(bjj_k_mul_fixed_base, dim3(grid), dim3(BJJ_K1_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
+  if (variant)
+    hipLaunchKernelGGL(bjj_k_mul_fixed_base_2x256, dim3(grid), dim3(256), 0, st, table, W, nwin, scalars, n, out, scratch);
+  else
+    hipLaunchKernelGGL(bjj_k_mul_fixed_base, dim3(grid), dim3(BJJ_K1_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
   return hipGetLastError();
 }
 }  // namespace bjjk

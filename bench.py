@@ -62,10 +62,12 @@ KERNEL = {"fixed_base": "bjj_k_mul_fixed_base", "var_base": "bjj_k_mul_var_base"
           "poseidon5": "bjj_k_poseidon5", "verify_compressed": "bjj_k_eddsa_verify", "decompress": "bjj_k_decompress_points",
           "sign": "bjj_k_sign", "point_add": "bjj_k_point_add", "compress": "bjj_k_compress_points"}
 # Streams the timed loop alternates over by default.  The context keeps one scratch set per stream (two sets), so with two
-# streams the head of launch k+1 fills the partly empty last wave-round of launch k: worth it for the kernels whose 2^20-item
-# launch is a non-integral number of rounds (verify 8.1, variable-base 5.3).  K1 is exactly 8 items per resident lane and one
-# workgroup per CU (150 KB of LDS): nothing to overlap, the headline stays on one stream with per-launch HIP events.
-DEFAULT_STREAMS = {"verify": 2, "var_base": 2, "verify_compressed": 2}
+# streams consecutive launches overlap: the head of launch k+1 fills the partly empty last wave-round of launch k (verify is
+# 8.1 rounds of the resident waves, variable base 5.3), and for K1 the library switches to its two-workgroups-per-CU shape,
+# in which one launch's serial section (the workgroup-wide inversion, the epilogue) is covered by the other launch's main loop.
+# `value` is the rate of the K timed launches under that protocol; `roofline` / `valu` keep describing ONE launch on one stream
+# (per-launch HIP events; what the rocprofv3 summaries under profiles/ profile), and `single_stream` carries its rate.
+DEFAULT_STREAMS = {"fixed_base": 2, "verify": 2, "var_base": 2, "verify_compressed": 2}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 T8 = (4342719913949491028786768530115087822524712248835451589697801404893164183326,
       4826523245007015323400664741523384119579596407052839571721035538011798951543)  # a point of order 8 (SURVEY.md 8d cfg 3)
@@ -489,13 +491,16 @@ def measure(ctx, kind, n, offset, dev, stream, steps, warmup, warm_s, world, nb,
         extra["per_launch_event_ms"] = step_stats(wl.step_ms, n, world)
     if stream2 is not None:
         dt1, k1 = dt, kernel_ms
-        dt, kernel_ms = timed_steps(wl, steps, 2, world, 0.2, streams=[stream, stream2])
-        extra = {"streams": 2,
+        dt, km2 = timed_steps(wl, steps, 2, world, 0.2, streams=[stream, stream2])
+        # kernel_ms stays the ONE-launch time (per-launch HIP events on one stream): roofline / valu describe a launch, and the
+        # rocprofv3 summaries profile exactly that; the overlapped protocol's device time per launch is reported next to it
+        extra = {"streams": 2, "device_ms_per_launch": km2,
                  "single_stream": {"wall_s": dt1, "kernel_ms_avg": k1, "value_this_rank": n * steps / dt1,
                                    "per_launch_event_ms": extra.get("per_launch_event_ms")},
                  "streams_note": "timed launches alternate over two HIP streams; the context keeps one scratch set per stream, "
-                                 "so consecutive launches overlap at their tails.  kernel_ms_avg = (first start .. last end over "
-                                 "both streams, HIP events) / steps; single_stream = the same K launches back to back on one stream"}
+                                 "so consecutive launches overlap.  device_ms_per_launch = (first start .. last end over both "
+                                 "streams, HIP events) / steps; single_stream = the same K launches back to back on one stream, "
+                                 "which is also what roofline.kernel_ms_avg and valu are computed from"}
     if len(wl.batches) > 1 and rank == 0:  # Infinity-Cache control: the same protocol on ONE repeated batch
         one = Workload.__new__(Workload)
         one.__dict__.update(wl.__dict__)

@@ -61,7 +61,10 @@ def test_bench_one_gpu_line_has_every_block():
     assert r.returncode == 0, r.stderr[-3000:]
     assert j["n_gpus"] == 1 and j["parity_sample_ok"] and j["roofline"]["frac"] > 0 and j["cpu_baseline"]["value"] > 0
     assert j["rotating_batches"] == 4 and j["single_batch_kernel_ms"] > 0
-    assert j["streams"] == 1 and j["per_launch_event_ms"]["median_ms"] > 0 and j["per_launch_event_ms"]["value_from_median"] > 0
+    # headline: two-stream protocol, the one-stream control (per-launch HIP events, median) next to it; roofline describes ONE launch
+    assert j["streams"] == 2 and j["device_ms_per_launch"] > 0
+    assert j["single_stream"]["per_launch_event_ms"]["median_ms"] > 0 and j["single_stream"]["per_launch_event_ms"]["value_from_median"] > 0
+    assert abs(j["roofline"]["kernel_ms_avg"] - j["single_stream"]["kernel_ms_avg"]) < 1e-9
     for k in ("verify", "var_base"):
         assert j["also"][k]["roofline"]["kernel_ms_avg"] > 0 and j["also"][k]["cpu_baseline"]["cores"] >= 1
         # two-stream protocol for the kernels whose launch is a non-integral number of rounds, one-stream control next to it

@@ -184,7 +184,8 @@ def test_overlapping_launches_on_two_and_three_streams_use_separate_scratch_sets
             sc = w.scalars_254(n, offset=17 + b * n)
             batches.append(dict(A=A, sc=sc, bad=bad, d=[up(A), up(R), up(S), up(msg)], d_sc=up(sc),
                                 d_ok=torch.zeros(n, dtype=torch.uint8, device=dev),
-                                d_out=torch.zeros(n * 64, dtype=torch.uint8, device=dev)))
+                                d_out=torch.zeros(n * 64, dtype=torch.uint8, device=dev),
+                                d_fb=torch.zeros(n * 64, dtype=torch.uint8, device=dev)))
         streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
         torch.cuda.synchronize()
         before = ctx.info().scratch_bytes
@@ -197,6 +198,7 @@ def test_overlapping_launches_on_two_and_three_streams_use_separate_scratch_sets
                     B, st = batches[b], streams[b].cuda_stream
                     ctx.eddsa_verify_dev(*[t.data_ptr() for t in B["d"]], n, B["d_ok"].data_ptr(), st)
                     ctx.mul_var_base_dev(B["d"][0].data_ptr(), B["d_sc"].data_ptr(), n, B["d_out"].data_ptr(), st)
+                    ctx.mul_fixed_base_dev(B["d_sc"].data_ptr(), n, B["d_fb"].data_ptr(), st)   # picks its shape per call
             ctx.sync()                                       # waits for every caller stream the context has work on
             for b in range(ns):
                 B = batches[b]
@@ -204,6 +206,7 @@ def test_overlapping_launches_on_two_and_three_streams_use_separate_scratch_sets
                 idx = np.arange(b, n, 257)
                 got = B["d_out"].cpu().numpy().reshape(n, 64)[idx]
                 assert (got == oracle.mul_var_base(B["A"][idx], B["sc"][idx])).all(), (ns, b)
+                assert (B["d_fb"].cpu().numpy().reshape(n, 64)[idx] == oracle.mul_fixed_base(B["sc"][idx])).all(), (ns, b)
         assert ctx.info().scratch_bytes > before            # the second set came into being with the second stream
         # a single-stream caller never leaves set 0: a fresh context's footprint does not depend on this feature
         c1 = bjj.Context(0, 16)

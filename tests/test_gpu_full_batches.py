@@ -42,6 +42,35 @@ def test_cfg2_fixed_base_1m_every_item(ctx_for_window, oracle):
     assert _mismatches(got, _oracle_once("cfg2", lambda: oracle.mul_fixed_base(sc))) == (0, [])
 
 
+def test_cfg2_fixed_base_two_workgroup_shape_every_item(oracle, monkeypatch):
+    """K1 has two shapes (k_fixed.hip): one 512-lane workgroup per CU, and two 256-lane workgroups per CU, which the library
+    picks per call while another launch of the context is in flight.  BJJ_K1_VARIANT=1 forces the second shape for a context:
+    all 2^20 outputs against the oracle, and -- same context, two streams, different batches -- the overlapping case."""
+    import torch
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    monkeypatch.setenv("BJJ_K1_VARIANT", "1")
+    ctx = bjj.Context(0, 23)
+    monkeypatch.delenv("BJJ_K1_VARIANT")
+    try:
+        sc = w.scalars_254(N)
+        want = _oracle_once("cfg2", lambda: oracle.mul_fixed_base(sc))
+        assert _mismatches(ctx.mul_fixed_base(sc), want) == (0, [])
+        dev = torch.device("cuda", 0)
+        d_sc = [torch.from_numpy(sc.reshape(-1)).to(dev), torch.from_numpy(sc[::-1].copy().reshape(-1)).to(dev)]
+        d_out = [torch.zeros(N * 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        for rnd in range(6):
+            for b in range(2):
+                ctx.mul_fixed_base_dev(d_sc[b].data_ptr(), N, d_out[b].data_ptr(), streams[b].cuda_stream)
+        ctx.sync()
+        assert _mismatches(d_out[0].cpu().numpy().reshape(N, 64), want) == (0, [])
+        assert _mismatches(d_out[1].cpu().numpy().reshape(N, 64), want[::-1]) == (0, [])
+    finally:
+        ctx.close()
+
+
 def cfg3_points(gpu_ctx, pyoracle, n, offset=0):
     """SURVEY.md 8d cfg 3: P_i = k_i*B8 + c_i*T (k_i < l, c_i in 0..7, T of order 8: the full group), every 97th point
     pushed off the curve."""

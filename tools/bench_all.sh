@@ -10,6 +10,6 @@ for line in sys.stdin:
     d=json.loads(line)
     one=d.get('single_stream')
     extra=('   [1 stream: %9.3f ms, %8.2f M/s]' % (one['kernel_ms_avg'], one['value_this_rank']/1e6)) if one else ''
-    print('%-11s %10.2f M/s  %9.3f ms/step  device %9.3f ms/launch (%d stream%s)  parity %s%s' % ('$WL', d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms_avg'], d.get('streams',1), 's' if d.get('streams',1)>1 else '', d['parity_sample_ok'], extra))
+    print('%-11s %10.2f M/s  %9.3f ms/step  device %9.3f ms/launch (%d stream%s)  parity %s%s' % ('$WL', d['value']/1e6, d['ms_per_step'], d.get('device_ms_per_launch', d['roofline']['kernel_ms_avg']), d.get('streams',1), 's' if d.get('streams',1)>1 else '', d['parity_sample_ok'], extra))
 "
 done
