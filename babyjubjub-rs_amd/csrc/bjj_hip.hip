@@ -89,6 +89,8 @@ struct ScratchSet {
   // launch's pending workgroups for a whole launch (profiles/r03_ab_verify_group_dispatch.txt)
   hipStream_t scan_stream = nullptr;
   hipEvent_t ev_scan_in = nullptr, ev_scan_out = nullptr;
+  u32* slotq2 = nullptr;       // variable base, one tile per workgroup: the same per-XCD rings, one slot = one workgroup's tables
+  u32 slot_cap2 = 0;
   u32* slotq = nullptr;        // verify, one group per workgroup: per-XCD ring of free per-lane-table slots (k_verify.hip)
   u32 slot_cap = 0;            // slots per XCD
   uint8_t* codec = nullptr;    // verify_compressed: n * (64 pk + 64 R + 32 s + 2 flags) bytes; public_keys: the scalar keys
@@ -218,8 +220,20 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
   // up to a whole number per XCD (the slot queues are per XCD)
   const size_t cu_per_xcc = ((size_t)c->cus + c->xccs - 1) / c->xccs;
   const u32 cap = (u32)(cu_per_xcc * c->occ_verify * (BJJ_VERIFY_BLOCK / 64));
-  size_t tv = (size_t)c->cus * c->lanes_var, te = (size_t)c->xccs * cap * 64 * 2;
+  size_t tv = cu_per_xcc * c->xccs * (size_t)c->lanes_var, te = (size_t)c->xccs * cap * 64 * 2;
   size_t threads = tv > te ? tv : te;
+  const u32 cap2 = (u32)(cu_per_xcc * (size_t)(c->lanes_var / bjjk::var_base_block()));
+  if (!S->slotq2 || S->slot_cap2 != cap2) {
+    if (S->slotq2) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->slotq2)); S->slotq2 = nullptr; }
+    const size_t stride = 16 + cap2;
+    std::vector<u32> h((size_t)c->xccs * stride, 0u);
+    for (int x = 0; x < c->xccs; x++)
+      for (u32 i = 0; i < cap2; i++) h[(size_t)x * stride + 16 + i] = (u32)x * cap2 + i + 1u;
+    HIPCK(hipMalloc((void**)&S->slotq2, h.size() * sizeof(u32)));
+    HIPCK(hipMemcpy(S->slotq2, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice));
+    HIPCK(hipStreamSynchronize(nullptr));
+    S->slot_cap2 = cap2;
+  }
   if (!S->slotq || S->slot_cap != cap) {
     if (S->slotq) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->slotq)); S->slotq = nullptr; }
     const size_t stride = 16 + cap;
@@ -370,6 +384,7 @@ static void ctx_destroy(bjj_ctx* c) {
     if (S.vb_tables) hipFree(S.vb_tables);
     if (S.slow) hipFree(S.slow);
     if (S.slotq) hipFree(S.slotq);
+    if (S.slotq2) hipFree(S.slotq2);
     if (S.ev_scan_in) hipEventDestroy(S.ev_scan_in);
     if (S.ev_scan_out) hipEventDestroy(S.ev_scan_out);
     if (S.scan_stream) hipStreamDestroy(S.scan_stream);
@@ -601,7 +616,8 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   SET_ENTER(c, stream, n, false);
   LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
-                              (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow), "bjj_mul_var_base_dev");
+                              (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow, S->slotq2, S->slot_cap2),
+           "bjj_mul_var_base_dev");
   SET_LEAVE(c);
 }
 int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* stream) {

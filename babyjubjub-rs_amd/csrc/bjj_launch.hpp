@@ -29,6 +29,7 @@ static inline int occupancy_of(K kernel, int block) {
 // resident workgroups per CU -- resident LANES per CU for K1 / K2 (queried on the current device)
 int fixed_base_lanes_per_cu(int variant);   // variant 0: one 512-lane workgroup per CU, 1: two 256-lane workgroups
 int var_base_lanes_per_cu();
+int var_base_block();
 int occ_point_add();
 int occ_poseidon5();
 int occ_decompress();
@@ -48,7 +49,7 @@ hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant
                           const uint8_t* scalars, size_t n, uint8_t* out, uint32_t* scratch);
 // k_var.hip (sc_words: 32-bit words per scalar record, 8 for the 32-byte form)
 hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
-                        uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow);
+                        uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow, uint32_t* slotq, uint32_t slot_cap);
 hipError_t point_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);
 hipError_t proj_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);
 hipError_t proj_affine(hipStream_t st, int grid, const uint8_t* p, size_t n, uint8_t* out);

@@ -171,17 +171,23 @@ struct GatherCoopLds {
 // refills it is still in flight (it then spins on that one word).  The tickets wrap at cap by themselves (atomicInc).
 #define SLOTQ_HDR 16
 __device__ __forceinline__ u32 xcc_id() { return (u32)__builtin_amdgcn_s_getreg(6164); }   // hwreg(HW_REG_XCC_ID, 0, 4)
+// one thread takes / returns a slot
+__device__ __forceinline__ u32 slot_pop_one(u32* q, u32 cap) {
+  const u32 t = atomicInc(&q[0], cap - 1u);            // ticket in [0, cap): wraps by itself
+  u32 v;
+  do { v = atomicExch(&q[SLOTQ_HDR + t], 0u); } while (v == 0u);
+  return v - 1u;
+}
+__device__ __forceinline__ void slot_push_one(u32* q, u32 cap, u32 slot) {
+  const u32 t = atomicInc(&q[1], cap - 1u);
+  while (atomicCAS(&q[SLOTQ_HDR + t], 0u, slot + 1u) != 0u) {}
+}
+// a WAVE takes / returns a slot (lane 0 does it, every lane gets the number)
 __device__ __forceinline__ u32 slot_pop(u32* q, u32 cap, int lane) {
   u32 v = 0;
-  if (lane == 0) {
-    const u32 t = atomicInc(&q[0], cap - 1u);            // ticket in [0, cap): wraps by itself
-    do { v = atomicExch(&q[SLOTQ_HDR + t], 0u); } while (v == 0u);
-  }
-  return (u32)__builtin_amdgcn_readfirstlane((int)v) - 1u;
+  if (lane == 0) v = slot_pop_one(q, cap);
+  return (u32)__builtin_amdgcn_readfirstlane((int)v);
 }
 __device__ __forceinline__ void slot_push(u32* q, u32 cap, u32 slot, int lane) {
-  if (lane == 0) {
-    const u32 t = atomicInc(&q[1], cap - 1u);
-    while (atomicCAS(&q[SLOTQ_HDR + t], 0u, slot + 1u) != 0u) {}
-  }
+  if (lane == 0) slot_push_one(q, cap, slot);
 }

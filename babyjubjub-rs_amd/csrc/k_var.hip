@@ -17,6 +17,10 @@
 #ifndef BJJ_K2_MIN_BLOCKS
 #define BJJ_K2_MIN_BLOCKS 3
 #endif
+// 0: one resident set of workgroups, items grid-strided (rounds 1-2);  1: one tile of items per workgroup (see below)
+#ifndef BJJ_K2_DISPATCH
+#define BJJ_K2_DISPATCH 1
+#endif
 
 // (n >> 3) mod l of a little-endian integer of nw words, as 8 words -> n mod 8l = 8*that + (n & 7) < 2^254.
 // Horner over 261-bit chunks, most significant first: acc <- acc * 2^261 + chunk (mod l), with the mod-l Montgomery
@@ -44,13 +48,11 @@ __device__ void wide_scalar_mod_order(const u32* __restrict__ w, int nw, u32 out
 // WIDE: scalars are records of `sc_words` 32-bit words (a multiple of 8; `n: &BigInt` is unbounded, src/lib.rs:149,
 // 156-157); for an on-curve point n*P == (n mod 8l)*P exactly.
 // ---------------------------------------------------------------------------
+// The items of one lane are tid, tid + nthreads, ... below n; tbl = this lane's table scratch.
 template <bool WIDE>
 __device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars, int sc_words,
                                               size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch,
-                                              u32* __restrict__ vb_tables, u32* __restrict__ slow, u32* lds) {
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
-  u32* tbl = vb_tables + tid * VB_TABLE_WORDS;
+                                              u32* __restrict__ tbl, u32* __restrict__ slow, u32* lds, size_t tid, size_t nthreads) {
   Fr run = fr_one();
 #pragma unroll 1
   for (size_t i = tid; i < n; i += nthreads) {
@@ -80,14 +82,50 @@ __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var
                                                                 uint8_t* __restrict__ out, u32* __restrict__ scratch,
                                                                 u32* __restrict__ vb_tables, u32* __restrict__ slow) {
   __shared__ u32 lds[NL * 64];
-  var_base_body<false>(pts, scalars, 8, n, out, scratch, vb_tables, slow, lds);
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  var_base_body<false>(pts, scalars, 8, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_wide(const uint8_t* __restrict__ pts,
                                                                      const uint8_t* __restrict__ scalars, int sc_words, size_t n,
                                                                      uint8_t* __restrict__ out, u32* __restrict__ scratch,
                                                                      u32* __restrict__ vb_tables, u32* __restrict__ slow) {
   __shared__ u32 lds[NL * 64];
-  var_base_body<true>(pts, scalars, sc_words, n, out, scratch, vb_tables, slow, lds);
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  var_base_body<true>(pts, scalars, sc_words, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x);
+}
+// ---- dispatch mode 1: one tile of BJJ_K2_BLOCK consecutive items per workgroup ------------------------------------------
+// The grid-strided form above is one resident set of workgroups whose lanes own 5 or 6 items of a 2^20-item batch: the
+// launch costs 6 item-times, and a second launch on another stream can only use what the 5-item workgroups free at the end.
+// Here a workgroup does ONE item per lane (its own workgroup-wide inversion: one wave inverts while the CU's other two
+// workgroups, which are in other phases, keep the SIMDs busy), retires, and the hardware dispatches the next tile -- of
+// this launch or of the other one in flight: the pair is work-conserving.  The per-lane table scratch comes from a
+// per-XCD slot queue (k_common.hpp), one slot = the tables of one workgroup.
+template <bool WIDE>
+__device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars, int sc_words, size_t n,
+                                              uint8_t* __restrict__ out, u32* __restrict__ scratch, u32* __restrict__ vb_tables,
+                                              u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap) {
+  __shared__ u32 lds[NL * 64];
+  __shared__ u32 sh_slot;
+  u32* q = slotq + (size_t)xcc_id() * (SLOTQ_HDR + cap);
+  if (threadIdx.x == 0) sh_slot = slot_pop_one(q, cap);
+  __syncthreads();
+  const u32 slot = sh_slot;
+  const size_t base = (size_t)blockIdx.x * BJJ_K2_BLOCK;
+  const size_t hi = base + BJJ_K2_BLOCK < n ? base + BJJ_K2_BLOCK : n;
+  var_base_body<WIDE>(pts, scalars, sc_words, hi, out, scratch, vb_tables + ((size_t)slot * BJJ_K2_BLOCK + threadIdx.x) * VB_TABLE_WORDS, slow,
+                      lds, base + threadIdx.x, (size_t)BJJ_K2_BLOCK);
+  __syncthreads();
+  if (threadIdx.x == 0) slot_push_one(q, cap, slot);
+}
+__global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_tiles(const uint8_t* __restrict__ pts,
+    const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch, u32* __restrict__ vb_tables,
+    u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap) {
+  var_base_tile<false>(pts, scalars, 8, n, out, scratch, vb_tables, slow, slotq, cap);
+}
+__global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_wide_tiles(const uint8_t* __restrict__ pts,
+    const uint8_t* __restrict__ scalars, int sc_words, size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch,
+    u32* __restrict__ vb_tables, u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap) {
+  var_base_tile<true>(pts, scalars, sc_words, n, out, scratch, vb_tables, slow, slotq, cap);
 }
 // K6: exact replay of the reference's loop for the (rare) off-curve inputs, one per lane; sc_words words per scalar.
 __global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __restrict__ pts,
@@ -165,8 +203,13 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_proj_affine(const uint8_t* __
 }
 
 namespace bjjk {
+int var_base_block() { return BJJ_K2_BLOCK; }
 int var_base_lanes_per_cu() {   // resident lanes of K2 per CU (sizes the per-lane table scratch and the grid)
+#if BJJ_K2_DISPATCH == 1
+  const int a = occupancy_of(bjj_k_mul_var_base_tiles, BJJ_K2_BLOCK), b = occupancy_of(bjj_k_mul_var_base_wide_tiles, BJJ_K2_BLOCK);
+#else
   const int a = occupancy_of(bjj_k_mul_var_base, BJJ_K2_BLOCK), b = occupancy_of(bjj_k_mul_var_base_wide, BJJ_K2_BLOCK);
+#endif
   return (a < b ? a : b) * BJJ_K2_BLOCK;   // one grid size (and one per-lane table allocation) serves both kernels
 }
 int occ_point_add() {
@@ -175,16 +218,27 @@ int occ_point_add() {
   return a < b ? (a < c ? a : c) : (b < c ? b : c);
 }
 hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
-                        uint8_t* out, u32* scratch, u32* vb_tables, u32* slow) {
+                        uint8_t* out, u32* scratch, u32* vb_tables, u32* slow, u32* slotq, u32 slot_cap) {
   hipError_t e = hipMemsetAsync(slow, 0, 8 * sizeof(u32), st);
   if (e != hipSuccess) return e;
   const size_t want = (n + BJJ_K2_BLOCK - 1) / BJJ_K2_BLOCK, cap = (size_t)cus * (size_t)(lanes_per_cu / BJJ_K2_BLOCK);
+#if BJJ_K2_DISPATCH == 1
+  (void)cap;
+  if (sc_words == 8)
+    hipLaunchKernelGGL(bjj_k_mul_var_base_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow,
+                       slotq, slot_cap);
+  else
+    hipLaunchKernelGGL(bjj_k_mul_var_base_wide_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
+                       vb_tables, slow, slotq, slot_cap);
+#else
+  (void)slotq; (void)slot_cap;
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
   if (sc_words == 8)
     hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow);
   else
     hipLaunchKernelGGL(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
                        vb_tables, slow);
+#endif
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(bjj_k_mul_var_base_exact, dim3(grid_exact), dim3(64), 0, st, pts, scalars, sc_words, out, slow);

@@ -69,6 +69,8 @@ def test_bench_one_gpu_line_has_every_block():
         assert j["also"][k]["roofline"]["kernel_ms_avg"] > 0 and j["also"][k]["cpu_baseline"]["cores"] >= 1
         # two-stream protocol for the kernels whose launch is a non-integral number of rounds, one-stream control next to it
         assert j["also"][k]["streams"] == 2 and j["also"][k]["single_stream"]["kernel_ms_avg"] > 0
+    assert j["also"]["fixed_base_window_bits_23"]["parity_sample_ok"]
+    assert j["config"]["init_ms"] > 0 and j["config"]["table_bytes"] > 0
 
 
 def test_bench_point_add_and_compress_workloads():
@@ -78,5 +80,3 @@ def test_bench_point_add_and_compress_workloads():
                      "--no-also", "--no-strong"])
         assert r.returncode == 0, r.stderr[-3000:]
         assert j["parity_sample_ok"] and j["unit"] == unit and j["roofline"]["achieved"] > 0 and j["cpu_baseline"]["value"] > 0
-    assert j["also"]["fixed_base_window_bits_23"]["parity_sample_ok"]
-    assert j["config"]["init_ms"] > 0 and j["config"]["table_bytes"] > 0
