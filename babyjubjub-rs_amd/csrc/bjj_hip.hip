@@ -119,6 +119,7 @@ struct bjj_ctx {
   // business); the others: resident 256-lane workgroups per CU
   int lanes_fixed = 512, lanes_var = 512;
   int lanes_fixed_2x256 = 512;   // resident lanes per CU of K1's two-workgroup shape
+  int k2_variant = -1;           // -1 = per call (tiles for a launch that runs alone, grid-strided while another is in flight), 0 / 1 = forced (BJJ_K2_VARIANT)
   int k1_variant = -1;           // -1 = per call (two-workgroup shape while another launch of the context is in flight), 0 / 1 = forced (BJJ_K1_VARIANT)
   int occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
   int xccs = 1;                // XCDs of the device (probed at init; sizes the verify kernels' slot queues)
@@ -445,6 +446,9 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->nwin = fixed_nwin(W);
   c->lanes_fixed = bjjk::fixed_base_lanes_per_cu(0);
   c->lanes_fixed_2x256 = bjjk::fixed_base_lanes_per_cu(1);
+  if (const char* e = getenv("BJJ_K2_VARIANT")) {
+    if (e[0] == '0' || e[0] == '1') c->k2_variant = e[0] - '0';
+  }
   if (const char* e = getenv("BJJ_K1_VARIANT")) {   // tests / A-B: force one shape of the fixed-base kernel
     if (e[0] == '0' || e[0] == '1') c->k1_variant = e[0] - '0';
   }
@@ -615,7 +619,8 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
   if (!d_pts || !d_scalars || !d_out || !aligned16(d_pts) || !aligned16(d_scalars) || !aligned16(d_out))
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   SET_ENTER(c, stream, n, false);
-  LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
+  const int kv = c->k2_variant >= 0 ? c->k2_variant : (other_launch_in_flight(c, S) ? 0 : 1);   // k_var.hip: the two forms of K2
+  LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, kv, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
                               (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow, S->slotq2, S->slot_cap2),
            "bjj_mul_var_base_dev");
   SET_LEAVE(c);

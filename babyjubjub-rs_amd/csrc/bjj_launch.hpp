@@ -48,7 +48,7 @@ hipError_t check_fixed_table(hipStream_t st, int grid, const uint32_t* table, co
 hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant, const uint32_t* table, int W, int nwin,
                           const uint8_t* scalars, size_t n, uint8_t* out, uint32_t* scratch);
 // k_var.hip (sc_words: 32-bit words per scalar record, 8 for the 32-byte form)
-hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
+hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int variant, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
                         uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow, uint32_t* slotq, uint32_t slot_cap);
 hipError_t point_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);
 hipError_t proj_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);

@@ -17,10 +17,14 @@
 #ifndef BJJ_K2_MIN_BLOCKS
 #define BJJ_K2_MIN_BLOCKS 3
 #endif
-// 0: one resident set of workgroups, items grid-strided (rounds 1-2);  1: one tile of items per workgroup (see below)
-#ifndef BJJ_K2_DISPATCH
-#define BJJ_K2_DISPATCH 1
-#endif
+// K2 comes in two forms, both compiled, picked per call by the host (bjj_hip.hip: var_base_variant):
+//   0  one resident set of workgroups, items grid-strided (rounds 1-2): best while ANOTHER launch of the context is in flight
+//      -- its long-lived workgroups let the other launch fill the tail, and the two launches' per-lane tables are not all
+//      live at once (2 x 200 MB of tables interleaved would fall out of the 256 MB Infinity Cache);
+//   1  one 256-item tile per workgroup (below): best for a launch that runs alone -- the hardware balances 4 096 short
+//      workgroups over the chip, so a 2^20-item launch costs ~5.4 item-times instead of 6.
+// Interleaved A/B, one MI355X (profiles/r03_ab_k2_tiles.txt): alone 15.0 vs 15.4 ms (tiles +2.6 %); on two streams 72.7 vs
+// 74.1 M mults/s (strided +1.9 %).  BJJ_K2_VARIANT=0|1 forces one form.
 
 // (n >> 3) mod l of a little-endian integer of nw words, as 8 words -> n mod 8l = 8*that + (n & 7) < 2^254.
 // Horner over 261-bit chunks, most significant first: acc <- acc * 2^261 + chunk (mod l), with the mod-l Montgomery
@@ -204,12 +208,10 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_proj_affine(const uint8_t* __
 
 namespace bjjk {
 int var_base_block() { return BJJ_K2_BLOCK; }
-int var_base_lanes_per_cu() {   // resident lanes of K2 per CU (sizes the per-lane table scratch and the grid)
-#if BJJ_K2_DISPATCH == 1
-  const int a = occupancy_of(bjj_k_mul_var_base_tiles, BJJ_K2_BLOCK), b = occupancy_of(bjj_k_mul_var_base_wide_tiles, BJJ_K2_BLOCK);
-#else
-  const int a = occupancy_of(bjj_k_mul_var_base, BJJ_K2_BLOCK), b = occupancy_of(bjj_k_mul_var_base_wide, BJJ_K2_BLOCK);
-#endif
+int var_base_lanes_per_cu() {   // resident lanes of K2 per CU (sizes the per-lane table scratch and the grid): the least of all forms
+  int a = occupancy_of(bjj_k_mul_var_base_tiles, BJJ_K2_BLOCK), b = occupancy_of(bjj_k_mul_var_base_wide_tiles, BJJ_K2_BLOCK);
+  const int a0 = occupancy_of(bjj_k_mul_var_base, BJJ_K2_BLOCK), b0 = occupancy_of(bjj_k_mul_var_base_wide, BJJ_K2_BLOCK);
+  a = a < a0 ? a : a0; b = b < b0 ? b : b0;
   return (a < b ? a : b) * BJJ_K2_BLOCK;   // one grid size (and one per-lane table allocation) serves both kernels
 }
 int occ_point_add() {
@@ -217,28 +219,26 @@ int occ_point_add() {
             c = occupancy_of(bjj_k_proj_affine, BJJ_BLOCK);
   return a < b ? (a < c ? a : c) : (b < c ? b : c);
 }
-hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
+hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int variant, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
                         uint8_t* out, u32* scratch, u32* vb_tables, u32* slow, u32* slotq, u32 slot_cap) {
   hipError_t e = hipMemsetAsync(slow, 0, 8 * sizeof(u32), st);
   if (e != hipSuccess) return e;
   const size_t want = (n + BJJ_K2_BLOCK - 1) / BJJ_K2_BLOCK, cap = (size_t)cus * (size_t)(lanes_per_cu / BJJ_K2_BLOCK);
-#if BJJ_K2_DISPATCH == 1
-  (void)cap;
+  if (variant == 1) {
   if (sc_words == 8)
     hipLaunchKernelGGL(bjj_k_mul_var_base_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow,
                        slotq, slot_cap);
   else
     hipLaunchKernelGGL(bjj_k_mul_var_base_wide_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
                        vb_tables, slow, slotq, slot_cap);
-#else
-  (void)slotq; (void)slot_cap;
+  } else {
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
   if (sc_words == 8)
     hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow);
   else
     hipLaunchKernelGGL(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
                        vb_tables, slow);
-#endif
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(bjj_k_mul_var_base_exact, dim3(grid_exact), dim3(64), 0, st, pts, scalars, sc_words, out, slow);

@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(BJJ_SCAN_BLOCK) bjj_k_eddsa_verify_scan(const 
     if (verify_needs_exact(in, c_K)) wl[WL_HDR + atomicAdd(&wl[0], 1u)] = (u32)i;
   }
 }
+#if BJJ_VERIFY_DISPATCH == 0   // ---- dispatch mode 0: persistent waves + atomic cursors (rounds 1-2; A/B control)
 // NOTE on this cursor idiom (`if (lane == 0) c = atomicAdd(..); c = __shfl(c, 0);`): it is safe in the two loops below,
 // whose bodies contain no other `if (lane == 0)` block.  In a loop whose body ENDS with such a block hipcc threads lanes
 // 1..63 from the end of the body straight into the next iteration's cross-lane read while lane 0 is still away -- they read
@@ -114,6 +115,7 @@ __global__ void __launch_bounds__(BJJ_VERIFY_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k
   verify_kernel_body<false>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
 }
 
+#endif  // BJJ_VERIFY_DISPATCH == 0
 __global__ void bjj_k_probe_xcc(u32* out) {
   if (threadIdx.x == 0) atomicMax(out, xcc_id() + 1u);
 }

@@ -97,6 +97,30 @@ def test_cfg3_var_base_1m_every_item(gpu_ctx, oracle, pyoracle):
     assert _mismatches(got, oracle.mul_var_base(pts, sc)) == (0, [])
 
 
+def test_cfg3_var_base_both_kernel_forms_agree_on_every_item(gpu_ctx, pyoracle, monkeypatch):
+    """K2 has two forms (k_var.hip): one 256-item tile per workgroup (what a launch that runs alone gets -- the form the test
+    above compared with the oracle item by item) and the grid-strided resident set (picked while another launch of the context
+    is in flight).  BJJ_K2_VARIANT forces one form for a context: both must agree on all 2^20 outputs, off-curve points included."""
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    pts = cfg3_points(gpu_ctx, pyoracle, N)
+    sc = w.scalars_254(N)
+    got = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("BJJ_K2_VARIANT", v)
+        ctx = bjj.Context(0, 16)
+        monkeypatch.delenv("BJJ_K2_VARIANT")
+        try:
+            got[v] = ctx.mul_var_base(pts, sc)
+            wide = np.zeros((4096, 64), np.uint8)
+            wide[:, :32] = sc[:4096]
+            assert (ctx.mul_var_base_wide(pts[:4096], wide, 64) == got[v][:4096]).all()          # the wide kernels of that form
+        finally:
+            ctx.close()
+    assert _mismatches(got["0"], got["1"]) == (0, [])
+    assert _mismatches(got["1"], gpu_ctx.mul_var_base(pts, sc)) == (0, [])
+
+
 @BOTH_TABLES
 def test_cfg4_verify_1m_every_item(ctx_for_window, oracle):
     """configs[3]: 2^20 EdDSA-Poseidon verifications, 1/64 corrupted: every verdict vs the oracle and vs the known mask,
