@@ -119,6 +119,7 @@ struct bjj_ctx {
   // business); the others: resident 256-lane workgroups per CU
   int lanes_fixed = 512, lanes_var = 512;
   int lanes_fixed_2x256 = 512;   // resident lanes per CU of K1's two-workgroup shape
+  int verify_mode = -1;          // -1 = per call (persistent waves for one launch > 2^21 items that runs alone, groups otherwise), 0 / 1 = forced (BJJ_VERIFY_DISPATCH)
   int k2_variant = -1;           // -1 = per call (tiles for a launch that runs alone, grid-strided while another is in flight), 0 / 1 = forced (BJJ_K2_VARIANT)
   int k1_variant = -1;           // -1 = per call (two-workgroup shape while another launch of the context is in flight), 0 / 1 = forced (BJJ_K1_VARIANT)
   int occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
@@ -220,7 +221,7 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
   // slots of per-lane tables: K2 needs its resident lanes; verify (2 tables per lane) the waves that can be resident, rounded
   // up to a whole number per XCD (the slot queues are per XCD)
   const size_t cu_per_xcc = ((size_t)c->cus + c->xccs - 1) / c->xccs;
-  const u32 cap = (u32)(cu_per_xcc * c->occ_verify * (BJJ_VERIFY_BLOCK / 64));
+  const u32 cap = (u32)(cu_per_xcc * c->occ_verify);   // occ_verify counts waves
   size_t tv = cu_per_xcc * c->xccs * (size_t)c->lanes_var, te = (size_t)c->xccs * cap * 64 * 2;
   size_t threads = tv > te ? tv : te;
   const u32 cap2 = (u32)(cu_per_xcc * (size_t)(c->lanes_var / bjjk::var_base_block()));
@@ -446,6 +447,9 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->nwin = fixed_nwin(W);
   c->lanes_fixed = bjjk::fixed_base_lanes_per_cu(0);
   c->lanes_fixed_2x256 = bjjk::fixed_base_lanes_per_cu(1);
+  if (const char* e = getenv("BJJ_VERIFY_DISPATCH")) {
+    if (e[0] == '0' || e[0] == '1') c->verify_mode = e[0] - '0';
+  }
   if (const char* e = getenv("BJJ_K2_VARIANT")) {
     if (e[0] == '0' || e[0] == '1') c->k2_variant = e[0] - '0';
   }
@@ -545,9 +549,9 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
     info->scratch_bytes += S.scratch_items * 64 + S.vb_threads * VB_TABLE_WORDS_MAX * sizeof(u32) + S.slow_items * 4 +
                            (S.codec_items ? S.codec_items * 162 + 64 : 0);
   info->kernel_fixed_base = "bjj_k_mul_fixed_base";
-  info->kernel_var_base = "bjj_k_mul_var_base";
+  info->kernel_var_base = "bjj_k_mul_var_base_tiles";   // the form a launch that runs alone gets (k_var.hip)
   info->kernel_poseidon5 = "bjj_k_poseidon5";
-  info->kernel_verify = "bjj_k_eddsa_verify";
+  info->kernel_verify = "bjj_k_eddsa_verify_groups";
   info->init_ms = c->init_ms;
   const size_t fill = cap < sizeof(full) ? cap : sizeof(full);   // never past the caller's struct
   full.struct_size = (uint32_t)fill;
@@ -652,7 +656,10 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
     HIPCK(hipEventCreateWithFlags(&S->ev_scan_out, hipEventDisableTiming));
   }
   const int scan_grid = grid_for(c, n, c->occ_scan, 64) * 64 / bjjk::verify_scan_block();   // occ_scan counts waves
-  if (other_launch_in_flight(c, S)) {   // the chip is (about to be) full of another launch's workgroups: priority stream
+  const bool busy = other_launch_in_flight(c, S);
+  // k_verify.hip: persistent waves for ONE large launch that runs alone, one group per workgroup otherwise
+  const int mode = c->verify_mode >= 0 ? c->verify_mode : ((!busy && n > ((size_t)1 << 21)) ? 0 : 1);
+  if (busy) {   // the chip is (about to be) full of another launch's workgroups: priority stream
     HIPCK(hipEventRecord(S->ev_scan_in, st));
     HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));
     LAUNCHCK(bjjk::verify_scan(S->scan_stream, scan_grid, pk, r, msg, n, S->slow), "verify scan");
@@ -661,7 +668,7 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
   } else {                              // nothing to compete with: in line, no event hops
     LAUNCHCK(bjjk::verify_scan(st, scan_grid, pk, r, msg, n, S->slow), "verify scan");
   }
-  LAUNCHCK(bjjk::verify_main(st, grid_for(c, n, c->occ_verify, BJJ_VERIFY_BLOCK), schnorr, c->table, c->W, c->nwin, pk, r, s, msg, n, ok,
+  LAUNCHCK(bjjk::verify_main(st, mode, grid_for(c, n, c->occ_verify, 64) * 64 / BJJ_VERIFY_BLOCK, schnorr, c->table, c->W, c->nwin, pk, r, s, msg, n, ok,
                              S->vb_tables, S->slow, S->slotq, S->slot_cap), "verify");
   return BJJ_OK;
 }

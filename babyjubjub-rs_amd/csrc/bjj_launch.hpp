@@ -33,8 +33,7 @@ int var_base_block();
 int occ_point_add();
 int occ_poseidon5();
 int occ_decompress();
-int occ_verify();
-int verify_dispatch_mode();                         // 1: one 64-item group per workgroup + per-XCD slot queues
+int occ_verify();           // resident verify WAVES per CU
 int probe_xccs(hipStream_t st, uint32_t* d_word);   // number of XCDs of the current device (0 on error)
 int occ_verify_scan();      // resident scan WAVES per CU
 int verify_scan_block();
@@ -62,7 +61,7 @@ hipError_t merge_codec_flags(hipStream_t st, int grid, uint8_t* ok, const uint8_
 hipError_t scalar_keys(hipStream_t st, int grid, const uint8_t* keys, size_t n, uint8_t* out);
 // k_verify.hip
 hipError_t verify_scan(hipStream_t st, int grid_scan, const uint8_t* pk, const uint8_t* rb8, const uint8_t* msg, size_t n, uint32_t* wl);
-hipError_t verify_main(hipStream_t st, int grid, bool schnorr, const uint32_t* table, int W, int nwin, const uint8_t* pk,
+hipError_t verify_main(hipStream_t st, int mode, int grid, bool schnorr, const uint32_t* table, int W, int nwin, const uint8_t* pk,
                        const uint8_t* rb8, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok, uint32_t* vb_tables,
                        uint32_t* wl, uint32_t* slotq, uint32_t slot_cap);
 // k_sign.hip

@@ -25,17 +25,18 @@
 // [8..] exact item indices.
 // ---------------------------------------------------------------------------
 #define WL_HDR 8
-// How the main kernel's work is handed out (A/B knob):
-//   0  persistent waves: the grid is one resident set, waves pull 64-item groups through atomic cursors (rounds 1-2);
+// How the main kernel's work is handed out -- both forms are compiled, the host picks per call (bjj_hip.hip: enqueue_verify;
+// BJJ_VERIFY_DISPATCH=0|1 in the environment forces one):
+//   0  persistent waves: the grid is one resident set, waves pull 64-item groups through atomic cursors (rounds 1-2).  Its
+//      waves stay in lock-step over the 70 K-instruction body, which is worth ~4 % in a launch of many rounds: the form for
+//      one launch of more than 2^21 items that runs alone (profiles/r03_ab_verify_group_dispatch.txt: 59.5 vs 57.1 M/s at 2^22);
 //   1  one group per 64-lane workgroup: the grid is (exact-list groups) + (batch chunks), the hardware's workgroup dispatcher
-//      does the scheduling, and a per-XCD queue hands every running workgroup a slot of the per-lane table scratch.
+//      does the scheduling, and a per-XCD queue hands every running workgroup a slot of the per-lane table scratch: better at
+//      2^20 items (the last, partly empty round is cheaper) and the form that makes overlapping launches work-conserving.
 // With persistent waves two launches that overlap (two streams, two scratch sets) split the chip half and half for their
 // whole life and each pays its own partly empty last round (profiles/r03_ab_inkernel_scan_rejected.txt); workgroups that
 // retire after one group give every freed slot to whichever launch has work pending, which is what makes the pair
 // work-conserving.  The exact-list groups have the lowest block indices, so they are still dispatched first.
-#ifndef BJJ_VERIFY_DISPATCH
-#define BJJ_VERIFY_DISPATCH 1
-#endif
 // 64-lane workgroups: one light wave (73 VGPRs) fits into any slot a retiring wave of the main kernel frees.
 #ifndef BJJ_SCAN_BLOCK
 #define BJJ_SCAN_BLOCK 64
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(BJJ_SCAN_BLOCK) bjj_k_eddsa_verify_scan(const 
     if (verify_needs_exact(in, c_K)) wl[WL_HDR + atomicAdd(&wl[0], 1u)] = (u32)i;
   }
 }
-#if BJJ_VERIFY_DISPATCH == 0   // ---- dispatch mode 0: persistent waves + atomic cursors (rounds 1-2; A/B control)
+// ---- dispatch mode 0: persistent waves + atomic cursors (rounds 1-2; still the better form for one very large launch)
 // NOTE on this cursor idiom (`if (lane == 0) c = atomicAdd(..); c = __shfl(c, 0);`): it is safe in the two loops below,
 // whose bodies contain no other `if (lane == 0)` block.  In a loop whose body ENDS with such a block hipcc threads lanes
 // 1..63 from the end of the body straight into the next iteration's cross-lane read while lane 0 is still away -- they read
@@ -115,7 +116,6 @@ __global__ void __launch_bounds__(BJJ_VERIFY_BLOCK, BJJ_VERIFY_MIN_BLOCKS) bjj_k
   verify_kernel_body<false>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
 }
 
-#endif  // BJJ_VERIFY_DISPATCH == 0
 __global__ void bjj_k_probe_xcc(u32* out) {
   if (threadIdx.x == 0) atomicMax(out, xcc_id() + 1u);
 }
@@ -125,47 +125,55 @@ __device__ __forceinline__ void verify_group_body(const u32* __restrict__ table,
                                                   const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
                                                   const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg, size_t n,
                                                   uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
-                                                  const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap) {
-  static_assert(BJJ_VERIFY_DISPATCH == 0 || BJJ_VERIFY_BLOCK == 64, "one group per workgroup needs 64-lane workgroups");
+                                                  const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap, u32 exact_wgs) {
   __shared__ __attribute__((aligned(16))) u32 stage[FB_STAGE_WORDS];
   const int lane = threadIdx.x & 63;
+  // grid = exact_wgs workgroups for the exact list (lowest indices: dispatched first) + the rest for the batch; both kinds
+  // stride over their groups, so that the grid stays small for huge batches (one group each up to 2^21 items)
   const size_t nchunks = (n + 63) / 64, b = blockIdx.x;
-  const bool exact = b < nchunks;                            // block indices [0, nchunks): groups of the exact list
+  const bool exact = b < exact_wgs;
   const unsigned long long nexact = wl[0];
   if (exact && b * 64 >= nexact) return;                     // wave-uniform: nothing on the list for this block
   u32* q = slotq + (size_t)xcc_id() * (SLOTQ_HDR + cap);
   const u32 slot = slot_pop(q, cap, lane);
   u32* tbl = vb_tables + ((size_t)slot * 64 + lane) * VB_VERIFY_WORDS;
   if (exact) {
-    const size_t c = b * 64;
-    if (c + lane < nexact) {
-      const size_t i = wl[WL_HDR + c + lane];
-      VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
-      ok[i] = (uint8_t)verify_exact_t<SCHNORR>(in, table, W, nwin, tbl, c_K);
+#pragma unroll 1
+    for (size_t c = b * 64; c < nexact; c += (size_t)exact_wgs * 64) {
+      if (c + lane < nexact) {
+        const size_t i = wl[WL_HDR + c + lane];
+        VerifyIn in = {pk + i * 64, rb8 + i * 64, s + i * 32, msg + i * 32};
+        ok[i] = (uint8_t)verify_exact_t<SCHNORR>(in, table, W, nwin, tbl, c_K);
+      }
     }
   } else {
     const GatherCoopLds<1> fb = {table, stage, lane};
-    const size_t i = (b - nchunks) * 64 + lane, ic = i < n ? i : n - 1;   // every lane runs (cooperative gathers)
-    VerifyIn in = {pk + ic * 64, rb8 + ic * 64, s + ic * 32, msg + ic * 32};
-    bool need_exact;
-    const int v = verify_fast_t<SCHNORR>(in, fb, W, nwin, tbl, c_K, need_exact);
-    if (i < n && !need_exact) ok[i] = (uint8_t)v;
+    const size_t bulk_wgs = gridDim.x - exact_wgs;
+#pragma unroll 1
+    for (size_t ch = b - exact_wgs; ch < nchunks; ch += bulk_wgs) {
+      const size_t i = ch * 64 + lane, ic = i < n ? i : n - 1;   // every lane runs (cooperative gathers)
+      VerifyIn in = {pk + ic * 64, rb8 + ic * 64, s + ic * 32, msg + ic * 32};
+      bool need_exact;
+      const int v = verify_fast_t<SCHNORR>(in, fb, W, nwin, tbl, c_K, need_exact);
+      if (i < n && !need_exact) ok[i] = (uint8_t)v;
+    }
   }
   slot_push(q, cap, slot, lane);
 }
 __global__ void __launch_bounds__(64, BJJ_VERIFY_MIN_BLOCKS) bjj_k_schnorr_verify_groups(const u32* __restrict__ table, int W, int nwin,
     const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8, const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg,
-    size_t n, uint8_t* __restrict__ ok, u32* __restrict__ vb_tables, const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap) {
-  verify_group_body<true>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, cap);
+    size_t n, uint8_t* __restrict__ ok, u32* __restrict__ vb_tables, const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap,
+    u32 exact_wgs) {
+  verify_group_body<true>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, cap, exact_wgs);
 }
 __global__ void __launch_bounds__(64, BJJ_VERIFY_MIN_BLOCKS) bjj_k_eddsa_verify_groups(const u32* __restrict__ table, int W, int nwin,
     const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8, const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg,
-    size_t n, uint8_t* __restrict__ ok, u32* __restrict__ vb_tables, const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap) {
-  verify_group_body<false>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, cap);
+    size_t n, uint8_t* __restrict__ ok, u32* __restrict__ vb_tables, const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap,
+    u32 exact_wgs) {
+  verify_group_body<false>(table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, cap, exact_wgs);
 }
 
 namespace bjjk {
-int verify_dispatch_mode() { return BJJ_VERIFY_DISPATCH; }
 int probe_xccs(hipStream_t st, u32* d_word) {   // number of XCDs = highest XCC_ID seen by a few thousand workgroups + 1
   if (hipMemsetAsync(d_word, 0, sizeof(u32), st) != hipSuccess) return 0;
   hipLaunchKernelGGL(bjj_k_probe_xcc, dim3(4096), dim3(64), 0, st, d_word);
@@ -174,12 +182,10 @@ int probe_xccs(hipStream_t st, u32* d_word) {   // number of XCDs = highest XCC_
   return (int)h;
 }
 int occ_verify() {   // resident workgroups per CU; one grid size (and one per-lane table allocation) serves both kernels
-#if BJJ_VERIFY_DISPATCH == 1
-  const int a = occupancy_of(bjj_k_eddsa_verify_groups, 64), b = occupancy_of(bjj_k_schnorr_verify_groups, 64);
-#else
-  const int a = occupancy_of(bjj_k_eddsa_verify, BJJ_VERIFY_BLOCK), b = occupancy_of(bjj_k_schnorr_verify, BJJ_VERIFY_BLOCK);
-#endif
-  return a < b ? a : b;
+  int a = occupancy_of(bjj_k_eddsa_verify_groups, 64), b = occupancy_of(bjj_k_schnorr_verify_groups, 64);
+  const int a0 = occupancy_of(bjj_k_eddsa_verify, BJJ_VERIFY_BLOCK) * (BJJ_VERIFY_BLOCK / 64), b0 = occupancy_of(bjj_k_schnorr_verify, BJJ_VERIFY_BLOCK) * (BJJ_VERIFY_BLOCK / 64);
+  a = a < a0 ? a : a0; b = b < b0 ? b : b0;
+  return a < b ? a : b;   // resident WAVES per CU, the least of all four kernels
 }
 int occ_verify_scan() { return occupancy_of(bjj_k_eddsa_verify_scan, BJJ_SCAN_BLOCK) * BJJ_SCAN_BLOCK / 64; }   // resident scan WAVES per CU
 int verify_scan_block() { return BJJ_SCAN_BLOCK; }
@@ -191,23 +197,24 @@ hipError_t verify_scan(hipStream_t st, int grid_scan, const uint8_t* pk, const u
   hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_scan), dim3(BJJ_SCAN_BLOCK), 0, st, pk, rb8, msg, n, wl);
   return hipGetLastError();
 }
-hipError_t verify_main(hipStream_t st, int grid, bool schnorr, const u32* table, int W, int nwin, const uint8_t* pk,
+hipError_t verify_main(hipStream_t st, int mode, int grid, bool schnorr, const u32* table, int W, int nwin, const uint8_t* pk,
                        const uint8_t* rb8, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok, u32* vb_tables, u32* wl,
                        u32* slotq, u32 slot_cap) {
-#if BJJ_VERIFY_DISPATCH == 1
-  (void)grid;
-  const unsigned groups = (unsigned)(2 * ((n + 63) / 64));   // [0, n/64): exact-list groups (most exit at once), then the batch chunks
+  if (mode == 1) {
+  const size_t nchunks = (n + 63) / 64;
+  const unsigned exact_wgs = (unsigned)(nchunks < 4096 ? nchunks : 4096);      // most of them find nothing on the list and exit at once
+  const unsigned bulk_wgs = (unsigned)(nchunks < 32768 ? nchunks : 32768);    // one 64-item chunk each up to 2^21 items, strided beyond
+  const unsigned groups = exact_wgs + bulk_wgs;
   if (schnorr)
-    hipLaunchKernelGGL(bjj_k_schnorr_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap);
+    hipLaunchKernelGGL(bjj_k_schnorr_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap, exact_wgs);
   else
-    hipLaunchKernelGGL(bjj_k_eddsa_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap);
-#else
-  (void)slotq; (void)slot_cap;
+    hipLaunchKernelGGL(bjj_k_eddsa_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap, exact_wgs);
+  } else {
   if (schnorr)
     hipLaunchKernelGGL(bjj_k_schnorr_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
   else
     hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
-#endif
+  }
   return hipGetLastError();
 }
 }  // namespace bjjk

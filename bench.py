@@ -58,8 +58,9 @@ WORKLOAD_TEXT = {"fixed_base": "1M fixed-base scalar mults (generator B8), BASEL
                  "sign": "1M PrivateKey::sign (Blake-512 x2, 2 fixed-base mults, Poseidon; SURVEY 8f row 2)",
                  "point_add": "1M p.projective().add(&q.projective()).affine() (benches/bench_babyjubjub.rs:26-31)",
                  "compress": "1M Point::compress (benches/bench_babyjubjub.rs:40-41)"}
-KERNEL = {"fixed_base": "bjj_k_mul_fixed_base", "var_base": "bjj_k_mul_var_base", "verify": "bjj_k_eddsa_verify",
-          "poseidon5": "bjj_k_poseidon5", "verify_compressed": "bjj_k_eddsa_verify", "decompress": "bjj_k_decompress_points",
+# the kernel a launch that runs ALONE on one stream gets (what roofline / valu and the rocprofv3 summaries describe)
+KERNEL = {"fixed_base": "bjj_k_mul_fixed_base", "var_base": "bjj_k_mul_var_base_tiles", "verify": "bjj_k_eddsa_verify_groups",
+          "poseidon5": "bjj_k_poseidon5", "verify_compressed": "bjj_k_eddsa_verify_groups", "decompress": "bjj_k_decompress_points",
           "sign": "bjj_k_sign", "point_add": "bjj_k_point_add", "compress": "bjj_k_compress_points"}
 # Streams the timed loop alternates over by default.  The context keeps one scratch set per stream (two sets), so with two
 # streams consecutive launches overlap: the head of launch k+1 fills the partly empty last wave-round of launch k (verify is

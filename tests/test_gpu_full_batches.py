@@ -134,6 +134,28 @@ def test_cfg4_verify_1m_every_item(ctx_for_window, oracle):
     assert _mismatches(got, _oracle_once("cfg4", lambda: oracle.verify(A, R, S, msg))) == (0, [])
 
 
+def test_cfg4_verify_both_dispatch_forms_agree_on_every_verdict(gpu_ctx, monkeypatch):
+    """The verify kernel has two forms (k_verify.hip): one 64-item group per workgroup (what 2^20-item launches get -- compared
+    with the oracle verdict by verdict above) and persistent waves with atomic cursors (one launch of more than 2^21 items that
+    runs alone).  BJJ_VERIFY_DISPATCH forces one form for a context: every verdict of the cfg-4 batch must equal the corruption
+    mask in both, also for the Schnorr kernels (compared with each other)."""
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    A, R, S, msg = w.make_signatures(gpu_ctx.mul_fixed_base, gpu_ctx.poseidon5, N)
+    bad = w.corrupt(A, R, S, msg, N)
+    sch = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("BJJ_VERIFY_DISPATCH", v)
+        ctx = bjj.Context(0, 16)
+        monkeypatch.delenv("BJJ_VERIFY_DISPATCH")
+        try:
+            assert (ctx.eddsa_verify(A, R, S, msg) == (~bad).astype(np.uint8)).all(), v
+            sch[v] = ctx.schnorr_verify(A[:1 << 16], R[:1 << 16], S[:1 << 16], msg[:1 << 16])
+        finally:
+            ctx.close()
+    assert (sch["0"] == sch["1"]).all()
+
+
 def test_poseidon_1m_every_item(gpu_ctx, oracle):
     from babyjubjub_rs_amd import workload as w
     inp = w.random_u256(w.SEED_MSGS, 5 * N, 0).reshape(N, 160)      # full 256-bit inputs: reduced mod r on both sides

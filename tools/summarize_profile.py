@@ -6,7 +6,7 @@ import collections, csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, wl = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out", tag)
-KERNEL = {"fixed_base": "bjj_k_mul_fixed_base", "var_base": "bjj_k_mul_var_base", "verify": "bjj_k_eddsa_verify",
+KERNEL = {"fixed_base": "bjj_k_mul_fixed_base", "var_base": "bjj_k_mul_var_base_tiles", "verify": "bjj_k_eddsa_verify_groups",
           "poseidon5": "bjj_k_poseidon5"}[wl]
 out = ["# rocprofv3 summary — %s, workload %s" % (tag, wl), "",
        "Command (see tools/profile_r.sh): `rocprofv3 --output-format csv --kernel-trace --stats -- python3 bench.py "
