@@ -625,7 +625,7 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
   SET_ENTER(c, stream, n, false);
   const int kv = c->k2_variant >= 0 ? c->k2_variant : (other_launch_in_flight(c, S) ? 0 : 1);   // k_var.hip: the two forms of K2
   LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, kv, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
-                              (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow, S->slotq2, S->slot_cap2),
+                              (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)),
            "bjj_mul_var_base_dev");
   SET_LEAVE(c);
 }
@@ -669,7 +669,7 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
     LAUNCHCK(bjjk::verify_scan(st, scan_grid, pk, r, msg, n, S->slow), "verify scan");
   }
   LAUNCHCK(bjjk::verify_main(st, mode, grid_for(c, n, c->occ_verify, 64) * 64 / BJJ_VERIFY_BLOCK, schnorr, c->table, c->W, c->nwin, pk, r, s, msg, n, ok,
-                             S->vb_tables, S->slow, S->slotq, S->slot_cap), "verify");
+                             S->vb_tables, S->slow, S->slotq, S->slot_cap | ((u32)c->xccs << 16)), "verify");
   return BJJ_OK;
 }
 static int verify_launch(bjj_ctx* c, bool schnorr, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg,

@@ -171,6 +171,12 @@ struct GatherCoopLds {
 // refills it is still in flight (it then spins on that one word).  The tickets wrap at cap by themselves (atomicInc).
 #define SLOTQ_HDR 16
 __device__ __forceinline__ u32 xcc_id() { return (u32)__builtin_amdgcn_s_getreg(6164); }   // hwreg(HW_REG_XCC_ID, 0, 4)
+// The kernels get (slots per XCD) | (number of XCDs << 16) in one word.  The XCD count was probed at bjj_init; an id beyond it
+// (a partition mode that changed since) wraps onto an existing queue instead of indexing past the allocation.
+__device__ __forceinline__ u32* slot_queue_of_this_xcd(u32* slotq, u32 cap_nx) {
+  const u32 cap = cap_nx & 0xffffu, nx = cap_nx >> 16;
+  return slotq + (size_t)(xcc_id() % nx) * (SLOTQ_HDR + cap);
+}
 // one thread takes / returns a slot
 __device__ __forceinline__ u32 slot_pop_one(u32* q, u32 cap) {
   const u32 t = atomicInc(&q[0], cap - 1u);            // ticket in [0, cap): wraps by itself

@@ -107,10 +107,11 @@ __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var
 template <bool WIDE>
 __device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars, int sc_words, size_t n,
                                               uint8_t* __restrict__ out, u32* __restrict__ scratch, u32* __restrict__ vb_tables,
-                                              u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap) {
+                                              u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap_nx) {
   __shared__ u32 lds[NL * 64];
   __shared__ u32 sh_slot;
-  u32* q = slotq + (size_t)xcc_id() * (SLOTQ_HDR + cap);
+  u32* q = slot_queue_of_this_xcd(slotq, cap_nx);
+  const u32 cap = cap_nx & 0xffffu;
   if (threadIdx.x == 0) sh_slot = slot_pop_one(q, cap);
   __syncthreads();
   const u32 slot = sh_slot;

@@ -125,7 +125,7 @@ __device__ __forceinline__ void verify_group_body(const u32* __restrict__ table,
                                                   const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
                                                   const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg, size_t n,
                                                   uint8_t* __restrict__ ok, u32* __restrict__ vb_tables,
-                                                  const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap, u32 exact_wgs) {
+                                                  const u32* __restrict__ wl, u32* __restrict__ slotq, u32 cap_nx, u32 exact_wgs) {
   __shared__ __attribute__((aligned(16))) u32 stage[FB_STAGE_WORDS];
   const int lane = threadIdx.x & 63;
   // grid = exact_wgs workgroups for the exact list (lowest indices: dispatched first) + the rest for the batch; both kinds
@@ -134,7 +134,8 @@ __device__ __forceinline__ void verify_group_body(const u32* __restrict__ table,
   const bool exact = b < exact_wgs;
   const unsigned long long nexact = wl[0];
   if (exact && b * 64 >= nexact) return;                     // wave-uniform: nothing on the list for this block
-  u32* q = slotq + (size_t)xcc_id() * (SLOTQ_HDR + cap);
+  u32* q = slot_queue_of_this_xcd(slotq, cap_nx);
+  const u32 cap = cap_nx & 0xffffu;
   const u32 slot = slot_pop(q, cap, lane);
   u32* tbl = vb_tables + ((size_t)slot * 64 + lane) * VB_VERIFY_WORDS;
   if (exact) {
