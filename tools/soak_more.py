@@ -9,13 +9,22 @@ import babyjubjub_rs_amd as bjj
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 orc = conftest.Oracle()
-ctx = bjj.Context(0, int(os.environ.get("W", "0")))   # default table (23 bits); W=28 for the benchmark table
 bad = 0
-for seed in range(first, first + count):
-    try:
-        test_gpu_soak.test_soak_all_entry_points(ctx, orc, seed)
-    except AssertionError as e:
-        bad += 1
-        print("FAIL seed", seed, e)
-print("extended soak: seeds %d..%d, failures: %d" % (first, first + count - 1, bad))
+# every kernel form: the per-call defaults of a one-stream caller (K1 one workgroup per CU, K2 tiles, verify groups), then the
+# forms a caller only gets while launches overlap or for very large batches, forced through the environment
+for forms in ({}, {"BJJ_K1_VARIANT": "1", "BJJ_K2_VARIANT": "0", "BJJ_VERIFY_DISPATCH": "0"}):
+    os.environ.update(forms)
+    ctx = bjj.Context(0, int(os.environ.get("W", "0")))   # default table (23 bits); W=28 for the benchmark table
+    for k in forms:
+        del os.environ[k]
+    fails = 0
+    for seed in range(first, first + count):
+        try:
+            test_gpu_soak.test_soak_all_entry_points(ctx, orc, seed)
+        except AssertionError as e:
+            fails += 1
+            print("FAIL seed", seed, forms, e)
+    ctx.close()
+    print("extended soak, kernel forms %s: seeds %d..%d, failures: %d" % (forms or "default", first, first + count - 1, fails))
+    bad += fails
 sys.exit(1 if bad else 0)
