@@ -588,6 +588,57 @@ def run_native_multi(args):
     return 0 if ok_all else 3
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The headline line must not be hostage to the optional sections (`also`, `strong`): those are the only code of this file that
+# has never run over real multi-GPU RCCL (point-to-point groups of cfg 5's rank-0-resident shape).  Once the headline is
+# measured, a watchdog bounds everything that follows: if the optional sections raise on this rank, or are not finished by
+# the deadline (a rank stuck in a collective), rank 0 prints the headline line with what is complete plus a note, and every rank
+# leaves through os._exit -- no further collective, no destructor that could block on a wedged communicator.
+# ---------------------------------------------------------------------------------------------------------------
+class Headline:
+    def __init__(self, rank, result, deadline_s):
+        import threading
+        self.rank, self.result, self.deadline_s = rank, result, deadline_s
+        self.sections = {}            # name -> dict, filled as the optional sections complete
+        self.parity = True
+        self.lock = threading.Lock()
+        self.printed = False
+        self.done = threading.Event()
+        self.t0 = time.monotonic()
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+        self.thread.start()
+
+    def emit(self, note=None):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            if self.rank == 0:
+                r = self.result
+                for k, v in self.sections.items():
+                    if v:
+                        r[k] = v
+                r["parity_sample_ok"] = self.parity
+                if note:
+                    r["optional_sections"] = note
+                if not self.parity:
+                    r["value"] = None      # a miscomputing build publishes no number
+                sys.stdout.write(json.dumps(r) + "\n")
+                sys.stdout.flush()
+
+    def abandon(self, note):
+        """print what is complete and leave at once (called from the watchdog, or after an exception in an optional section)"""
+        self.emit(note)
+        sys.stderr.write("bench.py rank %d: %s\n" % (self.rank, note))
+        sys.stderr.flush()
+        os._exit(0 if self.parity else 3)
+
+    def _watch(self):
+        if not self.done.wait(self.deadline_s):
+            self.abandon("abandoned after %.0f s (BJJ_BENCH_OPTIONAL_DEADLINE_S): headline complete, optional sections incomplete"
+                         % (time.monotonic() - self.t0))
+
+
 def main():
     args = parse()
     if args.steps is None:
@@ -673,7 +724,27 @@ def main():
         if cb:
             result["cpu_baseline"] = cb
     del wl
+    hl = Headline(rank, result, float(os.environ.get("BJJ_BENCH_OPTIONAL_DEADLINE_S", "420")))
+    hl.parity = parity
+    try:
+        parity, devices = optional_sections(args, hl, ctx, bjj, kind, n, rank, local_rank, world, dev, red_dev, stream, stream_b,
+                                            second_stream, orc, one_gpu, info, parity)
+    except Exception as e:   # never a collective after a failure: the other ranks' watchdogs end them
+        import traceback
+        traceback.print_exc()
+        hl.abandon("optional section failed on rank %d: %s: %s -- headline complete" % (rank, type(e).__name__, e))
+    hl.done.set()
+    hl.parity = parity
+    if rank == 0:
+        result["devices"] = devices
+    hl.emit()
+    ctx.close()
+    return 0 if parity else 3
 
+
+def optional_sections(args, hl, ctx, bjj, kind, n, rank, local_rank, world, dev, red_dev, stream, stream_b, second_stream, orc,
+                      one_gpu, info, parity):
+    """`also` and `strong` of the bench line (module docstring); fills hl.sections as each completes; returns (parity, devices)"""
     # ---- the other halves of BASELINE's metric, same protocol (20 steps / 3 warm-up / warm-up by time)
     also = {}
     if not args.no_also:
@@ -710,6 +781,9 @@ def main():
                                                  "parity_sample_ok": ok23}
             del w23
             c23.close()
+
+    hl.sections["also"] = also
+    hl.parity = parity
 
     # ---- strong scaling: fixed total work over the N ranks
     strong = {}
@@ -803,6 +877,9 @@ def main():
         strong["verify_16M_total_cfg5" if tot == (1 << 24) else "verify_total"] = line
         del ws2
 
+    hl.sections["strong"] = strong
+    hl.parity = parity
+
     parity = all_and(parity, world, red_dev)
     if world > 1:
         devices = [None] * world
@@ -811,18 +888,7 @@ def main():
         dist.destroy_process_group()
     else:
         devices = [torch.cuda.current_device()]
-    if rank == 0:
-        result["devices"] = devices
-        if also:
-            result["also"] = also
-        if strong:
-            result["strong"] = strong
-        result["parity_sample_ok"] = parity
-        if not parity:
-            result["value"] = None      # a miscomputing build publishes no number
-        print(json.dumps(result))
-    ctx.close()
-    return 0 if parity else 3
+    return parity, devices
 
 
 if __name__ == "__main__":
