@@ -225,3 +225,112 @@ def test_rust_utils_model_matches_reference_vectors_and_oracle(pyoracle):
         assert _modulus(a, m) == a % m                     # Python's % has the sign of the modulus as well
     assert _tonelli(0, Q) is None and _tonelli(Q, Q) is None and _modinv(0, Q) is None
     assert _tonelli(2, 7) == pow(2, 2, 7) and _legendre(0, 7) == 1 and _legendre(3, 7) == -1
+
+
+# ---- a lexer-level check of the uncompiled sources: the nearest thing to `cargo check` this image allows --------------------
+def _rust_tokens(src):
+    """Rust tokens good enough to balance delimiters: skips // and nested /* */ comments, "..." / r#"..."# / b"..." strings,
+    char literals vs lifetimes.  Yields (kind, text, line)."""
+    i, n, line = 0, len(src), 1
+    while i < n:
+        c = src[i]
+        if c == "\n":
+            line += 1; i += 1
+        elif c.isspace():
+            i += 1
+        elif src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            depth, j = 1, i + 2
+            while depth and j < n:
+                if src.startswith("/*", j):
+                    depth += 1; j += 2
+                elif src.startswith("*/", j):
+                    depth -= 1; j += 2
+                else:
+                    line += src[j] == "\n"; j += 1
+            assert depth == 0, "unterminated block comment from line %d" % line
+            i = j
+        elif c == '"' or (c in "rb" and re.match(r'(?:b?r#*"|b")', src[i:])):
+            m = re.match(r'(b?)(r(#*))?"', src[i:])
+            raw, hashes = m.group(2) is not None, m.group(3) or ""
+            j = i + m.end()
+            while True:
+                assert j < n, "unterminated string from line %d" % line
+                if not raw and src[j] == "\\":
+                    j += 2; continue
+                if src[j] == '"' and src.startswith(hashes, j + 1):
+                    j += 1 + len(hashes); break
+                line += src[j] == "\n"; j += 1
+            yield ("str", src[i:j], line)
+            i = j
+        elif c == "'":
+            m = re.match(r"'(?:\\(?:x[0-9a-fA-F]{2}|u\{[0-9a-fA-F]+\}|.)|[^\\'])'", src[i:])
+            if m:
+                yield ("char", m.group(0), line); i += m.end()
+            else:
+                m = re.match(r"'[A-Za-z_]\w*", src[i:])
+                assert m, "stray ' on line %d" % line
+                yield ("lifetime", m.group(0), line); i += m.end()
+        elif c.isalpha() or c == "_":
+            m = re.match(r"\w+", src[i:])
+            yield ("ident", m.group(0), line); i += m.end()
+        elif c.isdigit():
+            m = re.match(r"\d[\w.]*", src[i:])
+            yield ("num", m.group(0), line); i += m.end()
+        else:
+            yield ("punct", c, line); i += 1
+
+
+def test_rust_sources_lex_and_balance():
+    """every .rs file and build.rs: comments / strings / chars terminate, (), [], {} nest properly, every `fn` item has a body
+    or a `;`, no `let` without `;`-terminated statement on the same nesting level, `unsafe` only before a block / fn / impl"""
+    close = {")": "(", "]": "[", "}": "{"}
+    files = [os.path.join(ROOT, "rust", "build.rs")] + [os.path.join(ROOT, "rust", "src", f)
+                                                        for f in sorted(os.listdir(os.path.join(ROOT, "rust", "src")))]
+    for path in files:
+        toks = list(_rust_tokens(open(path).read()))
+        stack = []
+        for k, (kind, t, line) in enumerate(toks):
+            if kind != "punct":
+                continue
+            if t in "([{":
+                stack.append((t, line))
+            elif t in ")]}":
+                assert stack and stack[-1][0] == close[t], "%s:%d: unbalanced %r" % (path, line, t)
+                stack.pop()
+        assert not stack, "%s: unclosed %r from line %d" % (path, stack[-1][0], stack[-1][1])
+        for k, (kind, t, line) in enumerate(toks):
+            if kind == "ident" and t == "unsafe":
+                nxt = toks[k + 1][1]
+                assert nxt in ("{", "fn", "impl", "extern"), "%s:%d: `unsafe %s`" % (path, line, nxt)
+            if kind == "ident" and t == "fn" and toks[k + 1][0] == "ident":
+                # scan to the end of the signature: the first `{` or `;` outside parentheses / angle-free brackets
+                depth, j = 0, k + 2
+                while True:
+                    assert j < len(toks), "%s:%d: fn %s has neither a body nor a `;`" % (path, line, toks[k + 1][1])
+                    tt = toks[j][1]
+                    if toks[j][0] == "punct":
+                        if tt in "([":
+                            depth += 1
+                        elif tt in ")]":
+                            depth -= 1
+                        elif depth == 0 and tt in "{;":
+                            break
+                    j += 1
+
+
+def test_rust_lexer_rejects_broken_sources():
+    import pytest
+    for bad in ('fn f() { let s = "abc; }', "fn f() { /* open", "fn f() { g(1, 2]; }"):
+        with pytest.raises(AssertionError):
+            toks = list(_rust_tokens(bad))
+            stack = []
+            for kind, t, line in toks:
+                if kind == "punct" and t in "([{":
+                    stack.append(t)
+                elif kind == "punct" and t in ")]}":
+                    assert stack and stack.pop() == {")": "(", "]": "[", "}": "{"}[t]
+            assert not stack
+    assert [t for k, t, _ in _rust_tokens("impl<'a> X<'a> { fn c() -> char { '}' } }") if k in ("char", "lifetime")] == ["'a", "'a", "'}'"]
