@@ -143,11 +143,7 @@ struct GatherCoopLds {
     for (int k = 0; k < 8; k++) {
       const int e = 8 * k + (lane >> 3);
       const u32 s = (u32)__shfl((int)(u32)slot, e, 64);
-#ifdef BJJ_EXP_GATHER_CHUNK_MASK   // timing-only experiment (wrong results): fetch only part of every 128-byte entry
-      const int c = ((lane & 7) ^ ((e >> 1) & 7)) & BJJ_EXP_GATHER_CHUNK_MASK;
-#else
       const int c = (lane & 7) ^ ((e >> 1) & 7);
-#endif
       __builtin_amdgcn_global_load_lds(table + (size_t)s * NIELS_WORDS + c * 4,
                                        (__attribute__((address_space(3))) void*)(wlds + (NBUF > 1 ? buf : 0) * FB_STAGE_WORDS + k * (8 * NIELS_WORDS)),
                                        16, 0, 0);
