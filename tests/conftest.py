@@ -151,12 +151,17 @@ def emul(request):
     (BJJ_PNIELS_LAYOUT: 0 = raw entries, the verify unit; 1 = packed entries, the variable-base unit)"""
     d = os.path.join(ROOT, "tests", "emul")
     layout = request.param
-    so = os.path.join(d, "libbjj_emul_l%d.so" % layout)
+    # BJJ_EMUL_SANITIZE=1 (set by tests/test_emul_sanitizers.py for a child pytest that runs under LD_PRELOAD=libasan):
+    # the same bodies with AddressSanitizer + UndefinedBehaviorSanitizer, any report aborts the process
+    san = os.environ.get("BJJ_EMUL_SANITIZE") == "1"
+    so = os.path.join(d, "libbjj_emul_l%d%s.so" % (layout, "_san" if san else ""))
     srcs = [os.path.join(d, "emul_bodies.cpp")] + [
         os.path.join(ROOT, "babyjubjub-rs_amd", "csrc", f)
         for f in ("fr.hpp", "curve.hpp", "poseidon.hpp", "bjj_device.hpp", "bjj_constants.inc")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        _sh(["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-DBJJ_PNIELS_LAYOUT=%d" % layout, "-o", so, srcs[0]], d)
+        extra = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"] if san else []
+        _sh(["g++", "-O1" if san else "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-DBJJ_PNIELS_LAYOUT=%d" % layout] + extra
+            + ["-o", so, srcs[0]], d)
     return ctypes.CDLL(so)
 
 

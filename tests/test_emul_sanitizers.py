@@ -1,0 +1,27 @@
+"""The kernel bodies (bjj_device.hpp, poseidon.hpp, curve.hpp, fr.hpp, sign.hpp) under AddressSanitizer and
+UndefinedBehaviorSanitizer: the CPU emulation suite (tests/test_emul_bodies.py, both per-lane table layouts) runs once more in a
+child pytest whose harness library is built with -fsanitize=address,undefined -fno-sanitize-recover=all.  GPU sanitizers are
+not available on the pool, so this is where out-of-bounds table indices, shift counts >= the type width, signed overflow
+and misaligned or uninitialised-length accesses in the per-item code would show up."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def test_kernel_bodies_under_asan_and_ubsan():
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan in this toolchain")
+    env = dict(os.environ, BJJ_EMUL_SANITIZE="1", LD_PRELOAD=asan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_emul_bodies.py"), "-x", "-q",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=1500)
+    tail = r.stdout[-6000:]
+    assert r.returncode == 0, tail
+    assert "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout, tail
+    assert " passed" in r.stdout and "libbjj_emul_l0_san.so" in " ".join(os.listdir(os.path.join(ROOT, "tests", "emul")))
