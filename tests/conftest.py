@@ -28,7 +28,13 @@ class Oracle:
 
     def __init__(self):
         path = os.path.join(ROOT, "oracle", "libbjj_oracle.so")
-        if not os.path.exists(path):
+        if os.environ.get("BJJ_ORACLE_SANITIZE") == "1":   # tests/test_emul_sanitizers.py: the checker itself under ASan + UBSan
+            path = os.path.join(ROOT, "oracle", "libbjj_oracle_san.so")
+            src = os.path.join(ROOT, "oracle", "bjj_ref.c")
+            if not os.path.exists(path) or os.path.getmtime(src) > os.path.getmtime(path):
+                _sh(["gcc", "-O1", "-g", "-fPIC", "-std=gnu11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                     "-fno-omit-frame-pointer", "-shared", "-o", path, src, "-lpthread"], os.path.join(ROOT, "oracle"))
+        elif not os.path.exists(path):
             _sh(["make", "-s"], os.path.join(ROOT, "oracle"))
         self.lib = ctypes.CDLL(path)
         self.threads = min(os.cpu_count() or 1, 64)

@@ -25,3 +25,19 @@ def test_kernel_bodies_under_asan_and_ubsan():
     assert r.returncode == 0, tail
     assert "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout, tail
     assert " passed" in r.stdout and "libbjj_emul_l0_san.so" in " ".join(os.listdir(os.path.join(ROOT, "tests", "emul")))
+
+
+def test_c_oracle_under_asan_and_ubsan():
+    """the checker: oracle/bjj_ref.c against every reference KAT and the codec / sign / Schnorr vectors, sanitized"""
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan in this toolchain")
+    env = dict(os.environ, BJJ_ORACLE_SANITIZE="1", LD_PRELOAD=asan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    files = [os.path.join(ROOT, "tests", f) for f in ("test_oracle_kat.py", "test_codec.py", "test_sign.py", "test_schnorr.py")]
+    r = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"], cwd=ROOT,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    tail = r.stdout[-6000:]
+    assert r.returncode == 0, tail
+    assert "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout, tail
+    assert " passed" in r.stdout and os.path.exists(os.path.join(ROOT, "oracle", "libbjj_oracle_san.so"))
