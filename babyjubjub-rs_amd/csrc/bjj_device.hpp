@@ -178,11 +178,9 @@ BJJ_HD Niels niels_cneg_lazy(const Niels& n, bool neg) {
 struct GatherPerLane {
   struct Pending { Niels e; };
   static constexpr int kBuffers = 2;   // gathers that may be in flight at once
-  static constexpr bool kDeep = false; // no third request behind two pending ones (see GatherCoopLds)
   const u32* table;
   BJJ_HD void issue(size_t slot, Pending& p, int) const { p.e = load_niels(table + slot * NIELS_WORDS); }
   BJJ_HD Niels finish(Pending& p, int) const { return p.e; }
-  BJJ_HD Niels finish_keep(Pending& p, int) const { return p.e; }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BJJ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // nothing is scheduled across: keeps `finish` behind the addition
@@ -221,35 +219,6 @@ BJJ_HD Ext fixed_base_mul(const G& g, int W, int nwin, const u32 raw[8], const C
   u32 carry = 0;
   bool neg0, neg;
   typename G::Pending p0, p;
-  if constexpr (G::kDeep) {
-    // Two gathers in flight at all times: entry j+2 is requested BEFORE addition j (into the staging area entry j was read
-    // from: it lives in registers by then), entry j+1 was requested before addition j-1 -- a gather has two additions (~12 us
-    // of the SIMD's time) to arrive instead of one.  nwin >= 9.
-    bool nega, negb;
-    g.issue(fixed_digit_slot(sc, 0, W, carry, neg0), p, 0);
-    g.issue(fixed_digit_slot(sc, 1, W, carry, nega), p, 1);
-    const Niels n0 = niels_cneg_lazy(g.finish_keep(p, 0), neg0);
-    g.issue(fixed_digit_slot(sc, 2, W, carry, negb), p, 0);
-    Ext acc;
-    acc.X = fr_reduce_weak(fr_sub(n0.ypx, n0.ymx));
-    acc.Y = fr_add(n0.ypx, n0.ymx);
-    acc.Z = fr_add(fr_one(), fr_one()); acc.T = fr_add(n0.t2d, fr_zero());
-    BJJ_SCHED_FENCE();
-    Niels cur = niels_cneg_lazy(g.finish_keep(p, 1), nega);
-    nega = negb;
-#pragma unroll 1
-    for (int j = 1; j + 2 < nwin; j++) {
-      g.issue(fixed_digit_slot(sc, j + 2, W, carry, negb), p, j & 1);
-      acc = ext_madd(acc, cur);
-      BJJ_SCHED_FENCE();
-      cur = niels_cneg_lazy(g.finish_keep(p, (j + 1) & 1), nega);
-      nega = negb;
-    }
-    acc = ext_madd(acc, cur);                                       // addition nwin-2: nothing left to request
-    BJJ_SCHED_FENCE();
-    cur = niels_cneg_lazy(g.finish(p, (nwin - 1) & 1), nega);
-    return ext_madd<false>(acc, cur);
-  }
   g.issue(fixed_digit_slot(sc, 0, W, carry, neg0), p0, 0);
   const size_t slot1 = fixed_digit_slot(sc, 1, W, carry, neg);
   if (G::kBuffers >= 2) g.issue(slot1, p, 1);

@@ -149,20 +149,8 @@ struct GatherCoopLds {
                                        16, 0, 0);
     }
   }
-  // kDeep: the policy can keep TWO gathers in flight behind a finished one (fixed_base_mul requests entry j+2 before
-  // addition j).  finish_keep completes the OLDER of two outstanding gathers and leaves the younger one -- its 8 load
-  // instructions -- in flight: loads return in order, so "at most 8 vector-memory operations outstanding" means every load
-  // of the older gather has landed (a stray older store or younger scratch access only makes the wait longer, never shorter).
-#ifndef BJJ_K1_PREFETCH2
-#define BJJ_K1_PREFETCH2 0
-#endif
-  static constexpr bool kDeep = NBUF >= 2 && BJJ_K1_PREFETCH2;
-  __device__ __forceinline__ Niels finish_keep(Pending& p, int buf) const { return finish_t<8>(p, buf); }
-  __device__ __forceinline__ Niels finish(Pending& p, int buf) const { return finish_t<0>(p, buf); }
-  template <int KEEP>
-  __device__ __forceinline__ Niels finish_t(Pending&, int buf) const {
-    if (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __device__ __forceinline__ Niels finish(Pending&, int buf) const {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const U4* q = (const U4*)(wlds + (NBUF > 1 ? buf : 0) * FB_STAGE_WORDS + lane * NIELS_WORDS);
     const int x = (lane >> 1) & 7;
     const U4 a = q[0 ^ x], b = q[1 ^ x], c = q[2 ^ x], d = q[3 ^ x], e = q[4 ^ x], f = q[5 ^ x], h = q[6 ^ x];
