@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "bjj_point_add_dev", "bjj_reserve", "bjj_get_info", "bjj_check_table",
     "bjj_compress_points", "bjj_decompress_points", "bjj_eddsa_verify_compressed",
     "bjj_schnorr_verify", "bjj_schnorr_verify_dev",
-    "bjj_scalar_keys", "bjj_public_keys", "bjj_sign", "bjj_scalar_keys_dev", "bjj_public_keys_dev", "bjj_sign_dev",
+    "bjj_set_signer_constant_time", "bjj_scalar_keys", "bjj_public_keys", "bjj_sign", "bjj_scalar_keys_dev", "bjj_public_keys_dev", "bjj_sign_dev",
     "bjj_sign_schnorr", "bjj_sign_schnorr_dev",
     "bjj_compress_points_dev", "bjj_decompress_points_dev", "bjj_eddsa_verify_compressed_dev",
     "bjj_mul_var_base_wide", "bjj_mul_var_base_wide_dev", "bjj_proj_add", "bjj_proj_add_dev",
@@ -55,6 +55,7 @@ class BjjInfo(ctypes.Structure):
         ("kernel_poseidon5", ctypes.c_char_p),
         ("kernel_verify", ctypes.c_char_p),
         ("init_ms", ctypes.c_double),
+        ("signer_constant_time", ctypes.c_int),
     ]
 
 
@@ -124,6 +125,7 @@ def load():
     lib.bjj_point_add_dev.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.bjj_compress_points.argtypes = [vp, vp, sz, vp]
     lib.bjj_scalar_keys.argtypes = [vp, vp, sz, vp]
+    lib.bjj_set_signer_constant_time.argtypes = [vp, ci]
     lib.bjj_public_keys.argtypes = [vp, vp, sz, vp]
     lib.bjj_sign.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     lib.bjj_scalar_keys_dev.argtypes = [vp, vp, sz, vp, vp]

@@ -216,6 +216,11 @@ class Context:
         self._ck(self.lib.bjj_point_add(self.handle, a.ctypes.data, b.ctypes.data, n, out.ctypes.data), "bjj_point_add")
         return out.reshape(n, 64)
 
+    def set_signer_constant_time(self, on=True):
+        """signer hardening: public_keys / sign / sign_schnorr scan a small 4-bit table instead of indexing the big one
+        with secret digits -- no secret-dependent address or branch; bit-identical results, ~2x slower sign"""
+        self._ck(self.lib.bjj_set_signer_constant_time(self.handle, 1 if on else 0), "bjj_set_signer_constant_time")
+
     def scalar_keys(self, keys):
         a = _as_u8(keys, 32, "keys")
         n = a.size // 32

@@ -80,6 +80,10 @@ class Context {  // RAII over bjj_ctx (one GPU + stream + fixed-base table)
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   bjj_ctx* handle() const { return h_; }
+  // signer hardening (bjj_hip.h): no secret-dependent address or branch in public / sign / sign_schnorr; same results
+  void set_signer_constant_time(bool on) {
+    if (bjj_set_signer_constant_time(h_, on ? 1 : 0) != BJJ_OK) throw std::runtime_error(std::string("bjj_set_signer_constant_time: ") + bjj_last_error());
+  }
   static Context& global() { static Context c; return c; }
  private:
   bjj_ctx* h_ = nullptr;

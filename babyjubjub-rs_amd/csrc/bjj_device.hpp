@@ -182,6 +182,28 @@ struct GatherPerLane {
   BJJ_HD void issue(size_t slot, Pending& p, int) const { p.e = load_niels(table + slot * NIELS_WORDS); }
   BJJ_HD Niels finish(Pending& p, int) const { return p.e; }
 };
+//  * GatherScan (here; the signer's constant-time option): a lane reads EVERY entry of the window its slot lies in -- the
+//    addresses depend on the window index alone, never on the digit -- and keeps the one its digit names by arithmetic
+//    selection.  For the small table the signer builds for this purpose (4-bit windows: 9 entries of 128 B per window,
+//    73 KB in all, cache-resident); 9 loads + 8 x 27 selects per addition instead of one gather.
+struct GatherScan {
+  struct Pending { Niels e; };
+  static constexpr int kBuffers = 2;
+  const u32* table;
+  u32 stride;   // entries per window (fixed_stride(W))
+  BJJ_HD void issue(size_t slot, Pending& p, int) const {
+    const u32 s = (u32)slot, base = (s / stride) * stride, d = s - base;   // base = window index * stride: public
+    Niels e = load_niels(table + (size_t)base * NIELS_WORDS);
+#pragma unroll 1
+    for (u32 k = 1; k < stride; k++) {
+      const Niels t = load_niels(table + (size_t)(base + k) * NIELS_WORDS);
+      const bool hit = d == k;
+      e.ymx = fr_select(hit, t.ymx, e.ymx); e.ypx = fr_select(hit, t.ypx, e.ypx); e.t2d = fr_select(hit, t.t2d, e.t2d);
+    }
+    p.e = e;
+  }
+  BJJ_HD Niels finish(Pending& p, int) const { return p.e; }
+};
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BJJ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // nothing is scheduled across: keeps `finish` behind the addition
 #else

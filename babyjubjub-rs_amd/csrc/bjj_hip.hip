@@ -35,7 +35,7 @@
 
 using namespace bjj;
 
-#define BJJ_VERSION_STRING "bjj-hip 0.3.0 gfx950"
+#define BJJ_VERSION_STRING "bjj-hip 0.3.1 gfx950"
 // Fixed-base window width.  window_bits = 0 (default) is a modest 23 bits = 11 signed digits, 5.9 GB: a library that
 // is linked into a process with other tenants of the GPU must not take half of the HBM unasked.  The wide tables are
 // opt-in: an explicit width (28 bits = 9 digits, 9 x (2^27 + 1) entries = 154.6 GB of the 288 GB; 26 = 10 digits,
@@ -125,6 +125,12 @@ struct bjj_ctx {
   int occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
   int xccs = 1;                // XCDs of the device (probed at init; sizes the verify kernels' slot queues)
   int occ_decomp = 1, occ_sign = 1, occ_sign_schnorr = 1;
+  // signer hardening (bjj_set_signer_constant_time): a second, small fixed-base table (4-bit windows: 63 x 9 entries) that
+  // the signer kernels SCAN instead of indexing; built on first use
+  bool ct_signer = false;
+  u32* ct_table = nullptr;
+  u32* ct_bases = nullptr;
+  int occ_sign_ct = 1, occ_sign_schnorr_ct = 1;
   hipStream_t stream = nullptr;
   u32* table = nullptr;      // [window][digit 0 .. 2^(W-1)] x 128 B
   u32* bases = nullptr;      // P_j = 2^(W j) * B8, one Niels entry per window
@@ -395,6 +401,8 @@ static void ctx_destroy(bjj_ctx* c) {
   for (StreamMark& k : c->marks) if (k.ev) hipEventDestroy(k.ev);
   if (c->table) hipFree(c->table);
   if (c->bases) hipFree(c->bases);
+  if (c->ct_table) hipFree(c->ct_table);
+  if (c->ct_bases) hipFree(c->ct_bases);
   for (int b = 0; b < 2; b++) {
     if (c->pinned[b]) { secure_bzero(c->pinned[b], c->pipe_bytes); hipHostFree(c->pinned[b]); }
     if (c->dstage[b]) { hipMemset(c->dstage[b], 0, c->pipe_bytes); hipFree(c->dstage[b]); }
@@ -553,6 +561,7 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   info->kernel_poseidon5 = "bjj_k_poseidon5";
   info->kernel_verify = "bjj_k_eddsa_verify_groups";
   info->init_ms = c->init_ms;
+  info->signer_constant_time = c->ct_signer ? 1 : 0;
   const size_t fill = cap < sizeof(full) ? cap : sizeof(full);   // never past the caller's struct
   full.struct_size = (uint32_t)fill;
   memcpy(out, &full, fill);
@@ -763,6 +772,43 @@ int bjj_eddsa_verify_compressed_dev(bjj_ctx* c, const void* d_pk32, const void* 
   SET_LEAVE(c);
 }
 
+// ---- signer hardening ---------------------------------------------------------------------------------------------
+#define BJJ_CT_W 4
+static int ensure_ct_table(bjj_ctx* c) {
+  if (c->ct_table) return BJJ_OK;
+  ENTER_DEVICE(c->device);
+  const int nwin = fixed_nwin(BJJ_CT_W);
+  const size_t bytes = fixed_stride(BJJ_CT_W) * (size_t)nwin * NIELS_WORDS * sizeof(u32);
+  u32 *t = nullptr, *b = nullptr;
+  unsigned long long* d_bad = nullptr;
+  unsigned long long bad = 1;
+  hipError_t e = hipMalloc((void**)&t, bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&b, (size_t)nwin * NIELS_WORDS * sizeof(u32));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_bad, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), c->stream);
+  if (e == hipSuccess) e = bjjk::build_fixed_table(c->stream, t, b, BJJ_CT_W, nwin);
+  if (e == hipSuccess) e = bjjk::check_fixed_table(c->stream, 8, t, b, BJJ_CT_W, nwin, d_bad);   // the same induction proof as the big table
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (d_bad) hipFree(d_bad);
+  if (e != hipSuccess || bad != 0) {
+    if (t) hipFree(t);
+    if (b) hipFree(b);
+    return e != hipSuccess ? set_err(BJJ_E_HIP, std::string("constant-time signer table: ") + hipGetErrorString(e))
+                           : set_err(BJJ_E_HIP, "constant-time signer table failed its self-check");
+  }
+  c->ct_table = t; c->ct_bases = b;
+  c->occ_sign_ct = bjjk::occ_sign_ct();
+  c->occ_sign_schnorr_ct = bjjk::occ_sign_schnorr_ct();
+  return BJJ_OK;
+}
+int bjj_set_signer_constant_time(bjj_ctx* c, int on) {
+  CHECK_CTX(c, "bjj_set_signer_constant_time");
+  if (on) { int rc = ensure_ct_table(c); if (rc) return rc; }
+  c->ct_signer = on != 0;
+  return BJJ_OK;
+}
+
 int bjj_scalar_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out, void* stream) {
   CHECK_CTX(c, "bjj_scalar_keys_dev");
   if (n == 0) return BJJ_OK;
@@ -781,9 +827,14 @@ int bjj_public_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy
   // B8.mul_scalar(&self.scalar_key()), src/lib.rs:304-306; the scalar keys live in the codec scratch only for the
   // duration of the multiplication and are wiped on the same stream right behind it
   LAUNCHCK(bjjk::scalar_keys(st, grid_for(c, n, 4), (const uint8_t*)d_keys, n, S->codec), "scalar_keys");
-  const int kv = fixed_base_variant(c, S);
-  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, kv ? c->lanes_fixed_2x256 : c->lanes_fixed, kv, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy,
-                                S->scratch), "mul_fixed_base");
+  if (c->ct_signer) {
+    LAUNCHCK(bjjk::mul_fixed_base_scan(st, c->cus, c->ct_table, BJJ_CT_W, fixed_nwin(BJJ_CT_W), S->codec, n, (uint8_t*)d_out_xy, S->scratch),
+             "mul_fixed_base_scan");
+  } else {
+    const int kv = fixed_base_variant(c, S);
+    LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, kv ? c->lanes_fixed_2x256 : c->lanes_fixed, kv, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy,
+                                  S->scratch), "mul_fixed_base");
+  }
   HIPCK(hipMemsetAsync(S->codec, 0, n * 32, st));
   SET_LEAVE(c);
 }
@@ -796,6 +847,10 @@ int bjj_sign_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, v
   CHECK_PTR(d_out_s, "bjj_sign_dev");
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_sign_dev: d_ok is NULL");
   DEV_ENTER(c, stream);
+  if (c->ct_signer)
+    LAUNCHCK(bjjk::sign_ct(st, grid_for(c, n, c->occ_sign_ct), c->ct_table, BJJ_CT_W, fixed_nwin(BJJ_CT_W), (const uint8_t*)d_keys,
+                           (const uint8_t*)d_msgs, n, (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok), "bjj_sign_dev (constant-time)");
+  else
   LAUNCHCK(bjjk::sign(st, grid_for(c, n, c->occ_sign), c->table, c->W, c->nwin, (const uint8_t*)d_keys, (const uint8_t*)d_msgs, n,
                       (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok), "bjj_sign_dev");
   DEV_LEAVE(c);
@@ -810,6 +865,11 @@ int bjj_sign_schnorr_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, con
   CHECK_PTR(d_out_r, "bjj_sign_schnorr_dev"); CHECK_PTR(d_out_s, "bjj_sign_schnorr_dev");
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_sign_schnorr_dev: d_ok is NULL");
   DEV_ENTER(c, stream);
+  if (c->ct_signer)
+    LAUNCHCK(bjjk::sign_schnorr_ct(st, grid_for(c, n, c->occ_sign_schnorr_ct), c->ct_table, BJJ_CT_W, fixed_nwin(BJJ_CT_W), (const uint8_t*)d_keys,
+                                   (const uint8_t*)d_msgs, (const uint8_t*)d_nonces, n, (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok),
+             "bjj_sign_schnorr_dev (constant-time)");
+  else
   LAUNCHCK(bjjk::sign_schnorr(st, grid_for(c, n, c->occ_sign_schnorr), c->table, c->W, c->nwin, (const uint8_t*)d_keys,
                               (const uint8_t*)d_msgs, (const uint8_t*)d_nonces, n, (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok),
            "bjj_sign_schnorr_dev");

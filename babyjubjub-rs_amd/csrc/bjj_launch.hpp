@@ -46,6 +46,8 @@ hipError_t check_fixed_table(hipStream_t st, int grid, const uint32_t* table, co
                              unsigned long long* d_bad);
 hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant, const uint32_t* table, int W, int nwin,
                           const uint8_t* scalars, size_t n, uint8_t* out, uint32_t* scratch);
+hipError_t mul_fixed_base_scan(hipStream_t st, int cus, const uint32_t* table, int W, int nwin, const uint8_t* scalars, size_t n,
+                               uint8_t* out, uint32_t* scratch);   // constant-time form over the small 4-bit table
 // k_var.hip (sc_words: 32-bit words per scalar record, 8 for the 32-byte form)
 hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int variant, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
                         uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow, uint32_t* slotq, uint32_t slot_cap);
@@ -69,5 +71,12 @@ hipError_t sign(hipStream_t st, int grid, const uint32_t* table, int W, int nwin
                 uint8_t* out_r, uint8_t* out_s, uint8_t* ok);
 hipError_t sign_schnorr(hipStream_t st, int grid, const uint32_t* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs,
                         const uint8_t* nonces, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok);
+// the same with the scanning (constant-time) gather policy over the small 4-bit table; ct = true in the occupancy queries
+hipError_t sign_ct(hipStream_t st, int grid, const uint32_t* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n,
+                   uint8_t* out_r, uint8_t* out_s, uint8_t* ok);
+hipError_t sign_schnorr_ct(hipStream_t st, int grid, const uint32_t* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs,
+                           const uint8_t* nonces, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok);
+int occ_sign_ct();
+int occ_sign_schnorr_ct();
 
 }  // namespace bjjk

@@ -414,17 +414,18 @@ BJJ_HD_NOINLINE Fr fr_inv_gcd(const Fr& x) {
       top = hit ? i : top;
     }
     const int L = (top == 0) ? 0 : 32 - __builtin_clz(ah | bh);  // significant bits of the top limb
-    u64 xa, xb;
-    if (29 * top + L > 60) {
-      const u64 ha = ((u64)ah << 29) | al, hb = ((u64)bh << 29) | bl;  // L + 29 significant bits
-      const u64 ta = (L >= 2) ? (ha >> (L >= 2 ? L - 2 : 0)) : ((ha << 1) | (all_ >> 28));
-      const u64 tb = (L >= 2) ? (hb >> (L >= 2 ? L - 2 : 0)) : ((hb << 1) | (bll >> 28));
-      xa = (ta << 29) | a.v[0];
-      xb = (tb << 29) | b.v[0];
-    } else {  // both below 2^60: exact
-      xa = ((u64)a.v[2] << 58) | ((u64)a.v[1] << 29) | a.v[0];
-      xb = ((u64)b.v[2] << 58) | ((u64)b.v[1] << 29) | b.v[0];
-    }
+    // Both forms are computed and one is SELECTED: no branch of this function depends on the operand (the signer's
+    // constant-time option inverts a secret-derived Z product; the trip counts are fixed).
+    const bool big = 29 * top + L > 60, l2 = L >= 2;
+    const int sh = l2 ? L - 2 : 0;
+    const u64 ha = ((u64)ah << 29) | al, hb = ((u64)bh << 29) | bl;  // L + 29 significant bits
+    const u64 ta_s = ha >> sh, tb_s = hb >> sh;
+    const u64 ta_l = (ha << 1) | (all_ >> 28), tb_l = (hb << 1) | (bll >> 28);
+    const u64 ta = l2 ? ta_s : ta_l, tb = l2 ? tb_s : tb_l;
+    const u64 xa_big = (ta << 29) | a.v[0], xb_big = (tb << 29) | b.v[0];
+    const u64 xa_small = ((u64)a.v[2] << 58) | ((u64)a.v[1] << 29) | a.v[0];   // both below 2^60: exact
+    const u64 xb_small = ((u64)b.v[2] << 58) | ((u64)b.v[1] << 29) | b.v[0];
+    u64 xa = big ? xa_big : xa_small, xb = big ? xb_big : xb_small;
     // ---- 29 binary-GCD steps on the approximations, recording the transition matrix (|entries| <= 2^29)
     int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
 #pragma unroll 1
@@ -459,8 +460,8 @@ BJJ_HD_NOINLINE Fr fr_inv_gcd(const Fr& x) {
         b.v[i] = negb ? (ib & MASK29) : nb.v[i];
       }
     }
-    if (nega) { f0 = -f0; g0 = -g0; }
-    if (negb) { f1 = -f1; g1 = -g1; }
+    f0 = nega ? -f0 : f0; g0 = nega ? -g0 : g0;
+    f1 = negb ? -f1 : f1; g1 = negb ? -g1 : g1;
     // ---- (u, v) <- (u f0 + v g0 + qu r, u f1 + v g1 + qv r) / 2^29   (exact; signed, unreduced)
     const u32 lu = (u.v[0] * (u32)f0 + v.v[0] * (u32)g0) & MASK29;
     const u32 lv = (u.v[0] * (u32)f1 + v.v[0] * (u32)g1) & MASK29;

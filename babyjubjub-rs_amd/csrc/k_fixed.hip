@@ -82,6 +82,25 @@ __global__ void __launch_bounds__(BJJ_K1_BLOCK, BJJ_K1_MIN_BLOCKS) bjj_k_mul_fix
                                                                   uint8_t* __restrict__ out, u32* __restrict__ scratch) {
   mul_fixed_base_body<BJJ_K1_BLOCK, BJJ_K1_NBUF>(table, W, nwin, scalars, n, out, scratch);
 }
+// The signer's constant-time option (bjj_set_signer_constant_time; PrivateKey::public, src/lib.rs:304-306): the multiplication
+// through the scanning policy over the context's small 4-bit table -- no address depends on a digit of the scalar.
+__global__ void __launch_bounds__(BJJ_EPI_BLOCK, 1) bjj_k_mul_fixed_base_scan(const u32* __restrict__ table, int W, int nwin,
+                                                                        const uint8_t* __restrict__ scalars, size_t n,
+                                                                        uint8_t* __restrict__ out, u32* __restrict__ scratch) {
+  __shared__ u32 lds[NL * 64];
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const GatherScan fb = {table, (u32)fixed_stride(W)};
+  Fr run = fr_one();
+#pragma unroll 1
+  for (size_t i = tid; i < n; i += nthreads) {
+    u32 sc[8];
+    load_w8(scalars + i * 32, sc);
+    Ext p = fixed_base_mul(fb, W, nwin, sc, c_K);
+    epilogue_stash(p, run, out + i * 64, scratch + i * 16);
+  }
+  epilogue_run<BJJ_EPI_BLOCK>(run, n, tid, nthreads, out, scratch, lds);
+}
 __global__ void __launch_bounds__(256, 2) bjj_k_mul_fixed_base_2x256(const u32* __restrict__ table, int W, int nwin,
                                                                     const uint8_t* __restrict__ scalars, size_t n,
                                                                     uint8_t* __restrict__ out, u32* __restrict__ scratch) {
@@ -107,6 +126,14 @@ hipError_t build_fixed_table(hipStream_t st, u32* table, u32* bases, int W, int 
 hipError_t check_fixed_table(hipStream_t st, int grid, const u32* table, const u32* bases, int W, int nwin,
                              unsigned long long* d_bad) {
   hipLaunchKernelGGL(bjj_k_check_fixed_table, dim3((unsigned)grid), dim3(BJJ_BLOCK), 0, st, table, bases, W, nwin, d_bad);
+  return hipGetLastError();
+}
+hipError_t mul_fixed_base_scan(hipStream_t st, int cus, const u32* table, int W, int nwin, const uint8_t* scalars, size_t n,
+                               uint8_t* out, u32* scratch) {
+  const size_t want = (n + BJJ_EPI_BLOCK - 1) / BJJ_EPI_BLOCK;
+  const size_t cap = (size_t)cus * (size_t)occupancy_of(bjj_k_mul_fixed_base_scan, BJJ_EPI_BLOCK);
+  const int grid = (int)(want < cap ? (want ? want : 1) : cap);
+  hipLaunchKernelGGL(bjj_k_mul_fixed_base_scan, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
   return hipGetLastError();
 }
 hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant, const u32* table, int W, int nwin, const uint8_t* scalars,

@@ -92,6 +92,9 @@ def parse():
     ap.add_argument("--window-bits", type=int, default=28,
                     help="fixed-base window width passed to bjj_init (28 = 154.6 GB table; 0 = the library default, 23; -1 = auto)")
     ap.add_argument("--strong-total", type=int, default=1 << 24, help="total items of the cfg-5 strong-scaling line")
+    ap.add_argument("--signer-constant-time", action="store_true",
+                    help="bjj_set_signer_constant_time(ctx, 1): the signer workloads (sign) scan the small 4-bit table instead of "
+                         "indexing the fixed-base table with secret digits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workload lines")
     ap.add_argument("--no-strong", action="store_true", help="skip the fixed-total-work (strong scaling / cfg 5) lines")
@@ -679,6 +682,8 @@ def main():
             raise
         # the requested table does not fit next to the GPU's other tenants: take the widest that does, and say so in `config`
         ctx = bjj.Context(local_rank, bjj.WINDOW_AUTO)
+    if args.signer_constant_time:
+        ctx.set_signer_constant_time(True)
     n = args.batch
     ctx.reserve(max(n, 1))
     stream = torch.cuda.Stream(device=dev)
@@ -714,6 +719,7 @@ def main():
                        "init_ms": info.init_ms, "library_default_window_bits": 23,
                        "limbs": "9 x 29-bit, 64-bit column accumulators (v_mad_u64_u32)",
                        "warmup_seconds": args.warmup_seconds, "resident_batches": args.batches,
+                       "signer_constant_time": bool(info.signer_constant_time),
                        "parallelism": "independent shards, one process per GPU, no data-path collective"},
             "roofline": roofline_block(kind, kernel_ms, n, info),
         }

@@ -170,6 +170,15 @@ int bjj_eddsa_verify_compressed(bjj_ctx* ctx, const uint8_t* pk /* n*32 */, cons
  * reference returns Err ("msg outside the Finite Field", msg > Q, src/lib.rs:309-311; outputs zeroed);
  * out_s is the canonical integer s < l that Signature.s holds. */
 int bjj_scalar_keys(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, size_t n, uint8_t* out /* n*32 */);
+/* Signer hardening (off by default; the reference itself branches on secret bits, src/lib.rs:158).  By default the signer
+ * entry points (bjj_public_keys, bjj_sign, bjj_sign_schnorr and their _dev forms) index the context's fixed-base table with
+ * digits of the nonce and of the scalar key: gather addresses -- and with them cache / TLB / HBM-channel timing -- depend on
+ * secrets.  on = 1 switches them to a form in which NO memory address and NO branch depends on a secret: the two fixed-base
+ * multiplications run over a separate 4-bit-window table (73 KB, built on first use), every lane reads all nine entries
+ * of each window and selects by arithmetic; Blake-512, the mod-l arithmetic, the fixed-trip-count inversion and Poseidon
+ * (public inputs) were free of secret-dependent addresses already.  Results are bit-identical; cost: 62 additions instead of
+ * 8 per multiplication (bjj_sign about 2x slower).  The verifier entry points handle public data only and are unaffected. */
+int bjj_set_signer_constant_time(bjj_ctx* ctx, int on);
 int bjj_public_keys(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, size_t n, uint8_t* out_xy /* n*64 */);
 int bjj_sign(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, const uint8_t* msgs /* n*32 */, size_t n,
              uint8_t* out_r_xy /* n*64 */, uint8_t* out_s /* n*32 */, uint8_t* ok /* n */);
@@ -235,6 +244,7 @@ typedef struct {
   const char* kernel_poseidon5;
   const char* kernel_verify;
   double init_ms;           /* wall time of bjj_init (allocation + table build on the GPU) */
+  int signer_constant_time; /* bjj_set_signer_constant_time: 1 = the signer entry points scan a small table (see there) */
 } bjj_info;
 int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
 

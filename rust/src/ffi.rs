@@ -29,6 +29,7 @@ pub struct BjjInfo {
     pub kernel_poseidon5: *const c_char,
     pub kernel_verify: *const c_char,
     pub init_ms: f64,
+    pub signer_constant_time: c_int,
 }
 
 pub const BJJ_OK: c_int = 0;
@@ -64,6 +65,7 @@ extern "C" {
     pub fn bjj_decompress_points(ctx: *mut BjjCtx, input: *const u8, n: usize, out_xy: *mut u8, ok: *mut u8) -> c_int;
     pub fn bjj_eddsa_verify_compressed(ctx: *mut BjjCtx, pk: *const u8, sig: *const u8, msg: *const u8, n: usize, ok: *mut u8) -> c_int;
     pub fn bjj_scalar_keys(ctx: *mut BjjCtx, keys: *const u8, n: usize, out: *mut u8) -> c_int;
+    pub fn bjj_set_signer_constant_time(ctx: *mut BjjCtx, on: c_int) -> c_int;
     pub fn bjj_public_keys(ctx: *mut BjjCtx, keys: *const u8, n: usize, out_xy: *mut u8) -> c_int;
     pub fn bjj_sign(ctx: *mut BjjCtx, keys: *const u8, msgs: *const u8, n: usize, out_r_xy: *mut u8, out_s: *mut u8, ok: *mut u8) -> c_int;
     pub fn bjj_sign_schnorr(ctx: *mut BjjCtx, keys: *const u8, msgs: *const u8, nonces: *const u8, n: usize, out_r_xy: *mut u8, out_s: *mut u8, ok: *mut u8) -> c_int;

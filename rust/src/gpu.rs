@@ -47,6 +47,14 @@ impl Gpu {
         Ok(i)
     }
 
+    /// Signer hardening: `public_keys` / `sign` / `sign_schnorr` then scan a small 4-bit table instead of indexing the big
+    /// fixed-base table with digits of the nonce and of the scalar key -- no memory address and no branch depends on a
+    /// secret.  Results are bit-identical; `sign` costs about twice as much.  Off by default (the reference branches on
+    /// secret bits itself, src/lib.rs:158).  `BJJ_SIGNER_CONSTANT_TIME=1` turns it on for the thread's lazily created context.
+    pub fn set_signer_constant_time(&self, on: bool) -> Result<(), String> {
+        check(unsafe { ffi::bjj_set_signer_constant_time(self.ctx, on as c_int) }, "bjj_set_signer_constant_time")
+    }
+
     /// `B8.mul_scalar(n)` for every 32-byte scalar (reference src/lib.rs:149-164 with self = B8).
     pub fn mul_fixed_base(&self, scalars: &[u8]) -> Result<Vec<u8>, String> {
         let n = records(scalars, 32, "scalars")?;
@@ -207,7 +215,8 @@ fn records(bytes: &[u8], width: usize, name: &str) -> Result<usize, String> {
 
 thread_local! {
     /// The context behind the reference-shaped single-item API: created on first use, one per thread (a `bjj_ctx` is
-    /// used by one host thread at a time).  BJJ_DEVICE / BJJ_WINDOW_BITS select the device and the table width.
+    /// used by one host thread at a time).  BJJ_DEVICE / BJJ_WINDOW_BITS select the device and the table width,
+    /// BJJ_SIGNER_CONSTANT_TIME=1 the hardened signer.
     static GPU: RefCell<Option<Rc<Gpu>>> = RefCell::new(None);
 }
 
@@ -223,6 +232,9 @@ pub fn with_gpu<R>(f: impl FnOnce(&Gpu) -> R) -> R {
         if slot.is_none() {
             let g = Gpu::new(env_i32("BJJ_DEVICE", 0), env_i32("BJJ_WINDOW_BITS", 0))
                 .unwrap_or_else(|e| panic!("babyjubjub_rs (HIP): {}", e));
+            if env_i32("BJJ_SIGNER_CONSTANT_TIME", 0) != 0 {
+                g.set_signer_constant_time(true).unwrap_or_else(|e| panic!("babyjubjub_rs (HIP): {}", e));
+            }
             *slot = Some(Rc::new(g));
         }
         slot.as_ref().unwrap().clone()

@@ -67,6 +67,12 @@ void emul_fixed_base(const uint8_t* scalar, int W, uint8_t* out) {
   alignas(16) u32 sc[8]; memcpy(sc, scalar, 32);
   ext_out(fixed_base_mul(table_ptr(), g_W, g_nwin, sc, K), out);
 }
+// the signer's constant-time option: the same multiplication through the scanning policy (every entry of a window is read)
+void emul_fixed_base_scan(const uint8_t* scalar, int W, uint8_t* out) {
+  ensure_table(W);
+  alignas(16) u32 sc[8]; memcpy(sc, scalar, 32);
+  ext_out(fixed_base_mul(GatherScan{table_ptr(), (u32)fixed_stride(g_W)}, g_W, g_nwin, sc, K), out);
+}
 void emul_var_base(const uint8_t* pt, const uint8_t* scalar, uint8_t* out) {
   alignas(16) u32 w[8], sc[8]; alignas(16) static u32 tbl[VB_TABLE_WORDS];
   memcpy(w, pt, 32); Fr x = fr_to_mont_words(w);

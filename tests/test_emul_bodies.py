@@ -48,6 +48,23 @@ def test_emul_fixed_base_signed_digit_edges(emul, pyoracle):
             assert unpack(out.raw, 2)[0] == o.mul_scalar(o.B8, n % (1 << 256)), (W, hex(n))
 
 
+def test_emul_fixed_base_scanning_policy(emul, pyoracle, golden):
+    """GatherScan (the signer's constant-time option: all 9 entries of a 4-bit window are read, the digit selects
+    arithmetically) gives the same points as the indexed gather: golden vectors and the signed-digit edge scalars"""
+    o = pyoracle
+    out = ctypes.create_string_buffer(64)
+    l = o.SUBORDER
+    for c in golden["oracle_vectors"]["fixed_base"][::2]:
+        emul.emul_fixed_base_scan(le32(hexint(c["n"])), 4, out)
+        assert unpack(out.raw, 2)[0] == tuple(hexint(v) for v in c["out"]), c["n"]
+    for W in (4, 5):
+        half = 1 << (W - 1)
+        for n in (0, 1, half, half + 1, (1 << W) - 1, l - 1, l, l + 1, (1 << 256) - 1,
+                  sum(half << (W * j) for j in range(252 // W)) % l, sum((half + 1) << (W * j) for j in range(252 // W))):
+            emul.emul_fixed_base_scan(le32(n % (1 << 256)), W, out)
+            assert unpack(out.raw, 2)[0] == o.mul_scalar(o.B8, n % (1 << 256)), (W, hex(n))
+
+
 def test_emul_var_base_golden(emul, golden):
     out = ctypes.create_string_buffer(64)
     for c in golden["oracle_vectors"]["var_base"]:

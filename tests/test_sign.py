@@ -111,3 +111,57 @@ def test_gpu_sign_random_vs_oracle_and_roundtrip(gpu_ctx, oracle):
     idx = np.arange(0, m, 2053)
     ro, so, _ = oracle.sign(keys[idx], msgs[idx])
     assert (r[idx] == ro).all() and (s[idx] == so).all()
+
+
+@pytest.mark.gpu
+def test_gpu_constant_time_signer_is_bit_identical(golden, oracle):
+    """bjj_set_signer_constant_time: public_keys / sign / sign_schnorr through the scanning policy over the small 4-bit table
+    (no secret-dependent address or branch) give exactly the bytes of the indexed form and of the oracle -- golden vectors, the
+    circomlib KAT (src/lib.rs:689-738), random batches with partially filled waves, msg edge cases; the flag is reported by
+    bjj_get_info and can be switched off again."""
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    ctx = bjj.Context(0, 16)
+    try:
+        assert ctx.info().signer_constant_time == 0
+        sg, keys, msgs = _sign_rows(golden)
+        plain = (ctx.sign(keys, msgs), ctx.public_keys(keys))
+        ctx.set_signer_constant_time(True)
+        assert ctx.info().signer_constant_time == 1
+        r, s, ok = ctx.sign(keys, msgs)
+        assert (r == plain[0][0]).all() and (s == plain[0][1]).all() and (ok == plain[0][2]).all()
+        assert [bool(v) for v in ok] == [c["ok"] for c in sg]
+        assert (r.reshape(-1) == pack([tuple(c["r_b8"]) for c in sg])).all() and (s.reshape(-1) == pack([c["s"] for c in sg])).all()
+        assert (ctx.public_keys(keys) == plain[1]).all()
+        assert (ctx.public_keys(keys).reshape(-1) == pack([tuple(c["pk"]) for c in sg])).all()
+        v = golden["reference_kats"]["circomlib_testvector"]
+        key = np.frombuffer(bytes.fromhex(v["key"]), np.uint8).reshape(1, 32)
+        r1, s1, ok1 = ctx.sign(key, pack([v["msg"]]).reshape(1, 32))
+        assert ok1[0] == 1 and unpack(r1[0], 2)[0] == tuple(v["r_b8"]) and unpack(s1[0])[0] == v["s"]
+        assert unpack(ctx.public_keys(key)[0], 2)[0] == tuple(v["pk"])
+        for n in (1, 63, 65, 1000, 5000):
+            keys = w.random_u256(w.SEED_KEYS ^ 0x5151, n, offset=n)
+            msgs = w.random_u256(w.SEED_MSGS ^ 0x5151, n, offset=n, top_bits_cleared=3)
+            if n > 8:
+                msgs[5] = 0
+                msgs[6] = np.frombuffer(le32(Q), np.uint8)
+                msgs[7] = np.frombuffer(le32(Q + 1), np.uint8)
+            r, s, ok = ctx.sign(keys, msgs)
+            ro, so, oko = oracle.sign(keys, msgs)
+            assert (ok == oko).all() and (r == ro).all() and (s == so).all(), n
+            pk = ctx.public_keys(keys)
+            assert (pk == oracle.public_keys(keys)).all(), n
+            assert (ctx.eddsa_verify(pk, r, s, msgs) == ok).all()
+        # Schnorr: unreduced s and R against the indexed form
+        rng = np.random.default_rng(99)
+        n = 777
+        keys = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8); msgs[:, 31] &= 0x1f
+        nonces = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+        ct = ctx.sign_schnorr(keys, msgs, nonces)
+        ctx.set_signer_constant_time(False)
+        assert ctx.info().signer_constant_time == 0
+        ix = ctx.sign_schnorr(keys, msgs, nonces)
+        assert all((a == b).all() for a, b in zip(ct, ix)) and ct[2].all()
+    finally:
+        ctx.close()
