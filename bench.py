@@ -730,7 +730,7 @@ def main():
         if cb:
             result["cpu_baseline"] = cb
     del wl
-    hl = Headline(rank, result, float(os.environ.get("BJJ_BENCH_OPTIONAL_DEADLINE_S", "420")))
+    hl = Headline(rank, result, float(os.environ.get("BJJ_BENCH_OPTIONAL_DEADLINE_S", "240")))
     hl.parity = parity
     try:
         parity, devices = optional_sections(args, hl, ctx, bjj, kind, n, rank, local_rank, world, dev, red_dev, stream, stream_b,
