@@ -12,11 +12,15 @@ orc = conftest.Oracle()
 bad = 0
 # every kernel form: the per-call defaults of a one-stream caller (K1 one workgroup per CU, K2 tiles, verify groups), then the
 # forms a caller only gets while launches overlap or for very large batches, forced through the environment
+# ...; the second pass also runs the signer in its constant-time form (bjj_set_signer_constant_time)
 for forms in ({}, {"BJJ_K1_VARIANT": "1", "BJJ_K2_VARIANT": "0", "BJJ_VERIFY_DISPATCH": "0"}):
     os.environ.update(forms)
     ctx = bjj.Context(0, int(os.environ.get("W", "0")))   # default table (23 bits); W=28 for the benchmark table
     for k in forms:
         del os.environ[k]
+    if forms:
+        ctx.set_signer_constant_time(True)
+        forms = dict(forms, signer_constant_time=1)
     fails = 0
     for seed in range(first, first + count):
         try:
