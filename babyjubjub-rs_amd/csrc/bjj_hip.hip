@@ -190,6 +190,16 @@ static bool other_launch_in_flight(bjj_ctx* c, const ScratchSet* mine) {
   (void)hipGetLastError();   // hipErrorNotReady is not an error
   return false;
 }
+// A launch of more than 2^21 items gains nothing from sharing the chip with another launch of the context (its partly empty last
+// round is a fraction of a percent) but would lose the kernel form that is best for a launch that runs alone (persistent verify
+// waves, K2 tiles: 2-4 % at >= 2^22 items, profiles/r03_throughput_vs_batch.txt).  Such a launch therefore queues BEHIND the other
+// scratch sets' last calls (a device-side wait, no host synchronisation) and is then enqueued as a launch that runs alone.
+#define BJJ_LARGE_LAUNCH ((size_t)1 << 21)
+static int wait_for_other_sets(bjj_ctx* c, const ScratchSet* mine, hipStream_t st) {
+  for (const ScratchSet& S : c->set)
+    if (&S != mine && S.have_last && S.last_stream != st) HIPCK(hipStreamWaitEvent(st, S.ev_last, 0));
+  return BJJ_OK;
+}
 // K1 comes in two shapes (k_fixed.hip): one 512-lane workgroup per CU, or two of 256 lanes.  The second is for overlapping
 // launches: each launch then occupies one workgroup slot per CU and the other launch's main loop covers its inversion.
 static int fixed_base_variant(bjj_ctx* c, const ScratchSet* S) {
@@ -632,7 +642,9 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
   if (!d_pts || !d_scalars || !d_out || !aligned16(d_pts) || !aligned16(d_scalars) || !aligned16(d_out))
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   SET_ENTER(c, stream, n, false);
-  const int kv = c->k2_variant >= 0 ? c->k2_variant : (other_launch_in_flight(c, S) ? 0 : 1);   // k_var.hip: the two forms of K2
+  bool busy2 = other_launch_in_flight(c, S);
+  if (busy2 && c->k2_variant < 0 && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; busy2 = false; }
+  const int kv = c->k2_variant >= 0 ? c->k2_variant : (busy2 ? 0 : 1);   // k_var.hip: the two forms of K2
   LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, kv, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
                               (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)),
            "bjj_mul_var_base_dev");
@@ -665,9 +677,10 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
     HIPCK(hipEventCreateWithFlags(&S->ev_scan_out, hipEventDisableTiming));
   }
   const int scan_grid = grid_for(c, n, c->occ_scan, 64) * 64 / bjjk::verify_scan_block();   // occ_scan counts waves
-  const bool busy = other_launch_in_flight(c, S);
+  bool busy = other_launch_in_flight(c, S);
+  if (busy && c->verify_mode < 0 && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; busy = false; }
   // k_verify.hip: persistent waves for ONE large launch that runs alone, one group per workgroup otherwise
-  const int mode = c->verify_mode >= 0 ? c->verify_mode : ((!busy && n > ((size_t)1 << 21)) ? 0 : 1);
+  const int mode = c->verify_mode >= 0 ? c->verify_mode : ((!busy && n > BJJ_LARGE_LAUNCH) ? 0 : 1);
   if (busy) {   // the chip is (about to be) full of another launch's workgroups: priority stream
     HIPCK(hipEventRecord(S->ev_scan_in, st));
     HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));

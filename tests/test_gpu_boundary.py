@@ -225,6 +225,50 @@ def test_overlapping_launches_on_two_and_three_streams_use_separate_scratch_sets
         ctx.close()
 
 
+def test_large_launches_on_two_streams_queue_behind_each_other(oracle):
+    """Launches of more than 2^21 items do not share the chip with another launch of the context: they queue behind the other
+    scratch set's last call (device-side wait) and run in the form of a launch that runs alone (persistent verify waves, K2
+    tiles).  Two streams alternating large and small launches: every verdict of every launch, sampled points, nothing stale."""
+    import torch
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    dev = torch.device("cuda", 0)
+    ctx = bjj.Context(0, 16)
+    try:
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)  # noqa: E731
+        sizes = [(1 << 21) + 4099, (1 << 21) + 64, 70001]      # two large batches, one small
+        batches = []
+        for b, n in enumerate(sizes):
+            keys = w.random_u256(w.SEED_KEYS, n, offset=b << 22)
+            msg = w.random_u256(w.SEED_MSGS, n, offset=b << 22, top_bits_cleared=3)
+            A = ctx.public_keys(keys)
+            R, S, okf = ctx.sign(keys, msg)
+            assert okf.all()
+            bad = w.corrupt(A, R, S, msg, n, offset=b << 22)
+            sc = w.scalars_254(n, offset=5 + (b << 22))
+            batches.append(dict(n=n, A=A, sc=sc, bad=bad, d=[up(A), up(R), up(S), up(msg)], d_sc=up(sc),
+                                d_ok=torch.zeros(n, dtype=torch.uint8, device=dev), d_out=torch.zeros(n * 64, dtype=torch.uint8, device=dev)))
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        order = [(0, 0), (1, 1), (2, 0), (1, 1), (0, 0), (2, 1)]   # (batch, stream): large / large / small / large / large / small
+        for rnd in range(2):
+            for B in batches:
+                B["d_ok"].fill_(7); B["d_out"].zero_()
+            torch.cuda.synchronize()
+            for b, si in order:
+                B, st = batches[b], streams[si].cuda_stream
+                ctx.eddsa_verify_dev(*[t.data_ptr() for t in B["d"]], B["n"], B["d_ok"].data_ptr(), st)
+                ctx.mul_var_base_dev(B["d"][0].data_ptr(), B["d_sc"].data_ptr(), B["n"], B["d_out"].data_ptr(), st)
+            ctx.sync()
+            for b, B in enumerate(batches):
+                assert (B["d_ok"].cpu().numpy() == (~B["bad"]).astype(np.uint8)).all(), (rnd, b)
+                idx = np.arange(b, B["n"], 4099)
+                got = B["d_out"].cpu().numpy().reshape(B["n"], 64)[idx]
+                assert (got == oracle.mul_var_base(B["A"][idx], B["sc"][idx])).all(), (rnd, b)
+    finally:
+        ctx.close()
+
+
 def test_entry_points_leave_the_callers_current_device_alone(oracle):
     """every entry point selects its context's device and restores the calling thread's current device on return"""
     import torch
