@@ -102,6 +102,7 @@ struct ScratchSet {
   hipStream_t last_stream = nullptr;
   bool have_last = false;
   uint64_t last_use = 0;
+  uint64_t last_set_use = 0;   // value of bjj_ctx::set_uses when this set was taken last
 };
 struct StreamMark {
   hipStream_t stream = nullptr;
@@ -141,6 +142,7 @@ struct bjj_ctx {
   // with the head of the next launch instead of idling it.  A single-stream caller only ever touches (and allocates) set 0.
   ScratchSet set[BJJ_SCRATCH_SETS];
   uint64_t use_counter = 0;
+  uint64_t set_uses = 0;         // calls that took a scratch set (streams_alternate)
   // calls that use no scratch (Poseidon, point add, codec, sign) are not ordered behind anything; their completion
   // events are only kept so that bjj_sync can wait for them: one slot per distinct caller stream
   StreamMark marks[BJJ_STREAM_MARKS];
@@ -181,13 +183,26 @@ static int set_leave(bjj_ctx* c, ScratchSet* S, hipStream_t st) {
   S->last_stream = st;
   S->have_last = true;
   S->last_use = ++c->use_counter;
+  S->last_set_use = ++c->set_uses;
   return BJJ_OK;
 }
 // Is a launch of this context that uses ANOTHER scratch set still queued or running?  (event query: no synchronisation)
+// hipEventQuery leaves hipErrorNotReady as the thread's last error; it is cleared on EVERY path so that a launcher that reads
+// hipGetLastError() after its launch never reports it.
 static bool other_launch_in_flight(bjj_ctx* c, const ScratchSet* mine) {
+  bool busy = false;
   for (const ScratchSet& S : c->set)
-    if (&S != mine && S.have_last && hipEventQuery(S.ev_last) == hipErrorNotReady) return true;
+    if (&S != mine && S.have_last && hipEventQuery(S.ev_last) == hipErrorNotReady) busy = true;
   (void)hipGetLastError();   // hipErrorNotReady is not an error
+  return busy;
+}
+// Does the caller ALTERNATE over streams (one scratch set each)?  True when another set took one of the last
+// BJJ_SCRATCH_SETS calls that used scratch.  Unlike the event query above this does not depend on how far the device has got
+// when the host enqueues: a caller that ping-pongs over two streams gets the same kernel shape for every launch of the run,
+// a one-stream caller never sees it (profiles/r04_driver_protocol.txt).
+static bool streams_alternate(const bjj_ctx* c, const ScratchSet* mine) {
+  for (const ScratchSet& S : c->set)
+    if (&S != mine && S.have_last && c->set_uses - S.last_set_use < BJJ_SCRATCH_SETS) return true;
   return false;
 }
 // A launch of more than 2^21 items gains nothing from sharing the chip with another launch of the context (its partly empty last
@@ -201,10 +216,12 @@ static int wait_for_other_sets(bjj_ctx* c, const ScratchSet* mine, hipStream_t s
   return BJJ_OK;
 }
 // K1 comes in two shapes (k_fixed.hip): one 512-lane workgroup per CU, or two of 256 lanes.  The second is for overlapping
-// launches: each launch then occupies one workgroup slot per CU and the other launch's main loop covers its inversion.
+// launches: each launch then occupies one workgroup slot per CU and the other launch's main loop covers its inversion.  It is
+// picked from the caller's PATTERN (streams_alternate), not from a racy look at the device: under the 20-launch protocol of
+// the round-end bench the per-call event query gave the first launches of a run the wrong shape.
 static int fixed_base_variant(bjj_ctx* c, const ScratchSet* S) {
   if (c->k1_variant >= 0) return c->k1_variant;
-  return other_launch_in_flight(c, S) ? 1 : 0;
+  return streams_alternate(c, S) ? 1 : 0;
 }
 // completion mark of a call that used no scratch (bjj_sync waits for these)
 static int mark_stream(bjj_ctx* c, hipStream_t st) {
@@ -539,17 +556,26 @@ int bjj_sync(bjj_ctx* c) {
 }
 void* bjj_stream(bjj_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-int bjj_reserve(bjj_ctx* c, size_t n) {
-  if (!c) return set_err(BJJ_E_INVALID, "bjj_reserve: ctx is NULL");
+// Sizes the first `sets` scratch sets for n items (the codec records only on request).  bjj_reserve is the public form: set 0
+// plus whatever a second stream has already brought into use.  The multi-GPU pipeline calls this with sets = 2 before it
+// enqueues anything when a peer's block travels in more than one piece -- pieces alternate over two streams, and the second
+// set must not be allocated (hipMalloc, a synchronous copy of the slot queues) in the middle of the pipeline.
+static int reserve_sets(bjj_ctx* c, size_t n, int sets, bool with_codec) {
   ENTER_DEVICE(c->device);
-  for (ScratchSet& S : c->set) {   // set 0, and every further set a second stream has already brought into use
-    if (&S != &c->set[0] && !S.have_last) continue;
+  int k = 0;
+  for (ScratchSet& S : c->set) {
+    const bool wanted = k < sets || S.have_last;
+    k++;
+    if (!wanted) continue;
     int rc = ensure_scratch(c, &S, n ? n : 1); if (rc) return rc;
-    rc = ensure_codec(c, &S, n ? n : 1); if (rc) return rc;
+    if (with_codec) { rc = ensure_codec(c, &S, n ? n : 1); if (rc) return rc; }
   }
   return BJJ_OK;
 }
-
+int bjj_reserve(bjj_ctx* c, size_t n) {
+  if (!c) return set_err(BJJ_E_INVALID, "bjj_reserve: ctx is NULL");
+  return reserve_sets(c, n, 1, true);
+}
 int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   if (!c || !out) return set_err(BJJ_E_INVALID, "bjj_get_info: NULL argument");
   const size_t cap = out->struct_size;

@@ -14,6 +14,11 @@
 
 using namespace bjj;
 
+// Every launcher returns hipGetLastError() right after its launch.  That call reports the thread's LAST error, which may be a
+// stale, harmless one (hipErrorNotReady of an event query): the slate is wiped before the launch so that the
+// status a launcher returns is the status of its own launch.
+#define BJJ_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static __constant__ Consts c_K = {
     BJJ_K_A, BJJ_K_D, BJJ_K_F, BJJ_K_FINV_PLAIN, BJJ_K_FINV, BJJ_K_L_R1, BJJ_K_L_R2, BJJ_K_DP, BJJ_K_D2P, BJJ_K_DPINV, BJJ_K_B8X, BJJ_K_B8Y, BJJ_K_TS_G, BJJ_K_HALFQ,
     BJJ_K_ORDER, BJJ_K_ORDER2, BJJ_K_ORDER4, BJJ_K_L, BJJ_K_L2, BJJ_K_L4,
@@ -177,14 +182,23 @@ __device__ __forceinline__ u32* slot_queue_of_this_xcd(u32* slotq, u32 cap_nx) {
   const u32 cap = cap_nx & 0xffffu, nx = cap_nx >> 16;
   return slotq + (size_t)(xcc_id() % nx) * (SLOTQ_HDR + cap);
 }
-// one thread takes / returns a slot
+// one thread takes / returns a slot.  Hand-over ordering: the holder's stores to its table slot are released
+// before the slot number is published (fence + the push), and the next holder acquires after its pop, so that nothing of the
+// previous holder can land on top of the new holder's table.  BJJ_SLOT_FENCE_SCOPE: "agent" is what the HIP memory model asks
+// for between workgroups; a slot never leaves its XCD (one L2), which is why this costs nothing measurable
+// (profiles/r04_ab_slot_fences.txt).
+#ifndef BJJ_SLOT_FENCE_SCOPE
+#define BJJ_SLOT_FENCE_SCOPE "agent"
+#endif
 __device__ __forceinline__ u32 slot_pop_one(u32* q, u32 cap) {
   const u32 t = atomicInc(&q[0], cap - 1u);            // ticket in [0, cap): wraps by itself
   u32 v;
   do { v = atomicExch(&q[SLOTQ_HDR + t], 0u); } while (v == 0u);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, BJJ_SLOT_FENCE_SCOPE);
   return v - 1u;
 }
 __device__ __forceinline__ void slot_push_one(u32* q, u32 cap, u32 slot) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, BJJ_SLOT_FENCE_SCOPE);
   const u32 t = atomicInc(&q[1], cap - 1u);
   while (atomicCAS(&q[SLOTQ_HDR + t], 0u, slot + 1u) != 0u) {}
 }

@@ -118,14 +118,14 @@ hipError_t build_fixed_table(hipStream_t st, u32* table, u32* bases, int W, int 
   size_t chain = entries >> 18;
   chain = chain < 4 ? 4 : (chain > 256 ? 256 : chain);
   const size_t chains = ((fixed_stride(W) + chain - 1) / chain) * (size_t)nwin;
-  hipLaunchKernelGGL(bjj_k_fixed_window_bases, dim3((nwin + 63) / 64), dim3(64), 0, st, bases, W, nwin);
-  hipLaunchKernelGGL(bjj_k_build_fixed_table, dim3((unsigned)((chains + BJJ_BLOCK - 1) / BJJ_BLOCK)), dim3(BJJ_BLOCK), 0, st,
+  BJJ_LAUNCH(bjj_k_fixed_window_bases, dim3((nwin + 63) / 64), dim3(64), 0, st, bases, W, nwin);
+  BJJ_LAUNCH(bjj_k_build_fixed_table, dim3((unsigned)((chains + BJJ_BLOCK - 1) / BJJ_BLOCK)), dim3(BJJ_BLOCK), 0, st,
                      table, bases, W, nwin, (u32)chain);
   return hipGetLastError();
 }
 hipError_t check_fixed_table(hipStream_t st, int grid, const u32* table, const u32* bases, int W, int nwin,
                              unsigned long long* d_bad) {
-  hipLaunchKernelGGL(bjj_k_check_fixed_table, dim3((unsigned)grid), dim3(BJJ_BLOCK), 0, st, table, bases, W, nwin, d_bad);
+  BJJ_LAUNCH(bjj_k_check_fixed_table, dim3((unsigned)grid), dim3(BJJ_BLOCK), 0, st, table, bases, W, nwin, d_bad);
   return hipGetLastError();
 }
 hipError_t mul_fixed_base_scan(hipStream_t st, int cus, const u32* table, int W, int nwin, const uint8_t* scalars, size_t n,
@@ -133,7 +133,7 @@ hipError_t mul_fixed_base_scan(hipStream_t st, int cus, const u32* table, int W,
   const size_t want = (n + BJJ_EPI_BLOCK - 1) / BJJ_EPI_BLOCK;
   const size_t cap = (size_t)cus * (size_t)occupancy_of(bjj_k_mul_fixed_base_scan, BJJ_EPI_BLOCK);
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  hipLaunchKernelGGL(bjj_k_mul_fixed_base_scan, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
+  BJJ_LAUNCH(bjj_k_mul_fixed_base_scan, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
   return hipGetLastError();
 }
 hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant, const u32* table, int W, int nwin, const uint8_t* scalars,
@@ -142,9 +142,9 @@ hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant
   const size_t want = (n + block - 1) / block, cap = (size_t)cus * (size_t)(lanes_per_cu / block);
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
   if (variant)
-    hipLaunchKernelGGL(bjj_k_mul_fixed_base_2x256, dim3(grid), dim3(256), 0, st, table, W, nwin, scalars, n, out, scratch);
+    BJJ_LAUNCH(bjj_k_mul_fixed_base_2x256, dim3(grid), dim3(256), 0, st, table, W, nwin, scalars, n, out, scratch);
   else
-    hipLaunchKernelGGL(bjj_k_mul_fixed_base, dim3(grid), dim3(BJJ_K1_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
+    BJJ_LAUNCH(bjj_k_mul_fixed_base, dim3(grid), dim3(BJJ_K1_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
   return hipGetLastError();
 }
 }  // namespace bjjk

@@ -84,24 +84,24 @@ namespace bjjk {
 int occ_poseidon5() { return occupancy_of(bjj_k_poseidon5, BJJ_BLOCK); }
 int occ_decompress() { return occupancy_of(bjj_k_decompress_points, BJJ_BLOCK); }
 hipError_t poseidon5(hipStream_t st, int grid, const uint8_t* in, size_t n, uint8_t* out) {
-  hipLaunchKernelGGL(bjj_k_poseidon5, dim3(grid), dim3(BJJ_BLOCK), 0, st, in, n, out);
+  BJJ_LAUNCH(bjj_k_poseidon5, dim3(grid), dim3(BJJ_BLOCK), 0, st, in, n, out);
   return hipGetLastError();
 }
 hipError_t compress_points(hipStream_t st, int grid, const uint8_t* in_xy, size_t n, uint8_t* out) {
-  hipLaunchKernelGGL(bjj_k_compress_points, dim3(grid), dim3(BJJ_BLOCK), 0, st, in_xy, n, out);
+  BJJ_LAUNCH(bjj_k_compress_points, dim3(grid), dim3(BJJ_BLOCK), 0, st, in_xy, n, out);
   return hipGetLastError();
 }
 hipError_t decompress_points(hipStream_t st, int grid, const uint8_t* in, size_t stride, size_t n, uint8_t* out_xy, uint8_t* ok,
                              uint8_t* out_s) {
-  hipLaunchKernelGGL(bjj_k_decompress_points, dim3(grid), dim3(BJJ_BLOCK), 0, st, in, stride, n, out_xy, ok, out_s);
+  BJJ_LAUNCH(bjj_k_decompress_points, dim3(grid), dim3(BJJ_BLOCK), 0, st, in, stride, n, out_xy, ok, out_s);
   return hipGetLastError();
 }
 hipError_t merge_codec_flags(hipStream_t st, int grid, uint8_t* ok, const uint8_t* f_pk, const uint8_t* f_r, size_t n) {
-  hipLaunchKernelGGL(bjj_k_merge_codec_flags, dim3(grid), dim3(BJJ_BLOCK), 0, st, ok, f_pk, f_r, n);
+  BJJ_LAUNCH(bjj_k_merge_codec_flags, dim3(grid), dim3(BJJ_BLOCK), 0, st, ok, f_pk, f_r, n);
   return hipGetLastError();
 }
 hipError_t scalar_keys(hipStream_t st, int grid, const uint8_t* keys, size_t n, uint8_t* out) {
-  hipLaunchKernelGGL(bjj_k_scalar_keys, dim3(grid), dim3(BJJ_BLOCK), 0, st, keys, n, out);
+  BJJ_LAUNCH(bjj_k_scalar_keys, dim3(grid), dim3(BJJ_BLOCK), 0, st, keys, n, out);
   return hipGetLastError();
 }
 }  // namespace bjjk

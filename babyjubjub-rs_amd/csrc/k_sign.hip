@@ -89,22 +89,22 @@ int occ_sign_ct() { return occupancy_of(bjj_k_sign_ct, BJJ_BLOCK); }
 int occ_sign_schnorr_ct() { return occupancy_of(bjj_k_sign_schnorr_ct, BJJ_BLOCK); }
 hipError_t sign(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n,
                 uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
-  hipLaunchKernelGGL(bjj_k_sign, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
+  BJJ_LAUNCH(bjj_k_sign, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
   return hipGetLastError();
 }
 hipError_t sign_ct(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n,
                    uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
-  hipLaunchKernelGGL(bjj_k_sign_ct, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
+  BJJ_LAUNCH(bjj_k_sign_ct, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
   return hipGetLastError();
 }
 hipError_t sign_schnorr(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs,
                         const uint8_t* nonces, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
-  hipLaunchKernelGGL(bjj_k_sign_schnorr, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, nonces, n, out_r, out_s, ok);
+  BJJ_LAUNCH(bjj_k_sign_schnorr, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, nonces, n, out_r, out_s, ok);
   return hipGetLastError();
 }
 hipError_t sign_schnorr_ct(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs,
                            const uint8_t* nonces, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
-  hipLaunchKernelGGL(bjj_k_sign_schnorr_ct, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, nonces, n, out_r, out_s, ok);
+  BJJ_LAUNCH(bjj_k_sign_schnorr_ct, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, nonces, n, out_r, out_s, ok);
   return hipGetLastError();
 }
 }  // namespace bjjk

@@ -227,34 +227,34 @@ hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int variant, 
   const size_t want = (n + BJJ_K2_BLOCK - 1) / BJJ_K2_BLOCK, cap = (size_t)cus * (size_t)(lanes_per_cu / BJJ_K2_BLOCK);
   if (variant == 1) {
   if (sc_words == 8)
-    hipLaunchKernelGGL(bjj_k_mul_var_base_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow,
+    BJJ_LAUNCH(bjj_k_mul_var_base_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow,
                        slotq, slot_cap);
   else
-    hipLaunchKernelGGL(bjj_k_mul_var_base_wide_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
+    BJJ_LAUNCH(bjj_k_mul_var_base_wide_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
                        vb_tables, slow, slotq, slot_cap);
   } else {
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
   if (sc_words == 8)
-    hipLaunchKernelGGL(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow);
+    BJJ_LAUNCH(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow);
   else
-    hipLaunchKernelGGL(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
+    BJJ_LAUNCH(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
                        vb_tables, slow);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bjj_k_mul_var_base_exact, dim3(grid_exact), dim3(64), 0, st, pts, scalars, sc_words, out, slow);
+  BJJ_LAUNCH(bjj_k_mul_var_base_exact, dim3(grid_exact), dim3(64), 0, st, pts, scalars, sc_words, out, slow);
   return hipGetLastError();
 }
 hipError_t point_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out) {
-  hipLaunchKernelGGL(bjj_k_point_add, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, q, n, out);
+  BJJ_LAUNCH(bjj_k_point_add, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, q, n, out);
   return hipGetLastError();
 }
 hipError_t proj_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out) {
-  hipLaunchKernelGGL(bjj_k_proj_add, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, q, n, out);
+  BJJ_LAUNCH(bjj_k_proj_add, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, q, n, out);
   return hipGetLastError();
 }
 hipError_t proj_affine(hipStream_t st, int grid, const uint8_t* p, size_t n, uint8_t* out) {
-  hipLaunchKernelGGL(bjj_k_proj_affine, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, n, out);
+  BJJ_LAUNCH(bjj_k_proj_affine, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, n, out);
   return hipGetLastError();
 }
 }  // namespace bjjk

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64, BJJ_VERIFY_MIN_BLOCKS) bjj_k_eddsa_verify_
 namespace bjjk {
 int probe_xccs(hipStream_t st, u32* d_word) {   // number of XCDs = highest XCC_ID seen by a few thousand workgroups + 1
   if (hipMemsetAsync(d_word, 0, sizeof(u32), st) != hipSuccess) return 0;
-  hipLaunchKernelGGL(bjj_k_probe_xcc, dim3(4096), dim3(64), 0, st, d_word);
+  BJJ_LAUNCH(bjj_k_probe_xcc, dim3(4096), dim3(64), 0, st, d_word);
   u32 h = 0;
   if (hipMemcpyAsync(&h, d_word, sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
   return (int)h;
@@ -195,7 +195,7 @@ int verify_scan_block() { return BJJ_SCAN_BLOCK; }
 hipError_t verify_scan(hipStream_t st, int grid_scan, const uint8_t* pk, const uint8_t* rb8, const uint8_t* msg, size_t n, u32* wl) {
   hipError_t e = hipMemsetAsync(wl, 0, WL_HDR * sizeof(u32), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bjj_k_eddsa_verify_scan, dim3(grid_scan), dim3(BJJ_SCAN_BLOCK), 0, st, pk, rb8, msg, n, wl);
+  BJJ_LAUNCH(bjj_k_eddsa_verify_scan, dim3(grid_scan), dim3(BJJ_SCAN_BLOCK), 0, st, pk, rb8, msg, n, wl);
   return hipGetLastError();
 }
 hipError_t verify_main(hipStream_t st, int mode, int grid, bool schnorr, const u32* table, int W, int nwin, const uint8_t* pk,
@@ -207,14 +207,14 @@ hipError_t verify_main(hipStream_t st, int mode, int grid, bool schnorr, const u
   const unsigned bulk_wgs = (unsigned)(nchunks < 32768 ? nchunks : 32768);    // one 64-item chunk each up to 2^21 items, strided beyond
   const unsigned groups = exact_wgs + bulk_wgs;
   if (schnorr)
-    hipLaunchKernelGGL(bjj_k_schnorr_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap, exact_wgs);
+    BJJ_LAUNCH(bjj_k_schnorr_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap, exact_wgs);
   else
-    hipLaunchKernelGGL(bjj_k_eddsa_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap, exact_wgs);
+    BJJ_LAUNCH(bjj_k_eddsa_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap, exact_wgs);
   } else {
   if (schnorr)
-    hipLaunchKernelGGL(bjj_k_schnorr_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+    BJJ_LAUNCH(bjj_k_schnorr_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
   else
-    hipLaunchKernelGGL(bjj_k_eddsa_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
+    BJJ_LAUNCH(bjj_k_eddsa_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
   }
   return hipGetLastError();
 }

@@ -596,7 +596,8 @@ def run_native_multi(args):
 # has never run over real multi-GPU RCCL (point-to-point groups of cfg 5's rank-0-resident shape).  Once the headline is
 # measured, a watchdog bounds everything that follows: if the optional sections raise on this rank, or are not finished by
 # the deadline (a rank stuck in a collective), rank 0 prints the headline line with what is complete plus a note, and every rank
-# leaves through os._exit -- no further collective, no destructor that could block on a wedged communicator.
+# leaves through os._exit(4) -- no further collective, no destructor that could block on a wedged communicator; the exit code
+# says that the run was cut short (3 stays reserved for a failed parity comparison).
 # ---------------------------------------------------------------------------------------------------------------
 class Headline:
     def __init__(self, rank, result, deadline_s):
@@ -634,7 +635,10 @@ class Headline:
         self.emit(note)
         sys.stderr.write("bench.py rank %d: %s\n" % (self.rank, note))
         sys.stderr.flush()
-        os._exit(0 if self.parity else 3)
+        # 3 = a parity comparison failed (no number published); 4 = the headline is complete and correct but an optional section
+        # raised or hung -- a process that has touched the GPU and is abandoned must not report success (CI, torchrun and the
+        # session scripts only see the exit code)
+        os._exit(4 if self.parity else 3)
 
     def _watch(self):
         if not self.done.wait(self.deadline_s):

@@ -1,5 +1,5 @@
 """bench.py prints its headline line even when an optional section (`also`, `strong`: the only code that talks point-to-point
-over multi-GPU RCCL) hangs or raises: the watchdog of bench.Headline.  CPU-only: the class is driven directly in a child
+over multi-GPU RCCL) hangs or raises: the watchdog of bench.Headline (exit code 4: the headline is printed, the run is not a success).  CPU-only: the class is driven directly in a child
 process (it leaves through os._exit)."""
 import json
 import os
@@ -48,7 +48,7 @@ def _run(mode, rank="0"):
 
 def test_hang_in_an_optional_section_still_prints_the_headline():
     r, js = _run("hang")
-    assert r.returncode == 0 and len(js) == 1 and "not reached" not in r.stdout
+    assert r.returncode == 4 and len(js) == 1 and "not reached" not in r.stdout
     j = js[0]
     assert j["value"] == 1.0 and j["parity_sample_ok"] is True and j["also"]["verify"]["value"] == 2.0
     assert "abandoned" in j["optional_sections"] and "abandoned" in r.stderr
@@ -56,12 +56,12 @@ def test_hang_in_an_optional_section_still_prints_the_headline():
 
 def test_other_ranks_leave_silently():
     r, js = _run("hang", "1")
-    assert r.returncode == 0 and js == [] and "not reached" not in r.stdout
+    assert r.returncode == 4 and js == [] and "not reached" not in r.stdout
 
 
 def test_exception_in_an_optional_section_still_prints_the_headline():
     r, js = _run("raise")
-    assert r.returncode == 0 and len(js) == 1 and "NCCL error" in js[0]["optional_sections"] and "not reached" not in r.stdout
+    assert r.returncode == 4 and len(js) == 1 and "NCCL error" in js[0]["optional_sections"] and "not reached" not in r.stdout
 
 
 def test_failed_parity_never_publishes_a_value():
