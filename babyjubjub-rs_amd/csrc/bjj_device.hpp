@@ -744,6 +744,12 @@ BJJ_HD Fr limbs_shift_up(const Fr& a, int k) {  // a * 2^(29 k), k in 0..8 (high
   }
   return r;
 }
+// The quotient estimate below is only an UNDER-estimate -- which is what keeps every step exact -- under IEEE-754 division and
+// multiplication: the (1 - 2^-48) factor covers two correctly rounded operations on 53-bit roundings of the operands, not an
+// approximate reciprocal.  -ffast-math / -freciprocal-math would break verdicts silently, so such a build does not compile.
+#if defined(__FAST_MATH__) || defined(__RECIPROCAL_MATH__)
+#error "bjj: build without -ffast-math / -freciprocal-math (euclid_partial_step relies on IEEE f64 division)"
+#endif
 // one "partial quotient" step of Euclid on (r0 >= r1 > 0): r0 -= q r1, |t0| += q |t1| with
 // 1 <= q <= floor(r0 / r1), where q = m * 2^(29 k) is the leading 29-bit digit of a 53-bit
 // floating-point UNDER-estimate of the quotient (so even a 2^250 quotient takes <= 9 steps)

@@ -182,13 +182,16 @@ __device__ __forceinline__ u32* slot_queue_of_this_xcd(u32* slotq, u32 cap_nx) {
   const u32 cap = cap_nx & 0xffffu, nx = cap_nx >> 16;
   return slotq + (size_t)(xcc_id() % nx) * (SLOTQ_HDR + cap);
 }
-// one thread takes / returns a slot.  Hand-over ordering: the holder's stores to its table slot are released
-// before the slot number is published (fence + the push), and the next holder acquires after its pop, so that nothing of the
-// previous holder can land on top of the new holder's table.  BJJ_SLOT_FENCE_SCOPE: "agent" is what the HIP memory model asks
-// for between workgroups; a slot never leaves its XCD (one L2), which is why this costs nothing measurable
-// (profiles/r04_ab_slot_fences.txt).
+// one thread takes / returns a slot.  Hand-over ordering: the holder's stores to its table slot are complete
+// before the slot number is published (fence + the push), and the next holder's accesses start after its pop (fence), so that
+// nothing of the previous holder can land on top of the new holder's table.
+// BJJ_SLOT_FENCE_SCOPE = "workgroup" (s_waitcnt vmcnt(0): the stores are acknowledged by the L2) is what ships: a slot never
+// leaves its XCD, i.e. holder and successor share ONE L2 -- the push / pop atomics and all table traffic meet there, vL1D is
+// write-through, and the successor reads only bytes it has itself written in this tenancy.  "agent" -- what the HIP memory model
+// asks for between workgroups in general -- adds an L2 write-back of every resident workgroup's dirty tables per hand-over and
+// costs verify 1.6 % (profiles/r04_ab_slot_fences.txt); it can be selected with -DBJJ_SLOT_FENCE_SCOPE='"agent"'.
 #ifndef BJJ_SLOT_FENCE_SCOPE
-#define BJJ_SLOT_FENCE_SCOPE "agent"
+#define BJJ_SLOT_FENCE_SCOPE "workgroup"
 #endif
 __device__ __forceinline__ u32 slot_pop_one(u32* q, u32 cap) {
   const u32 t = atomicInc(&q[0], cap - 1u);            // ticket in [0, cap): wraps by itself

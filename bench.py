@@ -74,6 +74,103 @@ T8 = (43427199139494910287867685301150878225247122488354515896978014048931641833
       4826523245007015323400664741523384119579596407052839571721035538011798951543)  # a point of order 8 (SURVEY.md 8d cfg 3)
 
 
+class GpuTelemetry:
+    """sclk / socket power / junction temperature of one HIP device, sampled from the amdgpu hwmon files in a background thread
+    (without the clock and the power in the line, numbers from different boxes cannot be compared -- this
+    path is power-capped, and the sustained clock differs from box to box and with how warm the package is).
+    Read-only sysfs; no root needed.  `window(t0, t1)` = statistics of the samples whose perf_counter timestamp lies in
+    [t0, t1]; when the region is too short to hold two samples the window is widened backwards (and says so)."""
+
+    def __init__(self, device_index, period_s=0.0005):
+        import ctypes
+        import glob
+        import threading
+        self.ok, self.why, self.samples, self.period = False, None, [], period_s
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+                raise RuntimeError("hipDeviceGetPCIBusId failed")
+            bus = buf.value.decode().lower()
+            hw = sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bus))
+            if not hw:
+                raise RuntimeError("no hwmon directory for %s" % bus)
+            self.dir, self.bus = hw[0], bus
+            lab = {}
+            for f in glob.glob(self.dir + "/*_label"):
+                lab[open(f).read().strip()] = f[:-len("_label")]
+            self.f_sclk = (lab.get("sclk") or self.dir + "/freq1") + "_input"
+            self.f_power = self.dir + ("/power1_input" if os.path.exists(self.dir + "/power1_input") else "/power1_average")
+            self.f_temp = (lab.get("junction") or self.dir + "/temp2") + "_input"
+            self.cap_w = None
+            try:
+                self.cap_w = int(open(self.dir + "/power1_cap").read()) / 1e6
+            except Exception:
+                pass
+            self._read()
+            self.ok = True
+        except Exception as e:   # no telemetry is not an error of the benchmark
+            self.why = "%s: %s" % (type(e).__name__, e)
+
+    def _read(self):
+        def rd(p):
+            try:
+                with open(p) as f:
+                    return float(f.read())
+            except Exception:
+                return float("nan")
+        return (time.perf_counter(), rd(self.f_sclk) / 1e6, rd(self.f_power) / 1e6, rd(self.f_temp) / 1e3)
+
+    def start(self):
+        import threading
+        if not self.ok or self._thread is not None:
+            return self
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._read())
+                if len(self.samples) > 400000:
+                    del self.samples[:200000]
+                time.sleep(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+
+    def window(self, t0, t1):
+        if not self.ok:
+            return {"available": False, "reason": self.why}
+        note = None
+        rows = [x for x in self.samples if t0 <= x[0] <= t1]
+        if len(rows) < 2:   # a 12 ms region may fall between two updates: take the last 50 ms up to its end
+            rows = [x for x in self.samples if t1 - 0.05 <= x[0] <= t1 + 0.002]
+            note = "timed region shorter than two samples: window widened to the 50 ms before its end"
+        if not rows:
+            return {"available": False, "reason": "no sample in the window"}
+        a = np.array([r[1:] for r in rows], dtype=np.float64)
+        a = a[~np.isnan(a).any(axis=1)] if len(a) else a
+        if not len(a):
+            return {"available": False, "reason": "hwmon files unreadable"}
+        out = {"available": True, "sclk_mhz": float(a[:, 0].mean()), "sclk_mhz_min": float(a[:, 0].min()),
+               "sclk_mhz_max": float(a[:, 0].max()), "socket_w": float(a[:, 1].mean()), "socket_w_max": float(a[:, 1].max()),
+               "junction_c": float(a[:, 2].mean()), "power_cap_w": self.cap_w, "samples": int(len(a)),
+               "window_ms": (rows[-1][0] - rows[0][0]) * 1e3,
+               "source": "sysfs hwmon of %s (freq1 = sclk, power1 = socket power, junction temperature), polled every ~%.1f ms "
+                         "by a host thread across the timed region" % (self.bus, self.period * 1e3)}
+        if note:
+            out["note"] = note
+        return out
+
+
+TELEMETRY = None   # set in main() (rank-local GPU)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,9 +443,11 @@ def timed_steps(wl, steps, warmup, world, warm_s=0.0, streams=None):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        dt = t1 - t0
         per = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
         wl.step_ms = per
+        wl.clock = TELEMETRY.window(t0, t1) if TELEMETRY else None
         return dt, float(np.mean(per))
     ev0 = torch.cuda.Event(enable_timing=True)
     ends = [torch.cuda.Event(enable_timing=True) for _ in sts]
@@ -365,9 +464,11 @@ def timed_steps(wl, steps, warmup, world, warm_s=0.0, streams=None):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    dt = t1 - t0
     dev_ms = max(ev0.elapsed_time(e) for e in ends)
     wl.step_ms = None
+    wl.clock = TELEMETRY.window(t0, t1) if TELEMETRY else None
     return dt, dev_ms / steps
 
 
@@ -442,20 +543,43 @@ def load_profile_json(name):
         return {}
 
 
+def source_hash_now():
+    """fingerprint of babyjubjub-rs_amd/csrc as it is in this tree (srchash.py); None if it cannot be computed"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "babyjubjub-rs_amd"))
+        import srchash
+        return srchash.tree_hash()
+    except Exception:
+        return None
+
+
+def profile_is_current(stored_hash):
+    """the committed counters are quoted only for the build they were taken from"""
+    now = source_hash_now()
+    return stored_hash is not None and now is not None and stored_hash == now
+
+
 def roofline_block(kind, kernel_ms, n, info):
     algo = ALGO_BYTES[kind] * n
     ach = algo / (kernel_ms * 1e-3) / 1e9
     tr = load_profile_json("hbm_traffic.json").get(kind, {})
     same_cfg = n == (1 << 20) and tr.get("window_bits") in (None, info.window_bits)
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-            "traffic": tr.get("bytes_per_launch") if same_cfg else None,
-            "traffic_source": ("static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, committed; "
-                               "not re-measured in this run)" % tr.get("source")) if same_cfg and tr else None,
-            "kernel": KERNEL[kind], "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": algo,
-            "note": "integer-ALU bound path (see DESIGN.md): HBM fraction is reported as measured"}
+    stale = bool(tr) and not profile_is_current(tr.get("source_hash"))
+    quote = same_cfg and bool(tr) and not stale
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+           "traffic": tr.get("bytes_per_launch") if quote else None,
+           "traffic_source": ("static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command at source fingerprint "
+                              "%s, committed; not re-measured in this run)" % (tr.get("source"), tr.get("source_hash"))) if quote else None,
+           "kernel": KERNEL[kind], "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": algo,
+           "note": "integer-ALU bound path (see DESIGN.md): HBM fraction is reported as measured"}
+    if stale:
+        out["stale_profile"] = True
+        out["stale_profile_note"] = ("profiles/hbm_traffic.json was taken at source fingerprint %s, this tree is %s: counters not "
+                                     "quoted (re-run tools/profile_r.sh + tools/summarize_profile.py)" % (tr.get("source_hash"), source_hash_now()))
+    return out
 
 
-def valu_block(kind, kernel_ms, n, info):
+def valu_block(kind, kernel_ms, n, info, clock=None):
     """The unit that actually bounds this path is VALU issue.  Peak = 1024 SIMDs x 2.4 GHz / (issue cycles per
     wave-instruction of THIS kernel's instruction mix): the static ISA histogram of the kernel (tools/isa_histogram.py ->
     profiles/isa_mix.json) weighted with the measured per-class issue cycles (profiles/r01_ubench_valu_rates.txt: 4.54 for
@@ -465,14 +589,29 @@ def valu_block(kind, kernel_ms, n, info):
     vi = tr.get("valu_insts_per_launch")
     if not vi or not mix or n != (1 << 20) or tr.get("window_bits") not in (None, info.window_bits):
         return None
+    if not profile_is_current(tr.get("source_hash")) or not profile_is_current(load_profile_json("isa_mix.json").get("_source_hash")):
+        return {"stale_profile": True, "frac": None,
+                "note": "the committed instruction counters / ISA mix describe another build (source fingerprint %s / %s, tree %s)"
+                        % (tr.get("source_hash"), load_profile_json("isa_mix.json").get("_source_hash"), source_hash_now())}
     cyc = mix["avg_issue_cycles_per_valu_inst"]
     peak = 1024 * 2.4 / cyc
     va = vi / (kernel_ms * 1e-3) / 1e9
-    return {"insts_per_launch": vi, "achieved": va, "peak": peak, "frac": va / peak, "unit": "G wave-instructions/s",
-            "avg_issue_cycles_per_inst": cyc, "quarter_rate_share": mix.get("quarter_rate_share"),
-            "note": "insts: static SQ_INSTS_VALU of the committed rocprofv3 PMC pass (%s) / live kernel time; peak: issue-cycle "
-                    "model from the kernel's static ISA mix (profiles/isa_mix.json) x measured per-class rates at the nominal "
-                    "2.4 GHz -- the sustained clock under the power cap is lower, see DESIGN.md" % tr.get("source")}
+    out = {"insts_per_launch": vi, "achieved": va, "peak": peak, "frac": va / peak, "unit": "G wave-instructions/s",
+           "avg_issue_cycles_per_inst": cyc, "quarter_rate_share": mix.get("quarter_rate_share"),
+           "note": "insts: static SQ_INSTS_VALU of the committed rocprofv3 PMC pass (%s) / live kernel time; peak: issue-cycle "
+                   "model from the kernel's static ISA mix (profiles/isa_mix.json) x measured per-class rates at the nominal "
+                   "2.4 GHz; frac_at_measured_clock prices the same ceiling at the sclk sampled across the timed region "
+                   "(the package runs into its power cap)" % tr.get("source")}
+    if clock and clock.get("available") and clock.get("sclk_mhz"):
+        out["clock_mhz"] = clock["sclk_mhz"]
+        out["peak_at_measured_clock"] = peak * clock["sclk_mhz"] / 2400.0
+        out["frac_at_measured_clock"] = va / out["peak_at_measured_clock"]
+    return out
+
+
+def one_stream_clock(extra):
+    """telemetry of the ONE-stream timed region -- the protocol roofline.kernel_ms_avg and valu are computed from"""
+    return (extra.get("single_stream") or {}).get("clock") or extra.get("clock")
 
 
 def step_stats(step_ms, n, world):
@@ -490,16 +629,16 @@ def measure(ctx, kind, n, offset, dev, stream, steps, warmup, warm_s, world, nb,
     see timed_steps) and the classic one-stream protocol is measured first and reported in extras["single_stream"]."""
     wl = Workload(ctx, kind, n, offset, dev, stream, nb=max(nb, 2 if stream2 is not None else 1))
     dt, kernel_ms = timed_steps(wl, steps, warmup, world, warm_s)
-    extra = {"streams": 1}
+    extra = {"streams": 1, "clock": wl.clock}
     if wl.step_ms:
         extra["per_launch_event_ms"] = step_stats(wl.step_ms, n, world)
     if stream2 is not None:
-        dt1, k1 = dt, kernel_ms
+        dt1, k1, clock1 = dt, kernel_ms, wl.clock
         dt, km2 = timed_steps(wl, steps, 2, world, 0.2, streams=[stream, stream2])
         # kernel_ms stays the ONE-launch time (per-launch HIP events on one stream): roofline / valu describe a launch, and the
         # rocprofv3 summaries profile exactly that; the overlapped protocol's device time per launch is reported next to it
-        extra = {"streams": 2, "device_ms_per_launch": km2,
-                 "single_stream": {"wall_s": dt1, "kernel_ms_avg": k1, "value_this_rank": n * steps / dt1,
+        extra = {"streams": 2, "device_ms_per_launch": km2, "clock": wl.clock,
+                 "single_stream": {"wall_s": dt1, "kernel_ms_avg": k1, "value_this_rank": n * steps / dt1, "clock": clock1,
                                    "per_launch_event_ms": extra.get("per_launch_event_ms")},
                  "streams_note": "timed launches alternate over two HIP streams; the context keeps one scratch set per stream, "
                                  "so consecutive launches overlap.  device_ms_per_launch = (first start .. last end over both "
@@ -515,6 +654,43 @@ def measure(ctx, kind, n, offset, dev, stream, steps, warmup, warm_s, world, nb,
     ok = wl.check_sample(orc)
     cb = cpu_baseline(kind, wl, orc) if with_cpu else None
     return wl, dt, kernel_ms, extra, ok, cb
+
+
+def host_api_block(ctx, n, orc):
+    """bjj_mul_fixed_base / bjj_eddsa_verify on HOST pointers (the signatures a Rust caller holding BigInts binds to,
+    include/bjj_hip.h): the call copies in, computes and copies out.  Caller buffers are allocated and touched before the
+    timed calls (no first-touch page faults inside them); best of a few calls, like tools/pcie_rates.py of round 1."""
+    from babyjubjub_rs_amd import workload as w
+    sc = np.ascontiguousarray(w.scalars_254(n)).reshape(-1)
+    out = np.zeros(n * 64, np.uint8)
+    ok = np.zeros(n, np.uint8)
+
+    def best(f, reps):
+        f()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t)
+        return min(ts)
+
+    t_fb = best(lambda: ctx._ck(ctx.lib.bjj_mul_fixed_base(ctx.handle, sc.ctypes.data, n, out.ctypes.data), "bjj_mul_fixed_base"), 5)
+    idx = np.unique(np.linspace(0, n - 1, 64).astype(np.int64))
+    good = bool((out.reshape(n, 64)[idx] == orc.mul_fixed_base(sc.reshape(n, 32)[idx])).all())
+    A = out.copy()                                   # n points of the group: used as pk and as R (verdicts are beside the point)
+    m = np.ascontiguousarray(w.random_u256(w.SEED_MSGS, n, 0, top_bits_cleared=3)).reshape(-1)
+    t_v = best(lambda: ctx._ck(ctx.lib.bjj_eddsa_verify(ctx.handle, A.ctypes.data, A.ctypes.data, sc.ctypes.data, m.ctypes.data, n,
+                                                        ok.ctypes.data), "bjj_eddsa_verify"), 3)
+    good = good and bool((ok[idx] == orc.verify(A.reshape(n, 64)[idx], A.reshape(n, 64)[idx], sc.reshape(n, 32)[idx],
+                                                m.reshape(n, 32)[idx])).all())
+    return {"note": "PCIe-inclusive: host pointers in, host pointers out (pageable caller memory, already touched); the library "
+                    "stages through pinned buffers in 2^18-item chunks on separate copy streams.  Reported beside the line, never "
+                    "as `value`.",
+            "fixed_base": {"value": n / t_fb, "unit": UNITS["fixed_base"], "ms_per_call": t_fb * 1e3, "items": n,
+                           "bytes_moved": n * 96, "entry_point": "bjj_mul_fixed_base"},
+            "verify": {"value": n / t_v, "unit": UNITS["verify"], "ms_per_call": t_v * 1e3, "items": n,
+                       "bytes_moved": n * 193, "entry_point": "bjj_eddsa_verify"},
+            "parity_sample_ok": good}
 
 
 def all_max(x, world, red_dev):
@@ -701,6 +877,8 @@ def main():
     orc = get_oracle()
     one_gpu = world == 1
     parity = True
+    global TELEMETRY
+    TELEMETRY = GpuTelemetry(local_rank).start()
 
     # ---- headline: weak scaling, every rank its own block(s) of the global batch
     wl, dt, kernel_ms, extra, ok, cb = measure(ctx, kind, n, rank * n, dev, stream, args.steps, args.warmup, args.warmup_seconds,
@@ -728,7 +906,10 @@ def main():
             "roofline": roofline_block(kind, kernel_ms, n, info),
         }
         result.update(extra)
-        vb = valu_block(kind, kernel_ms, n, info)
+        ck = extra.get("clock") or {}
+        result["clock_mhz"] = ck.get("sclk_mhz")      # sampled across the timed region that produced `value`
+        result["socket_w"] = ck.get("socket_w")
+        vb = valu_block(kind, kernel_ms, n, info, one_stream_clock(extra))
         if vb:
             result["valu"] = vb
         if cb:
@@ -748,6 +929,7 @@ def main():
     if rank == 0:
         result["devices"] = devices
     hl.emit()
+    TELEMETRY.stop()
     ctx.close()
     return 0 if parity else 3
 
@@ -772,7 +954,9 @@ def optional_sections(args, hl, ctx, bjj, kind, n, rank, local_rank, world, dev,
                             "unit": UNITS[k2], "steps": s2, "warmup": w2, "ms_per_step": d2m / s2 * 1e3, "batch_per_gpu": n,
                             "workload": WORKLOAD_TEXT[k2], "roofline": roofline_block(k2, km2, n, info), "parity_sample_ok": ok2}
                 also[k2].update(ex2)
-                vb2 = valu_block(k2, km2, n, info)
+                ck2 = ex2.get("clock") or {}
+                also[k2]["clock_mhz"], also[k2]["socket_w"] = ck2.get("sclk_mhz"), ck2.get("socket_w")
+                vb2 = valu_block(k2, km2, n, info, one_stream_clock(ex2))
                 if vb2:
                     also[k2]["valu"] = vb2
                 if cb2:
@@ -791,6 +975,12 @@ def optional_sections(args, hl, ctx, bjj, kind, n, rank, local_rank, world, dev,
                                                  "parity_sample_ok": ok23}
             del w23
             c23.close()
+
+        # PCIe-inclusive rates of the host-pointer API -- what a host holding its data in ordinary (pageable) memory gets from
+        # bjj_mul_fixed_base / bjj_eddsa_verify: chunked pinned-staging pipeline around the same kernels.  NEVER `value`.
+        if one_gpu and rank == 0:
+            also["host_api"] = host_api_block(ctx, n, orc)
+            parity = parity and also["host_api"]["parity_sample_ok"]
 
     hl.sections["also"] = also
     hl.parity = parity

@@ -9,7 +9,6 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def pytest_configure(config):
@@ -137,6 +136,12 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def pyoracle():
+    """The pure-Python oracle: CPU-side test infrastructure only.  No `-m gpu` test takes this fixture
+    (tests/test_golden_gpu_expected.py enforces it): on the GPU box expected values come from tests/golden/*.json and from
+    the C oracle.  oracle/ is put on sys.path here and nowhere else."""
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
     import bjj_oracle
     return bjj_oracle
 
@@ -144,7 +149,7 @@ def pyoracle():
 @pytest.fixture(scope="session")
 def golden():
     g = {}
-    for name in ("reference_kats", "oracle_vectors"):
+    for name in ("reference_kats", "oracle_vectors", "gpu_expected"):
         with open(os.path.join(ROOT, "tests", "golden", name + ".json")) as f:
             g[name] = json.load(f)
     return g
@@ -231,6 +236,13 @@ def pack(vals):
         for x in (v if isinstance(v, (tuple, list)) else (v,)):
             b += le32(int(x, 16) if isinstance(x, str) else x)
     return np.frombuffer(bytes(b), np.uint8).copy()
+
+
+def ints(v):
+    """fixture value -> int / tuple of ints (values are stored as hex strings or plain ints, points as 2-lists)"""
+    if isinstance(v, (list, tuple)):
+        return tuple(ints(x) for x in v)
+    return int(v, 16) if isinstance(v, str) else int(v)
 
 
 def unpack(arr, per_item=1):

@@ -9,6 +9,7 @@ from conftest import pack
 pytestmark = pytest.mark.gpu
 
 L = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+Q = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 N = 1 << 20
 
 
@@ -71,25 +72,31 @@ def test_cfg2_fixed_base_two_workgroup_shape_every_item(oracle, monkeypatch):
         ctx.close()
 
 
-def cfg3_points(gpu_ctx, pyoracle, n, offset=0):
+def _on_curve(x, y):
+    """A x^2 + y^2 == 1 + D x^2 y^2 (src/lib.rs:28-36): the workload generator's own sanity check, plain integers"""
+    return (168700 * x * x + y * y - 1 - 168696 * x * x * y * y) % Q == 0
+
+
+def cfg3_points(gpu_ctx, golden, n, offset=0):
     """SURVEY.md 8d cfg 3: P_i = k_i*B8 + c_i*T (k_i < l, c_i in 0..7, T of order 8: the full group), every 97th point
     pushed off the curve."""
     from babyjubjub_rs_amd import workload as w
     k = w.from_ints([v % L for v in w.to_ints(w.random_u256(w.SEED_POINTS, n, offset))])
     c = (w.splitmix64(w.SEED_POINTS ^ 0x77, n, offset) & np.uint64(7)).astype(np.int64)
-    tors = pack([pyoracle.mul_scalar(pyoracle.T8, j) for j in range(8)]).reshape(8, 64)
+    from conftest import ints
+    tors = pack([ints(t) for t in golden["gpu_expected"]["torsion_points"]]).reshape(8, 64)   # j * T8, j = 0..7
     pts = gpu_ctx.point_add(gpu_ctx.mul_fixed_base(k), tors[c]).copy()
     pts[::97, 0] ^= 1
     return pts
 
 
-def test_cfg3_var_base_1m_every_item(gpu_ctx, oracle, pyoracle):
+def test_cfg3_var_base_1m_every_item(gpu_ctx, oracle, golden):
     """configs[2]: 2^20 variable-base multiplications on random points of the whole group (cofactor components
     included) with every 97th point off the curve (exact-replay path), all outputs vs the oracle."""
     from babyjubjub_rs_amd import workload as w
-    pts = cfg3_points(gpu_ctx, pyoracle, N)
+    pts = cfg3_points(gpu_ctx, golden, N)
     idx = np.arange(0, N, 4099)
-    on = np.array([pyoracle.on_curve((int.from_bytes(pts[i, :32].tobytes(), "little"), int.from_bytes(pts[i, 32:].tobytes(), "little")))
+    on = np.array([_on_curve(int.from_bytes(pts[i, :32].tobytes(), "little"), int.from_bytes(pts[i, 32:].tobytes(), "little"))
                    for i in idx])
     assert (on == (idx % 97 != 0)).all()        # the generator did what it says (group points, off-curve every 97th)
     sc = w.scalars_254(N)
@@ -97,13 +104,13 @@ def test_cfg3_var_base_1m_every_item(gpu_ctx, oracle, pyoracle):
     assert _mismatches(got, oracle.mul_var_base(pts, sc)) == (0, [])
 
 
-def test_cfg3_var_base_both_kernel_forms_agree_on_every_item(gpu_ctx, pyoracle, monkeypatch):
+def test_cfg3_var_base_both_kernel_forms_agree_on_every_item(gpu_ctx, golden, monkeypatch):
     """K2 has two forms (k_var.hip): one 256-item tile per workgroup (what a launch that runs alone gets -- the form the test
     above compared with the oracle item by item) and the grid-strided resident set (picked while another launch of the context
     is in flight).  BJJ_K2_VARIANT forces one form for a context: both must agree on all 2^20 outputs, off-curve points included."""
     import babyjubjub_rs_amd as bjj
     from babyjubjub_rs_amd import workload as w
-    pts = cfg3_points(gpu_ctx, pyoracle, N)
+    pts = cfg3_points(gpu_ctx, golden, N)
     sc = w.scalars_254(N)
     got = {}
     for v in ("0", "1"):

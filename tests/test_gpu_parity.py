@@ -73,22 +73,22 @@ def test_empty_batches(gpu_ctx):
     assert gpu_ctx.eddsa_verify(e, e, e, e).shape == (0,)
 
 
-def _points(oracle, n, seed):
-    """cfg-3 points: k*B8 + c*T8 (whole group incl. torsion), via the oracle."""
+def _points(oracle, golden, n, seed):
+    """cfg-3 points: k*B8 + c*T8 (whole group incl. torsion), via the C oracle; the 8 torsion points are a fixture."""
     from babyjubjub_rs_amd import workload
-    import bjj_oracle as o
+    from conftest import ints
     ks = workload.random_u256(seed, n)
     base = oracle.mul_fixed_base(ks)
-    tors = [o.mul_scalar(o.T8, c) for c in range(8)]
+    tors = [ints(t) for t in golden["gpu_expected"]["torsion_points"]]
     cs = workload.splitmix64(seed ^ 0x55, n) & np.uint64(7)
     tp = pack([tors[int(c)] for c in cs]).reshape(n, 64)
     return oracle.point_add(base, tp)
 
 
-def test_var_base_random_full_group(gpu_ctx, oracle):
+def test_var_base_random_full_group(gpu_ctx, oracle, golden):
     from babyjubjub_rs_amd import workload
     n = 1536
-    pts = _points(oracle, n, workload.SEED_POINTS)
+    pts = _points(oracle, golden, n, workload.SEED_POINTS)
     sc = workload.random_u256(workload.SEED_SCALARS, n, offset=100)
     # edge rows: identity, order-2 point, off-curve garbage, zero scalar, huge scalars
     pts[0] = pack([(0, 1)]); pts[1] = pack([(0, Q - 1)]); pts[2] = 7; pts[3] = 0
@@ -120,10 +120,11 @@ def test_verify_random_with_corruption(gpu_ctx, oracle):
     assert (got[~bad] == 1).all() and (got[bad] == 0).all()
 
 
-def test_verify_msg_range_rule(gpu_ctx, oracle):
+def test_verify_msg_range_rule(gpu_ctx, oracle, golden):
     """msg > Q -> false; msg == Q accepted and hashed as 0 (src/lib.rs:396-399)."""
-    import bjj_oracle as o
-    A, R, S = o.sign_with_scalars(12345, 67890, 0)
+    from conftest import ints
+    c = golden["gpu_expected"]["msg_range_signature"]           # a valid signature of msg = 0 (tests/golden/make_gpu_expected.py)
+    A, R, S = ints(c["A"]), ints(c["R"]), ints(c["S"])
     msgs = [0, Q, Q + 1, (1 << 256) - 1, Q - 1]
     n = len(msgs)
     got = gpu_ctx.eddsa_verify(pack([A] * n), pack([R] * n), pack([S] * n), pack(msgs))
@@ -152,12 +153,12 @@ def test_fixed_base_other_window_widths(oracle, window_bits):
         ctx.close()
 
 
-def test_fixed_base_table_is_sound_and_signed_digit_edges(gpu_ctx, oracle, pyoracle):
+def test_fixed_base_table_is_sound_and_signed_digit_edges(gpu_ctx, oracle):
     """default-width table verified entry by entry on the device; scalars that stress the signed recoding
     (digits at +-2^(W-1), carry runs, values around l and 2^256) against the oracle."""
     assert gpu_ctx.check_table() == 0
     W = gpu_ctx.info().window_bits
-    l, half = pyoracle.SUBORDER, 1 << (W - 1)
+    l, half = L, 1 << (W - 1)
     nw = 252 // W
     cases = [0, 1, half, half + 1, (1 << W) - 1, 1 << W, l - 1, l, l + 1, 2 * l - 1, 8 * l, (1 << 256) - 1, (1 << 251) - 1,
              (1 << 251), sum(half << (W * j) for j in range(nw)) % l, sum((half + 1) << (W * j) for j in range(nw)),
@@ -360,13 +361,14 @@ def test_config0_bench_point_1k_scalars(gpu_ctx, oracle, golden):
     print("cfg0 output sha256:", hashlib.sha256(got.tobytes()).hexdigest())
 
 
-def test_verify_small_order_and_torsion_cases(gpu_ctx, oracle, pyoracle):
+def test_verify_small_order_and_torsion_cases(gpu_ctx, oracle, golden):
     """verdicts that hinge on the cofactor: pk of small order (8*hm*pk vanishes, so s*B8 == R decides),
     R or pk shifted by torsion points, s beyond l.  The GPU path multiplies the check by a short ODD v,
     which must not change any of these verdicts (verify)."""
     from babyjubjub_rs_amd import workload as w
-    o = pyoracle
-    tors = [o.mul_scalar(o.T8, c) for c in range(8)]          # the 8 points of order dividing 8
+    from conftest import ints
+    tors = [ints(t) for t in golden["gpu_expected"]["torsion_points"]]   # the 8 points of order dividing 8 (j * T8)
+    assert tors[0] == (0, 1) and tors[4] == (0, Q - 1)
     n = 96
     s_int = [v % (8 * L) for v in w.to_ints(w.random_u256(0x7075, n))]
     sB = oracle.mul_fixed_base(w.from_ints(s_int))
@@ -378,7 +380,8 @@ def test_verify_small_order_and_torsion_cases(gpu_ctx, oracle, pyoracle):
         if i % 3 == 0:      # small-order pk, R = s*B8           -> true
             pk.append(t1); R.append(sb); want_true.append(True)
         elif i % 3 == 1:    # small-order pk, R = s*B8 + torsion -> true only if the shift is the identity
-            pk.append(t1); R.append(o.proj_affine(o.proj_add(sb + (1,), t2 + (1,)))); want_true.append(t2 == (0, 1))
+            shifted = unpack(oracle.point_add(pack([sb]), pack([t2]))[0], 2)[0]     # s*B8 + torsion, src/lib.rs:88-131, 70-85
+            pk.append(t1); R.append(shifted); want_true.append(t2 == (0, 1))
         else:               # random pk: just compare with the oracle
             pk.append(unpack(sB[(i + 1) % n], 2)[0]); R.append(sb); want_true.append(None)
         S.append(s_int[i])

@@ -50,12 +50,12 @@ def test_mul_scalar(api):  # src/lib.rs:502-552
     assert p.mul_scalar(0).equals(api.Point(0, 1))
 
 
-def test_new_key_sign_verify(api, pyoracle):  # src/lib.rs:555-572 (signing is host-side oracle math here)
-    o = pyoracle
-    for msg in (5, 123456789012345678901234567890):
-        A, R, S = o.sign_with_scalars(0x1234567890abcdef1234567890abcdef % o.SUBORDER, 0xfeedface12345, msg)
+def test_new_key_sign_verify(api, golden):  # src/lib.rs:555-572 (the signature is a fixture: tests/golden/make_gpu_expected.py)
+    from conftest import ints
+    for c in golden["gpu_expected"]["sign_with_scalars"]:
+        msg, A, R, S = ints(c["msg"]), ints(c["A"]), ints(c["R"]), ints(c["S"])
         pk = api.Point(*A)
-        assert pk.equals(api.Point(*api.B8).mul_scalar(0x1234567890abcdef1234567890abcdef % o.SUBORDER))
+        assert pk.equals(api.Point(*api.B8).mul_scalar(ints(c["k"])))
         sig = api.Signature(api.Point(*R), S)
         assert api.verify(pk, sig, msg) is True
         assert api.verify(pk, sig, msg + 1) is False

@@ -1,0 +1,88 @@
+"""The static counters bench.py quotes (profiles/hbm_traffic.json, profiles/isa_mix.json) are tied to the build they were
+taken from: a fingerprint of babyjubjub-rs_amd/csrc is stored next to them, and a tree that differs gets `traffic: null` +
+`stale_profile: true` instead of another build's numbers."""
+import json
+import os
+import shutil
+import sys
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "babyjubjub-rs_amd"))
+import srchash  # noqa: E402
+
+
+class _Info:
+    window_bits = 28
+
+
+def test_one_flipped_byte_of_a_kernel_source_changes_the_fingerprint(tmp_path):
+    dst = tmp_path / "csrc"
+    dst.mkdir()
+    for pat in srchash.PATTERNS:
+        import glob
+        for f in glob.glob(os.path.join(srchash.CSRC, pat)):
+            shutil.copy(f, dst)
+    h0 = srchash.tree_hash(str(dst))
+    assert h0 == srchash.tree_hash()                       # same files, same fingerprint
+    p = dst / "k_fixed.hip"
+    b = bytearray(p.read_bytes())
+    b[len(b) // 2] ^= 1
+    p.write_bytes(bytes(b))
+    assert srchash.tree_hash(str(dst)) != h0
+
+
+def test_bench_does_not_quote_counters_of_another_build(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = {"hbm_traffic.json": {"fixed_base": {"bytes_per_launch": 1.5e9, "source": "profiles/x.md", "batch": 1 << 20,
+                                                "valu_insts_per_launch": 2.5e8, "window_bits": 28, "source_hash": "feedfacefeedface"}},
+            "isa_mix.json": {"_source_hash": "feedfacefeedface",
+                             "bjj_k_mul_fixed_base": {"avg_issue_cycles_per_valu_inst": 4.0, "quarter_rate_share": 0.76}}}
+    monkeypatch.setattr(bench, "load_profile_json", lambda name: prof.get(name, {}))
+    # (a) the tree IS the profiled one: counters are quoted, and the valu block prices the ceiling at the measured clock too
+    monkeypatch.setattr(bench, "source_hash_now", lambda: "feedfacefeedface")
+    r = bench.roofline_block("fixed_base", 0.6, 1 << 20, _Info())
+    assert r["traffic"] == 1.5e9 and "stale_profile" not in r and "feedfacefeedface" in r["traffic_source"]
+    v = bench.valu_block("fixed_base", 0.6, 1 << 20, _Info(), {"available": True, "sclk_mhz": 2160.0})
+    assert abs(v["frac_at_measured_clock"] / v["frac"] - 2400.0 / 2160.0) < 1e-9 and v["clock_mhz"] == 2160.0
+    # (b) one byte of a kernel source flipped since: nothing static is published
+    monkeypatch.setattr(bench, "source_hash_now", lambda: "0123456789abcdef")
+    r = bench.roofline_block("fixed_base", 0.6, 1 << 20, _Info())
+    assert r["traffic"] is None and r["traffic_source"] is None and r["stale_profile"] is True
+    assert r["achieved"] > 0 and r["frac"] > 0                    # the live part of the block is unaffected
+    v = bench.valu_block("fixed_base", 0.6, 1 << 20, _Info())
+    assert v["stale_profile"] is True and v["frac"] is None and "insts_per_launch" not in v
+    # (c) a profile without any fingerprint (the pre-round-4 files) counts as stale
+    del prof["hbm_traffic.json"]["fixed_base"]["source_hash"]
+    monkeypatch.setattr(bench, "source_hash_now", lambda: "feedfacefeedface")
+    assert bench.roofline_block("fixed_base", 0.6, 1 << 20, _Info())["stale_profile"] is True
+
+
+def test_committed_profiles_carry_a_fingerprint_or_are_flagged():
+    """whatever is committed under profiles/ either matches this tree or bench.py says so"""
+    sys.path.insert(0, ROOT)
+    import bench
+    tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    for kind in ("fixed_base", "verify", "var_base"):
+        r = bench.roofline_block(kind, 1.0, 1 << 20, _Info())
+        current = tr.get(kind, {}).get("source_hash") == srchash.tree_hash()
+        assert (r["traffic"] is not None) == current and (r.get("stale_profile", False) is True) == (not current)
+
+
+def test_a_fast_math_build_does_not_compile(tmp_path):
+    """euclid_partial_step decides an exact-integer path with an IEEE f64 division: -ffast-math in an overriding CXXFLAGS must
+    fail the build instead of changing verdicts silently (the Makefile passes -fno-fast-math explicitly)."""
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    src = tmp_path / "t.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n#include "%s"\n' % os.path.join(srchash.CSRC, "bjj_device.hpp"))
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fsyntax-only", str(src)]
+    ok = subprocess.run(base, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert ok.returncode == 0, ok.stdout[-2000:]
+    bad = subprocess.run(base + ["-ffast-math"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert bad.returncode != 0 and "build without -ffast-math" in bad.stdout
+    assert "-fno-fast-math" in open(os.path.join(srchash.CSRC, "Makefile")).read()

@@ -31,7 +31,7 @@ def test_emul_schnorr_golden(emul, golden):
 
 
 @pytest.mark.gpu
-def test_gpu_schnorr_golden_and_random(gpu_ctx, oracle, pyoracle, golden):
+def test_gpu_schnorr_golden_and_random(gpu_ctx, oracle, golden):
     sc, pk, r, s, m = _rows(golden)
     assert list(gpu_ctx.schnorr_verify(pk, r, s, m)) == [c["ok"] for c in sc]
     # seeded random batch: valid signatures built from GPU kernels + host integers, some corrupted
@@ -54,14 +54,16 @@ def test_gpu_schnorr_golden_and_random(gpu_ctx, oracle, pyoracle, golden):
 
 
 @pytest.mark.gpu
-def test_gpu_reference_api_schnorr(gpu_ctx, pyoracle):
+def test_gpu_reference_api_schnorr(gpu_ctx, golden):
     """src/lib.rs:678-686 re-stated (nonce fixed instead of thread_rng)"""
     import babyjubjub_rs_amd as bjj
+    from conftest import ints
     bjj.api._DEFAULT = gpu_ctx
-    sk = bjj.PrivateKey(bytes(range(32)))
+    c = golden["gpu_expected"]["sign_schnorr_api"][0]                              # key 00..1f, nonce 2^1023 + 12345
+    sk = bjj.PrivateKey(bytes.fromhex(c["key"]))
     pk = sk.public()
-    msg = 123456789012345678901234567890
-    r, s = pyoracle.sign_schnorr_with_nonce(sk.key, msg, (1 << 1023) + 12345)      # host-side signer math
+    msg = ints(c["msg"])
+    r, s = ints(c["r"]), ints(c["s"])                                              # fixture: tests/golden/make_gpu_expected.py
     assert s.bit_length() > 1000
     assert bjj.verify_schnorr(pk, msg, bjj.Point(*r), s) is True                  # s reduced mod 8l by the mirror
     assert bjj.verify_schnorr(pk, msg + 1, bjj.Point(*r), s) is False
@@ -93,6 +95,20 @@ def _schnorr_expect(pyoracle, cases):
     return out
 
 
+def _schnorr_expect_golden(golden, cases):
+    """the same expectations from tests/golden/gpu_expected.json (what the GPU box gets); the inputs stored there must be
+    the seeded case list above"""
+    from conftest import ints
+    rows = golden["gpu_expected"]["sign_schnorr_cases"]
+    assert [(bytes.fromhex(r["key"]), ints(r["msg"]), ints(r["nonce"])) for r in rows] == cases
+    return [None if r["r"] is None else (ints(r["r"]), ints(r["s"])) for r in rows]
+
+
+def test_schnorr_fixture_is_what_the_python_oracle_computes(pyoracle, golden):
+    cases = _schnorr_sign_cases()
+    assert _schnorr_expect_golden(golden, cases) == _schnorr_expect(pyoracle, cases)
+
+
 def test_oracle_sign_schnorr_roundtrip(pyoracle):
     """the reference's own (and only) Schnorr test is sign -> verify == true, src/lib.rs:678-686"""
     for key, m, k in _schnorr_sign_cases()[:6]:
@@ -119,9 +135,9 @@ def test_emul_sign_schnorr(emul, pyoracle):
 
 
 @pytest.mark.gpu
-def test_gpu_sign_schnorr_vs_oracle_and_roundtrip(gpu_ctx, pyoracle, oracle):
+def test_gpu_sign_schnorr_vs_oracle_and_roundtrip(gpu_ctx, golden, oracle):
     cases = _schnorr_sign_cases()
-    want = _schnorr_expect(pyoracle, cases)
+    want = _schnorr_expect_golden(golden, cases)
     keys = np.frombuffer(b"".join(c[0] for c in cases), np.uint8).reshape(-1, 32)
     msgs = pack([c[1] for c in cases]).reshape(-1, 32)
     nonces = np.frombuffer(b"".join(c[2].to_bytes(128, "little") for c in cases), np.uint8).reshape(-1, 128)
@@ -155,15 +171,18 @@ def test_gpu_sign_schnorr_vs_oracle_and_roundtrip(gpu_ctx, pyoracle, oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_reference_api_sign_schnorr(gpu_ctx, pyoracle):
+def test_gpu_reference_api_sign_schnorr(gpu_ctx, golden):
     import babyjubjub_rs_amd as bjj
+    from conftest import ints
     sk = bjj.new_key()                                                           # lib.rs:387-393
     assert len(sk.key) == 32
     msg = 123456789012345678901234567890
     r, s = sk.sign_schnorr(msg)                                                  # random nonce, lib.rs:347-348
     assert bjj.verify_schnorr(sk.public(), msg, r, s) is True                    # lib.rs:678-686
-    r2, s2 = sk.sign_schnorr(msg, k=(1 << 1000) + 99)
-    want = pyoracle.sign_schnorr_with_nonce(sk.key, msg, (1 << 1000) + 99)
-    assert (r2.x, r2.y) == tuple(want[0]) and s2 == want[1]
+    c = golden["gpu_expected"]["sign_schnorr_api"][1]                            # key 00..1f, nonce 2^1000 + 99: a fixture
+    sk = bjj.PrivateKey.import_(bytes.fromhex(c["key"]))
+    assert ints(c["msg"]) == msg
+    r2, s2 = sk.sign_schnorr(msg, k=ints(c["nonce"]))
+    assert (r2.x, r2.y) == ints(c["r"]) and s2 == ints(c["s"])
     with pytest.raises(ValueError):
         sk.sign_schnorr(Q + 1)

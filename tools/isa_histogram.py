@@ -115,6 +115,9 @@ def main():
                 name[:34], tot, 100 * cls["mad64"] / tot, 100 * cls["quarter"] / tot, 100 * cls["plain"] / tot, avg, 1024 * 2.4 / avg,
                 h["other"]["scratch"], h["other"]["ds"] + h["other"]["global"]))
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    sys.path.insert(0, os.path.join(ROOT, "babyjubjub-rs_amd"))
+    import srchash
+    mix["_source_hash"] = srchash.tree_hash()   # bench.py quotes the mix only for the tree it was taken from
     json.dump(mix, open(os.path.join(ROOT, "profiles", "isa_mix.json"), "w"), indent=1, sort_keys=True)
     open(os.path.join(ROOT, "profiles", "%s_isa_mix.txt" % tag), "w").write("\n".join(table) + "\n")
     print("\n".join(table))

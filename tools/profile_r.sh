@@ -5,6 +5,7 @@ TAG=${1:-r01}; WL=${2:-fixed_base}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
+python3 babyjubjub-rs_amd/srchash.py > $OUT/source_hash.txt   # the tree these counters describe (tools/summarize_profile.py, bench.py)
 python3 bench.py --workload $WL --no-also --no-strong > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; tail -c 3000 $OUT/bench_$WL.json
 export TMPDIR=/tmp
 ARGS="bench.py --workload $WL --streams 1 --no-cpu-baseline --no-also --no-strong"   # same steps / warm-up as the default bench line; ONE stream: the profiler serialises launches anyway, and per-launch counters / durations mean one thing

@@ -4,6 +4,8 @@ profiles/<tag>_<workload>_summary.md and update profiles/hbm_traffic.json (read 
 import collections, csv, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "babyjubjub-rs_amd"))
+import srchash  # noqa: E402  (fingerprint of csrc/: bench.py refuses to quote counters of another build)
 tag, wl = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out", tag)
 KERNEL = {"fixed_base": "bjj_k_mul_fixed_base", "var_base": "bjj_k_mul_var_base_tiles", "verify": "bjj_k_eddsa_verify_groups",
@@ -71,7 +73,14 @@ with open(os.path.join(ROOT, "profiles", "%s_%s_summary.md" % (tag, wl)), "w") a
 tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 d = json.load(open(tj)) if os.path.exists(tj) else {}
 if traffic:
-    d[wl] = {"bytes_per_launch": traffic, "source": "profiles/%s_%s_summary.md" % (tag, wl), "batch": int(meta.get("Grid_Size", 0)) and 1 << 20}
+    # the tree must be the one that was profiled: run this tool before touching csrc/ again (gpurun_out/<tag>/source_hash.txt,
+    # written on the GPU box by tools/profile_r.sh, is checked against it)
+    hp = os.path.join(src, "source_hash.txt")
+    profiled = open(hp).read().strip() if os.path.exists(hp) else None
+    if profiled and profiled != srchash.tree_hash():
+        raise SystemExit("csrc/ changed since %s was profiled (%s != %s): re-profile" % (tag, profiled, srchash.tree_hash()))
+    d[wl] = {"bytes_per_launch": traffic, "source": "profiles/%s_%s_summary.md" % (tag, wl), "batch": int(meta.get("Grid_Size", 0)) and 1 << 20,
+             "source_hash": profiled or srchash.tree_hash()}
     if "SQ_INSTS_VALU" in counters:
         d[wl]["valu_insts_per_launch"] = counters["SQ_INSTS_VALU"][0]
     try:  # the window width the counters were collected with (bench.py only quotes them for the same configuration)
