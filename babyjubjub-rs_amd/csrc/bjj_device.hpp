@@ -156,6 +156,37 @@ BJJ_HD size_t fixed_digit_slot(const u32 sc[8], int j, int W, u32& carry, bool& 
   const u32 d = neg ? (1u << W) - u : u;
   return (size_t)j * fixed_stride(W) + d;
 }
+// The same digits as a STREAM (windows 0, 1, 2, .. in order): the scalar sits in a shift register of 8 words that moves down by
+// W bits per window, so that a window is always the low W bits of word 0 -- eight funnel shifts per window instead of two
+// 8-way selections of words by a run-time window index (what scalar_window costs inside a rolled loop: ~60 instructions
+// per window in K1; profiles/r04_ab_digit_stream.txt).  4 <= W <= 28.
+struct DigitStream {
+  u32 w[8];
+  u32 carry;
+  size_t base;      // slot of digit 0 of the current window
+  size_t stride;
+  u32 mask, half;
+  int W;
+};
+BJJ_HD DigitStream digit_stream(const u32 sc[8], int W) {
+  DigitStream d;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d.w[i] = sc[i];
+  d.carry = 0; d.base = 0; d.stride = fixed_stride(W); d.mask = (1u << W) - 1u; d.half = 1u << (W - 1); d.W = W;
+  return d;
+}
+BJJ_HD size_t digit_next(DigitStream& d, bool& neg) {
+  const u32 u = (d.w[0] & d.mask) + d.carry;
+  neg = u > d.half;
+  d.carry = neg ? 1u : 0u;
+  const u32 dig = neg ? (d.mask + 1u) - u : u;
+  const size_t slot = d.base + dig;
+  d.base += d.stride;
+#pragma unroll
+  for (int i = 0; i < 7; i++) d.w[i] = (d.w[i] >> d.W) | (d.w[i + 1] << (32 - d.W));   // v_alignbit_b32
+  d.w[7] >>= d.W;
+  return slot;
+}
 // -(x', y) = (-x', y): swap y-x' / y+x', negate 2D'x'y.  The negation stays carry-less (limbs < 2^30): the entry
 // only ever feeds one multiplication whose other operand is N-form.
 BJJ_HD Niels niels_cneg_lazy(const Niels& n, bool neg) {
@@ -213,15 +244,15 @@ struct GatherScan {
 // acc + sc * B8, sc < l.  The result's T is not computed (callers only compare or convert X, Y, Z).
 template <class G>
 BJJ_HD Ext fixed_base_accumulate(Ext acc, const G& g, int W, int nwin, const u32 sc[8], const Consts& K) {
-  u32 carry = 0;
+  DigitStream ds = digit_stream(sc, W);
   bool neg;
   typename G::Pending p;
-  g.issue(fixed_digit_slot(sc, 0, W, carry, neg), p, 0);
+  g.issue(digit_next(ds, neg), p, 0);
   Niels cur = niels_cneg_lazy(g.finish(p, 0), neg);
   cur.t2d = fr_mul(cur.t2d, K.DP);                                 // window 0 is stored in T form
 #pragma unroll 1
   for (int j = 0; j + 1 < nwin; j++) {
-    g.issue(fixed_digit_slot(sc, j + 1, W, carry, neg), p, (j + 1) & 1);  // in flight during this window's 7 multiplications
+    g.issue(digit_next(ds, neg), p, (j + 1) & 1);                  // in flight during this window's 7 multiplications
     acc = ext_madd(acc, cur);
     BJJ_SCHED_FENCE();
     cur = niels_cneg_lazy(g.finish(p, (j + 1) & 1), neg);
@@ -238,11 +269,11 @@ template <class G>
 BJJ_HD Ext fixed_base_mul(const G& g, int W, int nwin, const u32 raw[8], const Consts& K) {
   u32 sc[8];
   scalar_mod_l(raw, sc, K);
-  u32 carry = 0;
+  DigitStream ds = digit_stream(sc, W);
   bool neg0, neg;
   typename G::Pending p0, p;
-  g.issue(fixed_digit_slot(sc, 0, W, carry, neg0), p0, 0);
-  const size_t slot1 = fixed_digit_slot(sc, 1, W, carry, neg);
+  g.issue(digit_next(ds, neg0), p0, 0);
+  const size_t slot1 = digit_next(ds, neg);
   if (G::kBuffers >= 2) g.issue(slot1, p, 1);
   const Niels n0 = niels_cneg_lazy(g.finish(p0, 0), neg0);
   if (G::kBuffers < 2) g.issue(slot1, p, 1);
@@ -254,7 +285,7 @@ BJJ_HD Ext fixed_base_mul(const G& g, int W, int nwin, const u32 raw[8], const C
   Niels cur = niels_cneg_lazy(g.finish(p, 1), neg);
 #pragma unroll 1
   for (int j = 1; j + 1 < nwin; j++) {
-    g.issue(fixed_digit_slot(sc, j + 1, W, carry, neg), p, (j + 1) & 1);
+    g.issue(digit_next(ds, neg), p, (j + 1) & 1);
     acc = ext_madd(acc, cur);
     BJJ_SCHED_FENCE();
     cur = niels_cneg_lazy(g.finish(p, (j + 1) & 1), neg);
@@ -769,7 +800,11 @@ BJJ_HD void euclid_partial_step(Fr& r0, const Fr& r1, Fr& t0, const Fr& t1) {
   }
 }
 // u (>= 0), |v|, sign(v) with u == v*kappa (mod l), v odd and != 0 (mod l); kappa plain canonical < l
+#ifdef BJJ_EXP_LATTICE_NOINLINE   // experiment (profiles/r04_verify_register_file.txt): the Euclid phase as a real call
+BJJ_HD_NOINLINE void lattice_short_pair(const Fr& kappa, Fr& u, Fr& vmag, bool& vneg, const Consts& K) {
+#else
 BJJ_HD void lattice_short_pair(const Fr& kappa, Fr& u, Fr& vmag, bool& vneg, const Consts& K) {
+#endif
   Fr r0 = K.L, r1 = kappa, t0 = fr_zero(), t1 = fr_one_plain();
   bool s1 = false;  // sign of t1; t0 has the opposite sign (or is 0)
   while (limbs_ge_2p126(r1)) {
@@ -849,6 +884,12 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* 
   else         { h[0] = rx; h[1] = ry; h[2] = ax; h[3] = ay; }  // :400
   Fr hm = poseidon5_t<true>(h, K);                              // :400-404
   Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));           // canonical integer, :406
+#ifdef BJJ_EXP_RELOAD_INPUTS   // experiment: the four coordinates are re-read (4 multiplications) instead of living through the hash
+  load_w8(in.r, w);                    rx = fr_to_mont_words(w);
+  load_w8((const char*)in.r + 32, w);  ry = fr_to_mont_words(w);
+  load_w8(in.pk, w);                   ax = fr_to_mont_words(w);
+  load_w8((const char*)in.pk + 32, w); ay = fr_to_mont_words(w);
+#endif
   u32 sw[8];
   load_w8(in.s, sw);
   int verdict;

@@ -115,12 +115,14 @@ BJJ_HD PNiels ext_to_pniels(const Ext& p, const Consts& K) {
   n.t2d = fr_mul(p.T, K.D2P); n.z2 = fr_dbl(p.Z);
   return n;
 }
-// conditional negation: -(x,y) = (-x,y)  => swap ymx/ypx, negate t2d
+// conditional negation: -(x,y) = (-x,y)  => swap ymx/ypx, negate t2d.  The negation stays carry-less (limbs < 2^30, value
+// < 4r): the entry's t2d only ever feeds ONE multiplication whose other operand (T, or the constant 1/D') is N-form -- 9
+// subtractions instead of 9 + a 24-instruction carry sweep, twice per window of the windowed loops.  Entries: t2d N-form < 4r.
 BJJ_HD PNiels pniels_cneg(const PNiels& n, bool neg) {
   PNiels r;
   r.ymx = fr_select(neg, n.ypx, n.ymx);
   r.ypx = fr_select(neg, n.ymx, n.ypx);
-  r.t2d = fr_select(neg, fr_neg(n.t2d), n.t2d);
+  r.t2d = fr_select(neg, fr_sub_lazy(fr_zero(), n.t2d), n.t2d);
   r.z2 = n.z2;
   return r;
 }

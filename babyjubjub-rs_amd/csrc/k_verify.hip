@@ -138,7 +138,11 @@ __device__ __forceinline__ void verify_group_body(const u32* __restrict__ table,
   const u32 cap = cap_nx & 0xffffu;
   const u32 slot = slot_pop(q, cap, lane);
   u32* tbl = vb_tables + ((size_t)slot * 64 + lane) * VB_VERIFY_WORDS;
+#ifdef BJJ_EXP_NO_EXACT_IN_BULK   // experiment (resource usage only: the exact path out of the bulk kernel's allocation)
+  if (false) {
+#else
   if (exact) {
+#endif
 #pragma unroll 1
     for (size_t c = b * 64; c < nexact; c += (size_t)exact_wgs * 64) {
       if (c + lane < nexact) {

@@ -742,13 +742,24 @@ def run_native_multi(args):
             mean = lambda k: float(np.mean([t[k] for t in tim]))  # noqa: E731
             return {"value": n * steps / dt, "ms_per_step": dt / steps * 1e3, "scatter_ms": mean("scatter_ms"),
                     "compute_ms": mean("compute_ms"), "gather_ms": mean("gather_ms"), "total_ms": mean("total_ms"),
-                    "chunks": tim[-1]["chunks"], "rccl_version": tim[-1]["rccl_version"]}
+                    "wall_ms": mean("wall_ms"), "chunks": tim[-1]["chunks"], "rccl_version": tim[-1]["rccl_version"]}
         serial = timed(1)                 # scatter everything -> kernels -> gather everything
         piped = timed(args.chunks)        # peer blocks in pieces, transfers behind the kernels
         ok = wl.check_sample(orc)
         ok_all = ok_all and ok
+        # reference point: the same batch as ONE launch of the first context (no handle, no blocks, no transfers)
+        wl.launch(0)
+        stream.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            wl.launch(0)
+        stream.synchronize()
+        dt1 = time.perf_counter() - t0
+        ok1 = wl.check_sample(orc)
+        ok_all = ok_all and ok1
         out[kind] = dict(piped, unit=UNITS[kind], items=n, steps=steps, parity_sample_ok=ok,
                          serial_schedule=serial,
+                         one_context_one_launch={"value": n * steps / dt1, "ms_per_step": dt1 / steps * 1e3, "parity_sample_ok": ok1},
                          note="spans are HIP-event intervals (max over devices); in the pipelined schedule they overlap: "
                               "total_ms is what the call took, scatter + compute + gather what a serial schedule pays")
         del wl
