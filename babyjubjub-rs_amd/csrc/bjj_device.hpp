@@ -200,6 +200,7 @@ BJJ_HD Niels niels_cneg_lazy(const Niels& n, bool neg) {
 // How a lane obtains table entry `slot`.  A policy has a `Pending` handle type and
 //     void  issue(size_t slot, Pending& p, int buf);   // start the gather (buf: staging buffer 0 / 1)
 //     Niels finish(Pending& p, int buf);               // complete it, return the entry
+//     static int wave_max(int v);                      // max of v over the lanes that gather together (identity if lane-private)
 // The loops below issue gather j+1, run the 7 multiplications of addition j, and only then finish.
 //  * GatherPerLane (here): every lane reads its own 128-byte entry (7 x dwordx4).  Works in divergent code and
 //    on the host (tests/emul).  hipcc sinks the loads to their first use, so nothing overlaps, and each of
@@ -210,6 +211,7 @@ struct GatherPerLane {
   struct Pending { Niels e; };
   static constexpr int kBuffers = 2;   // gathers that may be in flight at once
   const u32* table;
+  static BJJ_HD int wave_max(int v) { return v; }   // a lane-private policy makes no assumption about the other lanes
   BJJ_HD void issue(size_t slot, Pending& p, int) const { p.e = load_niels(table + slot * NIELS_WORDS); }
   BJJ_HD Niels finish(Pending& p, int) const { return p.e; }
 };
@@ -222,6 +224,7 @@ struct GatherScan {
   static constexpr int kBuffers = 2;
   const u32* table;
   u32 stride;   // entries per window (fixed_stride(W))
+  static BJJ_HD int wave_max(int v) { return v; }
   BJJ_HD void issue(size_t slot, Pending& p, int) const {
     const u32 s = (u32)slot, base = (s / stride) * stride, d = s - base;   // base = window index * stride: public
     Niels e = load_niels(table + (size_t)base * NIELS_WORDS);
@@ -926,9 +929,15 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* 
   vb_build_table(p1, vb_tbl, K);             // -8A: three doublings, Z != 1
   vb_build_table(p2, tbl2, K, true);         // -+R: affine
   const int ub = limbs_bits(u), vb = limbs_bits(vmag);
-  // signed recoding needs top nibble + carry < 8, i.e. scalars < 2^(4*jw - 2): 34 windows cover 134 bits
-  // (all but ~2e-5 of the pairs); the rest -- e.g. kappa = (l+1)/2 gives u of 250 bits -- take 64 windows
-  const int jw = ((ub > vb ? ub : vb) <= 134) ? 34 : 64;
+  // Signed recoding needs top nibble + carry < 8, i.e. scalars < 2^(4*jw - 2): an item needs ceil((bits + 2) / 4) windows --
+  // 32 for the 92 % of the pairs of at most 126 bits, 33 up to 130 bits (99.9 %), 64 for the odd kappa = (l+1)/2 with its
+  // 250-bit u.  The loop runs the number of windows the WIDEST item of the wave needs (leading zero digits select the identity
+  // entry, so more windows than needed never change a result): 33 for 96 % of the waves, where rounds 1-3 ran a flat 34
+  // (profiles/r04_ab_wave_windows.txt).  G::wave_max is the identity for the per-lane policies (host harness: every item
+  // runs exactly its own minimum, which is also the stricter test of the recoding bound).
+  const int mb = ub > vb ? ub : vb;
+  const int need = mb <= 2 ? 1 : (mb + 5) >> 2;
+  const int jw = G::wave_max(need > 64 ? 64 : need);
   Ext q = joint_mul_windowed(vb_tbl, tbl2, u, vmag, jw, K);
   q = fixed_base_accumulate(q, fb, W, nwin, cw, K);             // + (v s mod l)*B8
   verdict = (fr_is_zero(q.X) && fr_eq(q.Y, q.Z)) ? 1 : 0;       // projective identity (0 : z : z)

@@ -240,6 +240,41 @@ static int mark_stream(bjj_ctx* c, hipStream_t st) {
   return BJJ_OK;
 }
 
+// Per-XCD rings of free table slots (k_common.hpp): [0] head ticket, [1] tail ticket, [2] pops that gave up (SLOTQ_ERR),
+// [16 + i] = slot id + 1.  (Re)built on the host: every slot free.
+#define BJJ_SLOTQ_HDR 16
+#define BJJ_SLOTQ_ERR 2
+static int slot_queue_fill(bjj_ctx* c, u32* d_q, u32 cap) {
+  const size_t stride = BJJ_SLOTQ_HDR + cap;
+  std::vector<u32> h((size_t)c->xccs * stride, 0u);
+  for (int x = 0; x < c->xccs; x++)
+    for (u32 i = 0; i < cap; i++) h[(size_t)x * stride + BJJ_SLOTQ_HDR + i] = (u32)x * cap + i + 1u;   // slot id + 1
+  HIPCK(hipMemcpy(d_q, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice));
+  HIPCK(hipStreamSynchronize(nullptr));
+  return BJJ_OK;
+}
+static int slot_queue_make(bjj_ctx* c, u32** d_q, u32* have_cap, u32 cap) {
+  if (*d_q && *have_cap == cap) return BJJ_OK;
+  if (*d_q) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(*d_q)); *d_q = nullptr; *have_cap = 0; }
+  HIPCK(hipMalloc((void**)d_q, (size_t)c->xccs * (BJJ_SLOTQ_HDR + cap) * sizeof(u32)));
+  int rc = slot_queue_fill(c, *d_q, cap);
+  if (rc) { (void)hipFree(*d_q); *d_q = nullptr; return rc; }
+  *have_cap = cap;
+  return BJJ_OK;
+}
+// After the device is idle: did a pop ever give up waiting for a slot?  (number of such pops; the rings are rebuilt if so)
+static int slot_queue_check(bjj_ctx* c, u32* d_q, u32 cap, unsigned long long* starved) {
+  if (!d_q) return BJJ_OK;
+  const size_t stride = BJJ_SLOTQ_HDR + cap;
+  std::vector<u32> h((size_t)c->xccs * stride, 0u);
+  HIPCK(hipMemcpy(h.data(), d_q, h.size() * sizeof(u32), hipMemcpyDeviceToHost));
+  unsigned long long bad = 0;
+  for (int x = 0; x < c->xccs; x++) bad += h[(size_t)x * stride + BJJ_SLOTQ_ERR];
+  if (bad) { int rc = slot_queue_fill(c, d_q, cap); if (rc) return rc; }
+  *starved += bad;
+  return BJJ_OK;
+}
+
 static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
   if (n > S->scratch_items) {
     if (S->scratch) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->scratch)); S->scratch = nullptr; S->scratch_items = 0; }
@@ -252,34 +287,18 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
     S->slow_items = n;
   }
   // slots of per-lane tables: K2 needs its resident lanes; verify (2 tables per lane) the waves that can be resident, rounded
-  // up to a whole number per XCD (the slot queues are per XCD)
+  // up to a whole number per XCD (the slot queues are per XCD); plus ONE overflow slot per XCD behind the regular ones (what a
+  // pop that gave up waiting continues on, k_common.hpp)
   const size_t cu_per_xcc = ((size_t)c->cus + c->xccs - 1) / c->xccs;
   const u32 cap = (u32)(cu_per_xcc * c->occ_verify);   // occ_verify counts waves
-  size_t tv = cu_per_xcc * c->xccs * (size_t)c->lanes_var, te = (size_t)c->xccs * cap * 64 * 2;
-  size_t threads = tv > te ? tv : te;
   const u32 cap2 = (u32)(cu_per_xcc * (size_t)(c->lanes_var / bjjk::var_base_block()));
-  if (!S->slotq2 || S->slot_cap2 != cap2) {
-    if (S->slotq2) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->slotq2)); S->slotq2 = nullptr; }
-    const size_t stride = 16 + cap2;
-    std::vector<u32> h((size_t)c->xccs * stride, 0u);
-    for (int x = 0; x < c->xccs; x++)
-      for (u32 i = 0; i < cap2; i++) h[(size_t)x * stride + 16 + i] = (u32)x * cap2 + i + 1u;
-    HIPCK(hipMalloc((void**)&S->slotq2, h.size() * sizeof(u32)));
-    HIPCK(hipMemcpy(S->slotq2, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice));
-    HIPCK(hipStreamSynchronize(nullptr));
-    S->slot_cap2 = cap2;
-  }
-  if (!S->slotq || S->slot_cap != cap) {
-    if (S->slotq) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->slotq)); S->slotq = nullptr; }
-    const size_t stride = 16 + cap;
-    std::vector<u32> h((size_t)c->xccs * stride, 0u);
-    for (int x = 0; x < c->xccs; x++)
-      for (u32 i = 0; i < cap; i++) h[(size_t)x * stride + 16 + i] = (u32)x * cap + i + 1u;   // slot id + 1
-    HIPCK(hipMalloc((void**)&S->slotq, h.size() * sizeof(u32)));
-    HIPCK(hipMemcpy(S->slotq, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice));
-    HIPCK(hipStreamSynchronize(nullptr));
-    S->slot_cap = cap;
-  }
+  const size_t tv = (size_t)c->xccs * ((size_t)cap2 + 1) * (size_t)bjjk::var_base_block();
+  const size_t tv_strided = cu_per_xcc * c->xccs * (size_t)c->lanes_var;          // the grid-strided form indexes by global lane
+  const size_t te = (size_t)c->xccs * ((size_t)cap + 1) * 64 * 2;
+  size_t threads = tv > te ? tv : te;
+  if (tv_strided > threads) threads = tv_strided;
+  { int rc = slot_queue_make(c, &S->slotq2, &S->slot_cap2, cap2); if (rc) return rc; }
+  { int rc = slot_queue_make(c, &S->slotq, &S->slot_cap, cap); if (rc) return rc; }
   if (threads > S->vb_threads) {
     if (S->vb_tables) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->vb_tables)); S->vb_tables = nullptr; S->vb_threads = 0; }
     HIPCK(hipMalloc((void**)&S->vb_tables, threads * VB_TABLE_WORDS_MAX * sizeof(u32)));
@@ -552,6 +571,16 @@ int bjj_sync(bjj_ctx* c) {
   for (StreamMark& k : c->marks)
     if (k.used) HIPCK(hipEventSynchronize(k.ev));
   HIPCK(hipStreamSynchronize(c->stream));
+  // everything the context enqueued has run: a slot-queue pop that gave up waiting (k_common.hpp) is an ERROR of the launches
+  // just completed -- reported here instead of a hung GPU; the rings are rebuilt so that the context stays usable
+  unsigned long long starved = 0;
+  for (ScratchSet& S : c->set) {
+    int rc = slot_queue_check(c, S.slotq, S.slot_cap, &starved); if (rc) return rc;
+    rc = slot_queue_check(c, S.slotq2, S.slot_cap2, &starved); if (rc) return rc;
+  }
+  if (starved)
+    return set_err(BJJ_E_HIP, "bjj_sync: " + std::to_string(starved) + " workgroup(s) gave up waiting for a per-lane table slot; the results of "
+                   "the verify / variable-base launches since the last bjj_sync are not valid (slot queues rebuilt)");
   return BJJ_OK;
 }
 void* bjj_stream(bjj_ctx* c) { return c ? (void*)c->stream : nullptr; }

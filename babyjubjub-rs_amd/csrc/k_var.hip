@@ -111,8 +111,7 @@ __device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, c
   __shared__ u32 lds[NL * 64];
   __shared__ u32 sh_slot;
   u32* q = slot_queue_of_this_xcd(slotq, cap_nx);
-  const u32 cap = cap_nx & 0xffffu;
-  if (threadIdx.x == 0) sh_slot = slot_pop_one(q, cap);
+  if (threadIdx.x == 0) sh_slot = slot_pop_one(q, cap_nx);
   __syncthreads();
   const u32 slot = sh_slot;
   const size_t base = (size_t)blockIdx.x * BJJ_K2_BLOCK;
@@ -120,7 +119,7 @@ __device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, c
   var_base_body<WIDE>(pts, scalars, sc_words, hi, out, scratch, vb_tables + ((size_t)slot * BJJ_K2_BLOCK + threadIdx.x) * VB_TABLE_WORDS, slow,
                       lds, base + threadIdx.x, (size_t)BJJ_K2_BLOCK);
   __syncthreads();
-  if (threadIdx.x == 0) slot_push_one(q, cap, slot);
+  if (threadIdx.x == 0) slot_push_one(q, cap_nx, slot);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_tiles(const uint8_t* __restrict__ pts,
     const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch, u32* __restrict__ vb_tables,

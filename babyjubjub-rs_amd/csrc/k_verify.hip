@@ -135,8 +135,7 @@ __device__ __forceinline__ void verify_group_body(const u32* __restrict__ table,
   const unsigned long long nexact = wl[0];
   if (exact && b * 64 >= nexact) return;                     // wave-uniform: nothing on the list for this block
   u32* q = slot_queue_of_this_xcd(slotq, cap_nx);
-  const u32 cap = cap_nx & 0xffffu;
-  const u32 slot = slot_pop(q, cap, lane);
+  const u32 slot = slot_pop(q, cap_nx, lane);
   u32* tbl = vb_tables + ((size_t)slot * 64 + lane) * VB_VERIFY_WORDS;
 #ifdef BJJ_EXP_NO_EXACT_IN_BULK   // experiment (resource usage only: the exact path out of the bulk kernel's allocation)
   if (false) {
@@ -163,7 +162,7 @@ __device__ __forceinline__ void verify_group_body(const u32* __restrict__ table,
       if (i < n && !need_exact) ok[i] = (uint8_t)v;
     }
   }
-  slot_push(q, cap, slot, lane);
+  slot_push(q, cap_nx, slot, lane);
 }
 __global__ void __launch_bounds__(64, BJJ_VERIFY_MIN_BLOCKS) bjj_k_schnorr_verify_groups(const u32* __restrict__ table, int W, int nwin,
     const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8, const uint8_t* __restrict__ s, const uint8_t* __restrict__ msg,

@@ -131,8 +131,14 @@ def test_emul_verify_half_size_scalar_boundaries(emul, oracle, pyoracle):
     msg = w.random_u256(w.SEED_MSGS ^ 0xB0, n, 0, 3)
     A, R = oracle.mul_fixed_base(w.from_ints(kk)), oracle.mul_fixed_base(w.from_ints(rho))
     hm = w.to_ints(oracle.poseidon5(np.concatenate([R, A, msg], axis=1)))
-    picks = [i for i in range(n) if pair_bits(hm[i] % L) >= 131][:6] + [0, 1]
+    bits = [pair_bits(hm[i] % L) for i in range(n)]
+    picks = [i for i in range(n) if bits[i] >= 131][:6] + [0, 1]
     assert len(picks) >= 3
+    # since round 4 an item runs ceil((bits + 2) / 4) windows (the host harness: exactly its own minimum), so EVERY multiple of four
+    # is a window-count boundary: one item of each bit length that occurs, both sides of 122 | 123, 126 | 127, 130 | 131
+    for b in sorted(set(bits)):
+        picks.append(bits.index(b))
+    assert {126, 127, 130, 131} <= set(bits)
     for i in picks:
         S = (rho[i] + 8 * hm[i] * kk[i]) % L
         for s in (S, S ^ 2):

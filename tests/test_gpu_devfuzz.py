@@ -269,3 +269,69 @@ def test_extended_coordinate_formulas(fz):
             assert affine(hx[i], need_t) == exp[i], (op, i)
             for k in range(3):
                 check_nform_below(hx[i][9 * k:9 * k + 9], 2 * R_MOD)     # outputs of fr_mul: < 2r, as the next formula needs
+
+
+# ---- slot queues (csrc/slot_queue.hpp): hand-over and the bounded wait ------------------------------------------------
+def _slotq_lib():
+    d = os.path.join(ROOT, "tests", "devfuzz")
+    so = os.path.join(d, "libbjj_slotq_test.so")
+    if not os.path.exists(so) or os.path.getmtime(os.path.join(d, "slotq.hip")) > os.path.getmtime(so):
+        r = subprocess.run(["make", "-s"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+    lib.sq_run.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]
+    lib.sq_spin_limit.restype = ctypes.c_uint
+    return lib
+
+
+def _queue(torch, nx, cap, filled=True):
+    """host image of the rings: per XCD [head, tail, err, ..13 unused.., cap entries = slot id + 1]"""
+    q = np.zeros((nx, 16 + cap), np.uint32)
+    if filled:
+        for x in range(nx):
+            q[x, 16:] = x * cap + np.arange(cap, dtype=np.uint32) + 1
+    return torch.from_numpy(q.view(np.int32).reshape(-1).copy()).cuda()
+
+
+def test_slot_queue_hands_every_slot_to_one_holder_at_a_time():
+    import torch
+    lib = _slotq_lib()
+    nx, cap, blocks = 8, 24, 4096                      # far more workgroups than slots: every slot changes hands many times
+    q = _queue(torch, nx, cap)
+    owner = torch.zeros(nx * cap + nx, dtype=torch.int32, device="cuda")
+    got = torch.full((blocks,), -1, dtype=torch.int32, device="cuda")
+    clash = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert lib.sq_run(q.data_ptr(), cap | (nx << 16), owner.data_ptr(), got.data_ptr(), clash.data_ptr(), blocks, 40, None) == 0
+    torch.cuda.synchronize()
+    h = q.cpu().numpy().view(np.uint32).reshape(nx, 16 + cap)
+    g = got.cpu().numpy()
+    assert int(clash.item()) == 0 and (owner.cpu().numpy() == 0).all()
+    assert (h[:, 2] == 0).all()                                            # nobody gave up
+    assert ((g >= 0) & (g < nx * cap)).all()                               # regular slots only
+    for x in range(nx):                                                    # every ring holds exactly its own slots again
+        assert sorted(h[x, 16:].tolist()) == list(range(x * cap + 1, x * cap + cap + 1))
+    used_x = np.unique(g // cap)
+    assert len(used_x) >= 1 and (h[used_x, 0] == h[used_x, 1]).all()       # as many pops as pushes (tickets wrap together)
+
+
+def test_slot_queue_starved_pop_gives_up_flags_it_and_takes_the_overflow_slot():
+    """rings without a single free slot (what a kernel that died holding its slots leaves behind): every pop would wait for
+    ever.  With the bound it gives up after BJJ_SLOT_SPIN_LIMIT polls, counts itself in the ring's error word and continues on
+    the XCD's overflow slot -- the launch ENDS, and the host can see why its results are invalid (bjj_sync reports it)."""
+    import torch
+    lib = _slotq_lib()
+    assert lib.sq_spin_limit() == 2000
+    nx, cap, blocks = 8, 24, 512
+    q = _queue(torch, nx, cap, filled=False)
+    owner = torch.zeros(nx * cap + nx, dtype=torch.int32, device="cuda")
+    got = torch.full((blocks,), -1, dtype=torch.int32, device="cuda")
+    clash = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert lib.sq_run(q.data_ptr(), cap | (nx << 16), owner.data_ptr(), got.data_ptr(), clash.data_ptr(), blocks, 1, None) == 0
+    torch.cuda.synchronize()                                                # returns: no hang
+    h = q.cpu().numpy().view(np.uint32).reshape(nx, 16 + cap)
+    g = got.cpu().numpy()
+    assert int(h[:, 2].sum()) == blocks                                     # every workgroup flagged itself
+    assert ((g >= nx * cap) & (g < nx * cap + nx)).all()                    # ... and worked on an overflow slot
+    assert (h[:, 16:] == 0).all()                                           # overflow slots are never queued
