@@ -125,7 +125,11 @@ const char* bjj_last_error(void);
  * Valid: 0, BJJ_WINDOW_AUTO, 4..28. */
 int bjj_init(int device, int window_bits, bjj_ctx** out_ctx);
 void bjj_free(bjj_ctx* ctx);
-/* Blocks until everything enqueued on the context's stream has finished. */
+/* Blocks until everything the context has enqueued -- on its own stream and on the callers' streams -- has finished.
+ * Returns BJJ_E_HIP if a verify / variable-base workgroup had to give up waiting for a slot of per-lane table scratch since
+ * the last bjj_sync (it cannot happen unless a kernel was aborted while it held slots): the wait is bounded, the launch ends,
+ * and this call reports that the results of those launches are not valid instead of the GPU hanging; the slot queues are
+ * rebuilt, the context stays usable. */
 int bjj_sync(bjj_ctx* ctx);
 /* The context's own stream (hipStream_t as void*). */
 void* bjj_stream(bjj_ctx* ctx);

@@ -44,6 +44,22 @@ static void ext_out(const Ext& p, uint8_t* out) {  // single-item affine epilogu
   fr_to_words(fr_cond_sub_kr(fr_mul(p.Y, c1), R1), w); memcpy(out + 32, w, 32);
 }
 extern "C" {
+// the shift-register digit stream (DigitStream, what the kernels run) against the indexed definition (fixed_digit_slot):
+// number of windows on which slot or sign differ, for one 32-byte scalar and one window width
+int emul_digit_stream_mismatches(const uint8_t* scalar32, int W) {
+  alignas(16) u32 sc[8];
+  memcpy(sc, scalar32, 32);
+  const int nwin = fixed_nwin(W);
+  DigitStream ds = digit_stream(sc, W);
+  u32 carry = 0;
+  int bad = 0;
+  for (int j = 0; j < nwin; j++) {
+    bool n1, n2;
+    const size_t a = digit_next(ds, n1), b = fixed_digit_slot(sc, j, W, carry, n2);
+    bad += (a != b) || (n1 != n2);
+  }
+  return bad;
+}
 // builds the table with the chain builder, then (i) compares every entry with the independent per-entry ladder
 // (fixed_table_entry) and (ii) runs the induction check the GPU runs; `corrupt` >= 0 flips one bit of that
 // slot first so the test can see the check fire.  Returns mismatches in the high half, check failures in the low.

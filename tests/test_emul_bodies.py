@@ -48,6 +48,21 @@ def test_emul_fixed_base_signed_digit_edges(emul, pyoracle):
             assert unpack(out.raw, 2)[0] == o.mul_scalar(o.B8, n % (1 << 256)), (W, hex(n))
 
 
+def test_emul_digit_stream_equals_the_indexed_digits(emul):
+    """round 4: the kernels take the signed W-bit digits of the (reduced) scalar from a shift register instead of indexing the
+    words by a run-time window number; both definitions agree on every window for every width 4..28"""
+    import numpy as np
+    L = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+    rng = np.random.default_rng(0xD161)
+    edge = [0, 1, L - 1, (1 << 251) - 1, (1 << 250) + 1, int("8" * 62, 16) % L, int("7" * 62, 16) % L, (1 << 200) - 1]
+    for W in range(4, 29):
+        half = 1 << (W - 1)
+        cases = edge + [sum(half << (W * j) for j in range(252 // W)) % L, sum((half + 1) << (W * j) for j in range(252 // W)) % L]
+        cases += [int.from_bytes(rng.bytes(32), "little") % L for _ in range(40)]
+        for v in cases:
+            assert emul.emul_digit_stream_mismatches(le32(v), W) == 0, (W, hex(v))
+
+
 def test_emul_fixed_base_scanning_policy(emul, pyoracle, golden):
     """GatherScan (the signer's constant-time option: all 9 entries of a 4-bit window are read, the digit selects
     arithmetically) gives the same points as the indexed gather: golden vectors and the signed-digit edge scalars"""
