@@ -82,18 +82,16 @@ class GpuTelemetry:
     [t0, t1]; when the region is too short to hold two samples the window is widened backwards (and says so)."""
 
     def __init__(self, device_index, period_s=0.0005):
-        import ctypes
         import glob
         import threading
         self.ok, self.why, self.samples, self.period = False, None, [], period_s
         self._stop = threading.Event()
         self._thread = None
         try:
-            hip = ctypes.CDLL("libamdhip64.so")
-            buf = ctypes.create_string_buffer(64)
-            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
-                raise RuntimeError("hipDeviceGetPCIBusId failed")
-            bus = buf.value.decode().lower()
+            # the PCI address from torch's device properties (NOT a second dlopen of libamdhip64: torch ships its own copy of
+            # the runtime, and a process must not end up with two)
+            pr = torch.cuda.get_device_properties(int(device_index))
+            bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
             hw = sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bus))
             if not hw:
                 raise RuntimeError("no hwmon directory for %s" % bus)
