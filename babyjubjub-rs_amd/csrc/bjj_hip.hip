@@ -35,7 +35,7 @@
 
 using namespace bjj;
 
-#define BJJ_VERSION_STRING "bjj-hip 0.3.1 gfx950"
+#define BJJ_VERSION_STRING "bjj-hip 0.4.0 gfx950"
 // Fixed-base window width.  window_bits = 0 (default) is a modest 23 bits = 11 signed digits, 5.9 GB: a library that
 // is linked into a process with other tenants of the GPU must not take half of the HBM unasked.  The wide tables are
 // opt-in: an explicit width (28 bits = 9 digits, 9 x (2^27 + 1) entries = 154.6 GB of the 288 GB; 26 = 10 digits,
@@ -697,9 +697,12 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
   if (!d_pts || !d_scalars || !d_out || !aligned16(d_pts) || !aligned16(d_scalars) || !aligned16(d_out))
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   SET_ENTER(c, stream, n, false);
-  bool busy2 = other_launch_in_flight(c, S);
-  if (busy2 && c->k2_variant < 0 && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; busy2 = false; }
-  const int kv = c->k2_variant >= 0 ? c->k2_variant : (busy2 ? 0 : 1);   // k_var.hip: the two forms of K2
+  // k_var.hip: the two forms of K2.  Like K1's shape the form follows the caller's PATTERN (streams_alternate) first, the racy
+  // look at the device second: a caller that ping-pongs over two streams gets the grid-strided form for every launch of the
+  // run, a one-stream caller the tiles.  A large launch queues behind the other sets and runs alone (tiles).
+  bool overlap = streams_alternate(c, S) || other_launch_in_flight(c, S);
+  if (overlap && c->k2_variant < 0 && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; overlap = false; }
+  const int kv = c->k2_variant >= 0 ? c->k2_variant : (overlap ? 0 : 1);
   LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, kv, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
                               (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)),
            "bjj_mul_var_base_dev");
