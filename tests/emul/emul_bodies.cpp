@@ -89,6 +89,20 @@ void emul_fixed_base_scan(const uint8_t* scalar, int W, uint8_t* out) {
   alignas(16) u32 sc[8]; memcpy(sc, scalar, 32);
   ext_out(fixed_base_mul(GatherScan{table_ptr(), (u32)fixed_stride(g_W)}, g_W, g_nwin, sc, K), out);
 }
+// u * P1 + v * P2 through verify's joint double-and-add with EXACTLY nwin windows (P1, P2 on the curve; u, v < 2^(4 nwin - 1))
+void emul_joint_mul(const uint8_t* p1, const uint8_t* p2, const uint8_t* u32b, const uint8_t* v32b, int nwin, uint8_t* out) {
+  alignas(16) u32 w[8];
+  Fr c[4];
+  const uint8_t* src[4] = {p1, p1 + 32, p2, p2 + 32};
+  for (int i = 0; i < 4; i++) { memcpy(w, src[i], 32); c[i] = fr_to_mont_words(w); }
+  std::vector<u32> buf(2 * VB_TABLE_WORDS + 8);
+  u32* tbl = aligned16(buf);
+  vb_build_table(ext_from_ref_affine(c[0], c[1], K), tbl, K, true);
+  vb_build_table(ext_from_ref_affine(c[2], c[3], K), tbl + VB_TABLE_WORDS, K, true);
+  memcpy(w, u32b, 32); const Fr u = fr_from_words(w);
+  memcpy(w, v32b, 32); const Fr v = fr_from_words(w);
+  ext_out(joint_mul_windowed(tbl, tbl + VB_TABLE_WORDS, u, v, nwin, K), out);
+}
 void emul_var_base(const uint8_t* pt, const uint8_t* scalar, uint8_t* out) {
   alignas(16) u32 w[8], sc[8]; alignas(16) static u32 tbl[VB_TABLE_WORDS];
   memcpy(w, pt, 32); Fr x = fr_to_mont_words(w);

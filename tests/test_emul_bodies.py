@@ -48,6 +48,30 @@ def test_emul_fixed_base_signed_digit_edges(emul, pyoracle):
             assert unpack(out.raw, 2)[0] == o.mul_scalar(o.B8, n % (1 << 256)), (W, hex(n))
 
 
+def test_emul_joint_loop_at_the_minimal_window_count(emul, oracle, golden):
+    """verify's joint double-and-add, called directly with exactly the window count an item needs -- ceil((b + 2) / 4) for a
+    b-bit scalar (signed 4-bit digits: top nibble + carry must stay below 8) -- on the patterns that stress the recoding:
+    all-ones scalars (a carry through every window), 0x80..0, 0x88..8 runs, both scalars at the edge and only one of them"""
+    import numpy as np
+    from babyjubjub_rs_amd import workload as w
+    pts = oracle.mul_fixed_base(w.random_u256(0x70F, 2))             # two points of the group
+    p1, p2 = pts[0].tobytes(), pts[1].tobytes()
+    out = ctypes.create_string_buffer(64)
+    cases = []
+    for b in (4, 5, 8, 122, 123, 124, 125, 126, 127, 128, 130, 131, 132, 134, 250, 251):
+        top = 1 << (b - 1)
+        for val in (top, (1 << b) - 1, top | ((1 << (b - 1)) - 1) // 15 * 8, top + 0x88888888, (1 << b) - 0x77777777):
+            if val.bit_length() == b:                                    # b-bit values only (small widths drop some patterns)
+                cases.append((val, b))
+    for (u, b) in cases:
+        nwin = (b + 5) >> 2
+        for v in (u, 1, (1 << (4 * nwin - 2)) - 1, 0):
+            emul.emul_joint_mul(p1, p2, le32(u), le32(v), nwin, out)
+            want = oracle.point_add(oracle.mul_var_base(pts[0:1], pack([u]).reshape(1, 32)),
+                                    oracle.mul_var_base(pts[1:2], pack([v]).reshape(1, 32)))[0]
+            assert out.raw == want.tobytes(), (hex(u), hex(v), nwin)
+
+
 def test_emul_digit_stream_equals_the_indexed_digits(emul):
     """round 4: the kernels take the signed W-bit digits of the (reduced) scalar from a shift register instead of indexing the
     words by a run-time window number; both definitions agree on every window for every width 4..28"""
@@ -150,9 +174,9 @@ def test_emul_verify_half_size_scalar_boundaries(emul, oracle, pyoracle):
     picks = [i for i in range(n) if bits[i] >= 131][:6] + [0, 1]
     assert len(picks) >= 3
     # since round 4 an item runs ceil((bits + 2) / 4) windows (the host harness: exactly its own minimum), so EVERY multiple of four
-    # is a window-count boundary: one item of each bit length that occurs, both sides of 122 | 123, 126 | 127, 130 | 131
+    # is a window-count boundary: a few items of each bit length that occurs, both sides of 122 | 123, 126 | 127, 130 | 131
     for b in sorted(set(bits)):
-        picks.append(bits.index(b))
+        picks += [i for i in range(n) if bits[i] == b][:4]
     assert {126, 127, 130, 131} <= set(bits)
     for i in picks:
         S = (rho[i] + 8 * hm[i] * kk[i]) % L
