@@ -84,7 +84,7 @@ class GpuTelemetry:
     def __init__(self, device_index, period_s=0.0005):
         import glob
         import threading
-        self.ok, self.why, self.samples, self.period = False, None, [], period_s
+        self.ok, self.why, self.samples, self.period, self.paused = False, None, [], period_s, False
         self._stop = threading.Event()
         self._thread = None
         try:
@@ -128,6 +128,9 @@ class GpuTelemetry:
 
         def loop():
             while not self._stop.is_set():
+                if self.paused:                      # the CPU baseline has the host cores to itself
+                    time.sleep(0.01)
+                    continue
                 self.samples.append(self._read())
                 if len(self.samples) > 400000:
                     del self.samples[:200000]
@@ -500,6 +503,8 @@ def cpu_baseline(kind, wl, orc, budget_cpu_s=12.0):
     hc = host_cpu_info()
     logical = hc.get("affinity_cpus", hc["logical_cpus"])
     B = wl.batches[0]
+    if TELEMETRY:
+        TELEMETRY.paused = True       # no 2 kHz sysfs polling next to the timed host threads (resumed below)
 
     def run(m):
         t0 = time.perf_counter()
@@ -524,6 +529,8 @@ def cpu_baseline(kind, wl, orc, budget_cpu_s=12.0):
     sample = int(min(wl.n, max(best_t * 8, best_rate * budget_cpu_s)))
     dt = run(sample)
     quota = hc.get("cgroup_cpu_quota")
+    if TELEMETRY:
+        TELEMETRY.paused = False
     return {"value": sample / dt, "unit": UNITS[kind], "cores": best_t, "kind": "port",
             "sample": "first %d items of the same %s batch, oracle/bjj_ref.c (reference algorithm: bit-serial "
                       "double-and-add with unified adds, binary-Euclid inversions, plain Poseidon), %d pthreads = best of a "
