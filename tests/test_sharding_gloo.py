@@ -102,3 +102,12 @@ def test_piece_geometry_matches_the_library():
     assert workload.piece_bounds(40000, 4) == [(0, 40000)] and workload.piece_bounds(0) == []
     assert workload.piece_bounds(70000, 16) == [(0, 35008), (35008, 70000)]
     assert workload.piece_bounds(643, 4, 64) == [(0, 192), (192, 384), (384, 576), (576, 643)]
+
+
+def test_scatter_compute_gather_world8_the_node_size_of_the_scaling_bench():
+    """G = 8 (what `bench.py --gpus 8` and BASELINE configs[4] use): ragged blocks (1003 = 7 x 126 + 121), pieces per peer block,
+    and n < G (5 items: three ranks own nothing and neither send nor receive)"""
+    ok = {"gather_ok": True}
+    ok.update({"shard%d_ok" % r: True for r in range(8)})
+    assert _run_world(8, 1003) == ok
+    assert _run_world(8, 5) == ok
