@@ -50,6 +50,20 @@ def test_bench_gpus_3_ragged_strong_total():
     assert v["total_items"] == 100003 and v["rank0_resident"]["gathered_verdicts_ok"]
 
 
+def test_bench_gpus_8_node_shape_shared_gpu():
+    """eight ranks -- the node size of the scaling bench and of BASELINE configs[4] -- sharing the one GPU: every rank its own
+    context, a ragged total cut into 8 blocks, peer blocks in pieces, every gathered verdict checked on rank 0"""
+    r, j = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--warmup-seconds", "0", "--batch", "8192", "--batches", "1",
+                 "--window-bits", "12", "--strong-total", str((1 << 19) + 5), "--no-cpu-baseline", "--no-also"],
+                {"BJJ_BENCH_SHARE_GPU": "1", "BJJ_BENCH_BACKEND": "gloo"}, 1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and len(j["devices"]) == 8 and j["parity_sample_ok"] is True
+    assert j["config"]["global_batch"] == 8 * 8192 and j["scaling"] == "weak"
+    v = j["strong"]["verify_total"]
+    assert v["total_items"] == (1 << 19) + 5 and v["rank0_resident"]["gathered_verdicts_ok"]
+    assert v["rank0_resident"]["pieces_per_peer_block"] == 2          # 65 537-item blocks: two pieces of >= 32 768 items
+
+
 def test_bench_rejects_world_size_mismatch():
     r, j = _run(["--gpus", "2", "--no-also", "--no-strong"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, 300)
     assert r.returncode != 0 and j is None and "WORLD_SIZE=1 but --gpus 2" in r.stderr
@@ -71,6 +85,15 @@ def test_bench_one_gpu_line_has_every_block():
         assert j["also"][k]["streams"] == 2 and j["also"][k]["single_stream"]["kernel_ms_avg"] > 0
     assert j["also"]["fixed_base_window_bits_23"]["parity_sample_ok"]
     assert j["config"]["init_ms"] > 0 and j["config"]["table_bytes"] > 0
+    # round 4: clock / power sampled across the timed regions; counters only for the build they were taken from; PCIe-inclusive
+    # host-pointer rates beside the line
+    assert "clock_mhz" in j and "socket_w" in j and isinstance(j["clock"], dict)
+    if j["clock"].get("available"):
+        assert 300 < j["clock_mhz"] < 3000 and j["socket_w"] > 50 and j["clock"]["samples"] >= 1
+        assert j["single_stream"]["clock"]["sclk_mhz"] > 300
+    assert j["roofline"]["traffic"] is None          # 2^16-item batch / 16-bit table: the committed counters describe another configuration
+    h = j["also"]["host_api"]
+    assert h["parity_sample_ok"] and h["fixed_base"]["value"] > 0 and h["verify"]["value"] > 0 and "never" in h["note"]
 
 
 def test_bench_point_add_and_compress_workloads():
