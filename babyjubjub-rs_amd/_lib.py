@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "bjj_mul_fixed_base_multi", "bjj_mul_var_base_multi", "bjj_eddsa_verify_multi",
     "bjj_mul_fixed_base_multi_dev", "bjj_mul_var_base_multi_dev", "bjj_eddsa_verify_multi_dev",
     "bjj_multi_last_timing", "bjj_multi_set_transport", "bjj_multi_set_chunks", "bjj_multi_last_overlap",
+    "bjj_host_alloc", "bjj_host_free", "bjj_host_register", "bjj_host_unregister", "bjj_host_is_pinned",
 )
 
 
@@ -56,6 +57,15 @@ class BjjInfo(ctypes.Structure):
         ("kernel_verify", ctypes.c_char_p),
         ("init_ms", ctypes.c_double),
         ("signer_constant_time", ctypes.c_int),
+        ("last_fixed_base_shape", ctypes.c_int),
+        ("last_var_base_form", ctypes.c_int),
+        ("last_verify_dispatch", ctypes.c_int),
+        ("last_host_direct_arrays", ctypes.c_uint32),
+        ("last_host_staged_arrays", ctypes.c_uint32),
+        ("last_host_chunks", ctypes.c_uint32),
+        ("host_copy_threads", ctypes.c_int),
+        ("kernel_fixed_base_overlap", ctypes.c_char_p),
+        ("kernel_var_base_overlap", ctypes.c_char_p),
     ]
 
 
@@ -111,6 +121,11 @@ def load():
     lib.bjj_reserve.argtypes = [vp, sz]
     lib.bjj_get_info.argtypes = [vp, ctypes.POINTER(BjjInfo)]
     lib.bjj_check_table.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.bjj_host_alloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    lib.bjj_host_free.argtypes = [vp, vp]
+    lib.bjj_host_register.argtypes = [vp, vp, sz]
+    lib.bjj_host_unregister.argtypes = [vp, vp]
+    lib.bjj_host_is_pinned.argtypes = [vp, vp, sz]
     lib.bjj_mul_fixed_base.argtypes = [vp, vp, sz, vp]
     lib.bjj_mul_var_base.argtypes = [vp, vp, vp, sz, vp]
     lib.bjj_poseidon5.argtypes = [vp, vp, sz, vp]

@@ -90,6 +90,9 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            for ptr in list(getattr(self, "_pinned", {}).values()):   # arrays from host_empty that were never released
+                self.lib.bjj_host_free(self.handle, ptr)
+            self._pinned = {}
             if self._owned:
                 self.lib.bjj_free(self.handle)
             self.handle = None
@@ -121,6 +124,38 @@ class Context:
 
     def reserve(self, n):
         self._ck(self.lib.bjj_reserve(self.handle, n), "bjj_reserve")
+
+    # ---- pinned host memory (bjj_host_alloc / bjj_host_register): host-pointer calls copy such arrays directly ----
+    def host_empty(self, nbytes):
+        """uint8 numpy array of `nbytes` bytes in page-locked memory owned by the library; release with host_free(array).
+        Host-pointer calls whose arrays live in such memory skip the staging copy (include/bjj_hip.h)."""
+        p = ctypes.c_void_p()
+        self._ck(self.lib.bjj_host_alloc(self.handle, int(nbytes), ctypes.byref(p)), "bjj_host_alloc")
+        buf = (ctypes.c_uint8 * int(nbytes)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=np.uint8)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a):
+        """release an array from host_empty (the array must not be used afterwards)"""
+        ptr = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if ptr is None:
+            raise BjjError("host_free: not an array from host_empty")
+        self._ck(self.lib.bjj_host_free(self.handle, ptr), "bjj_host_free")
+
+    def host_register(self, a):
+        """pin the memory of an existing contiguous numpy array in place (hipHostRegister)"""
+        self._ck(self.lib.bjj_host_register(self.handle, a.ctypes.data, a.nbytes), "bjj_host_register")
+
+    def host_unregister(self, a):
+        self._ck(self.lib.bjj_host_unregister(self.handle, a.ctypes.data), "bjj_host_unregister")
+
+    def host_is_pinned(self, a):
+        rc = self.lib.bjj_host_is_pinned(self.handle, a.ctypes.data, a.nbytes)
+        if rc < 0:
+            self._ck(rc, "bjj_host_is_pinned")
+        return bool(rc)
 
     # ---- host-buffer batch calls (numpy uint8 in / out) ----
     def mul_fixed_base(self, scalars):

@@ -861,6 +861,30 @@ BJJ_HD Ext joint_mul_windowed(const u32* tbl1, const u32* tbl2, const Fr& u, con
   return acc;
 }
 
+// u*P1 + |v|*P2 for the short pair (u, |v|) of the EdDSA fast path: per-lane tables of P1 (any Z) and P2 (Z == 1) in vb_tbl
+// (VB_VERIFY_WORDS words), then the joint loop over the number of windows the WIDEST item of the wave needs.
+// Signed recoding needs top nibble + carry < 8, i.e. scalars < 2^(4*jw - 2): an item needs ceil((bits + 2) / 4) windows --
+// 32 for the 92 % of the pairs of at most 126 bits, 33 up to 130 bits (99.9 %), 63 for the odd kappa = (l+1)/2 with its
+// 250-bit u, 64 (the cap) from 251 bits on.  Leading zero digits select the identity entry, so more windows than an item needs never change its result:
+// 33 windows for 96 % of the waves, where rounds 1-3 ran a flat 34 (profiles/r04_ab_wave_windows.txt).  G::wave_max is the
+// identity for the per-lane policies (host harness: every item runs exactly its own minimum, which is also the stricter test
+// of the recoding bound); under the wave-cooperative policy it is a cross-lane maximum, i.e. a data-dependent trip count
+// shared by the wave -- tests/devfuzz/joint.hip drives THIS function on the device with chosen bit lengths per lane
+// (one lane at 250 bits next to lanes at 1, 126, 127, 130, 131 bits, partly filled waves).  *windows_run reports jw.
+template <class G>
+BJJ_HD Ext joint_short_pair(const Ext& p1, const Ext& p2, const Fr& u, const Fr& vmag, u32* vb_tbl, const Consts& K,
+                            int* windows_run = nullptr) {
+  u32* tbl2 = vb_tbl + VB_TABLE_WORDS;
+  vb_build_table(p1, vb_tbl, K);             // -8A: three doublings, Z != 1
+  vb_build_table(p2, tbl2, K, true);         // -+R: affine
+  const int ub = limbs_bits(u), vb = limbs_bits(vmag);
+  const int mb = ub > vb ? ub : vb;
+  const int need = mb <= 2 ? 1 : (mb + 5) >> 2;
+  const int jw = G::wave_max(need > 64 ? 64 : need);
+  if (windows_run) *windows_run = jw;
+  return joint_mul_windowed(vb_tbl, tbl2, u, vmag, jw, K);
+}
+
 // Fast path of verify (src/lib.rs:395-412) and, with SCHNORR, of verify_schnorr (src/lib.rs:375-385:
 // hash input order (pk, R, msg) instead of (R, pk, msg), the hash is NOT multiplied by 8, and msg > Q is
 // an Err -- verdict 2 -- rather than `false`).  Verdict 0 / 1 / 2; need_exact is set when pk or R is off
@@ -925,20 +949,7 @@ BJJ_HD int verify_fast_t(const VerifyIn& in, const G& fb, int W, int nwin, u32* 
   Ext p1 = ext_from_ref_affine(fr_neg(ax), ay, K);
   p1 = ext_dbl<false>(p1); p1 = ext_dbl<false>(p1); p1 = ext_dbl<true>(p1);
   Ext p2 = ext_from_ref_affine(vneg ? rx : fr_neg(rx), ry, K);
-  u32* tbl2 = vb_tbl + VB_TABLE_WORDS;
-  vb_build_table(p1, vb_tbl, K);             // -8A: three doublings, Z != 1
-  vb_build_table(p2, tbl2, K, true);         // -+R: affine
-  const int ub = limbs_bits(u), vb = limbs_bits(vmag);
-  // Signed recoding needs top nibble + carry < 8, i.e. scalars < 2^(4*jw - 2): an item needs ceil((bits + 2) / 4) windows --
-  // 32 for the 92 % of the pairs of at most 126 bits, 33 up to 130 bits (99.9 %), 64 for the odd kappa = (l+1)/2 with its
-  // 250-bit u.  The loop runs the number of windows the WIDEST item of the wave needs (leading zero digits select the identity
-  // entry, so more windows than needed never change a result): 33 for 96 % of the waves, where rounds 1-3 ran a flat 34
-  // (profiles/r04_ab_wave_windows.txt).  G::wave_max is the identity for the per-lane policies (host harness: every item
-  // runs exactly its own minimum, which is also the stricter test of the recoding bound).
-  const int mb = ub > vb ? ub : vb;
-  const int need = mb <= 2 ? 1 : (mb + 5) >> 2;
-  const int jw = G::wave_max(need > 64 ? 64 : need);
-  Ext q = joint_mul_windowed(vb_tbl, tbl2, u, vmag, jw, K);
+  Ext q = joint_short_pair<G>(p1, p2, u, vmag, vb_tbl, K);      // u*(-8A) + |v|*(-+R)
   q = fixed_base_accumulate(q, fb, W, nwin, cw, K);             // + (v s mod l)*B8
   verdict = (fr_is_zero(q.X) && fr_eq(q.Y, q.Z)) ? 1 : 0;       // projective identity (0 : z : z)
   return msg_gt ? 0 : verdict;

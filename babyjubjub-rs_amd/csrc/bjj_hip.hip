@@ -23,7 +23,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -32,10 +36,11 @@
 #include "../../include/bjj_hip.h"
 #include "bjj_device.hpp"
 #include "bjj_launch.hpp"
+#include "copy_pool.hpp"
 
 using namespace bjj;
 
-#define BJJ_VERSION_STRING "bjj-hip 0.4.0 gfx950"
+#define BJJ_VERSION_STRING "bjj-hip 0.5.0 gfx950"
 // Fixed-base window width.  window_bits = 0 (default) is a modest 23 bits = 11 signed digits, 5.9 GB: a library that
 // is linked into a process with other tenants of the GPU must not take half of the HBM unasked.  The wide tables are
 // opt-in: an explicit width (28 bits = 9 digits, 9 x (2^27 + 1) entries = 154.6 GB of the 288 GB; 26 = 10 digits,
@@ -75,6 +80,7 @@ struct DeviceGuard {
   DeviceGuard dg_(dev);                                                                                         \
   if (dg_.err != hipSuccess) return set_err(BJJ_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(dg_.err))
 
+#define BJJ_PIPE_BUFS 4
 #define BJJ_SCRATCH_SETS 2
 #define BJJ_STREAM_MARKS 8
 struct ScratchSet {
@@ -146,12 +152,25 @@ struct bjj_ctx {
   // calls that use no scratch (Poseidon, point add, codec, sign) are not ordered behind anything; their completion
   // events are only kept so that bjj_sync can wait for them: one slot per distinct caller stream
   StreamMark marks[BJJ_STREAM_MARKS];
-  // host-pointer API: chunked pipeline  user memory -> pinned[b] -H2D-> dstage[b] -kernel-> dstage[b] -D2H-> pinned[b] -> user
-  hipStream_t s_in = nullptr, s_out = nullptr;
-  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-  uint8_t* pinned[2] = {nullptr, nullptr};
-  uint8_t* dstage[2] = {nullptr, nullptr};
-  size_t pipe_bytes = 0;
+  // host-pointer API (run_pipelined): chunked pipeline over a ring of BJJ_PIPE_BUFS device staging buffers
+  //   caller's array -[H2D, s_in]-> dstage[b] -[kernels, stream / stream2 alternating]-> dstage[b] -[D2H, s_out]-> caller's array
+  // straight from / to the caller's memory when that is pinned (bjj_host_alloc / bjj_host_register / any hipHostMalloc'd or
+  // hipHostRegister'ed range); a PAGEABLE array goes through pinned[b], moved by the context's copy workers (CopyPool), never by
+  // the enqueueing thread
+  hipStream_t s_in = nullptr, s_out = nullptr, stream2 = nullptr;
+  hipEvent_t ev_in[BJJ_PIPE_BUFS] = {}, ev_k[BJJ_PIPE_BUFS] = {}, ev_out[BJJ_PIPE_BUFS] = {};
+  uint8_t* pinned[BJJ_PIPE_BUFS] = {};
+  uint8_t* dstage[BJJ_PIPE_BUFS] = {};
+  size_t pipe_bytes = 0;       // bytes of each dstage[b]
+  size_t pinned_bytes = 0;     // bytes of each pinned[b] (allocated on the first call that has a pageable array)
+  CopyPool* pool = nullptr;
+  size_t pipe_chunk = 0, pipe_first = 0;   // chunk schedule (items): first chunk, doubling up to pipe_chunk
+  bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
+  // what the last calls did (bjj_get_info; tests and the bench line read these)
+  int last_k1 = -1, last_k2 = -1, last_verify_mode = -1;
+  int idle_alternations = 0;               // expect_overlap: consecutive alternating calls that found the other set idle
+  u32 last_host_direct = 0, last_host_staged = 0, last_host_chunks = 0;
+  u32* err_words = nullptr;                // pinned: the slot queues' give-up counters as read back by ctx_check_slot_queues
 };
 
 static int grid_for(const bjj_ctx* c, size_t n, int blocks_per_cu, int block = BJJ_BLOCK) {
@@ -215,13 +234,27 @@ static int wait_for_other_sets(bjj_ctx* c, const ScratchSet* mine, hipStream_t s
     if (&S != mine && S.have_last && S.last_stream != st) HIPCK(hipStreamWaitEvent(st, S.ev_last, 0));
   return BJJ_OK;
 }
-// K1 comes in two shapes (k_fixed.hip): one 512-lane workgroup per CU, or two of 256 lanes.  The second is for overlapping
-// launches: each launch then occupies one workgroup slot per CU and the other launch's main loop covers its inversion.  It is
-// picked from the caller's PATTERN (streams_alternate), not from a racy look at the device: under the 20-launch protocol of
-// the round-end bench the per-call event query gave the first launches of a run the wrong shape.
+// Will this launch share the chip with another launch of the context?  The kernels come in a form for a launch that runs alone
+// and a form for overlapping launches (K1: one 512-lane workgroup per CU / two of 256 lanes; K2: tiles / grid-strided; verify:
+// scan in line / on the priority stream), and the wrong form costs: K1's two-workgroup shape run ALONE takes 0.86 ms instead of
+// 0.61 ms (profiles/r05_fixed_base_two_stream_summary.md).  Pattern AND state decide:
+//   * another set's launch is still queued or running (event query)          -> overlap
+//   * else the caller alternates over streams (streams_alternate) and this is the FIRST such call that finds the other set
+//     idle -- the first launch behind a synchronisation point of a caller that ping-pongs, e.g. launch 0 of a timed region:
+//     the pattern says the next launch follows at once (profiles/r04_driver_protocol.txt)                   -> overlap
+//   * else (one stream; or a caller that alternates but synchronises between its launches, so that the second call in a row
+//     finds the other set idle)                                                                             -> alone
+// One rule for the three entry points (enqueue_verify used the bare event query until round 4).
+static bool expect_overlap(bjj_ctx* c, const ScratchSet* S) {
+  if (other_launch_in_flight(c, S)) { c->idle_alternations = 0; return true; }
+  if (!streams_alternate(c, S)) { c->idle_alternations = 0; return false; }
+  if (c->idle_alternations < 2) c->idle_alternations++;
+  return c->idle_alternations < 2;
+}
 static int fixed_base_variant(bjj_ctx* c, const ScratchSet* S) {
-  if (c->k1_variant >= 0) return c->k1_variant;
-  return streams_alternate(c, S) ? 1 : 0;
+  const int kv = c->k1_variant >= 0 ? c->k1_variant : (expect_overlap(c, S) ? 1 : 0);
+  c->last_k1 = kv;
+  return kv;
 }
 // completion mark of a call that used no scratch (bjj_sync waits for these)
 static int mark_stream(bjj_ctx* c, hipStream_t st) {
@@ -249,8 +282,8 @@ static int slot_queue_fill(bjj_ctx* c, u32* d_q, u32 cap) {
   std::vector<u32> h((size_t)c->xccs * stride, 0u);
   for (int x = 0; x < c->xccs; x++)
     for (u32 i = 0; i < cap; i++) h[(size_t)x * stride + BJJ_SLOTQ_HDR + i] = (u32)x * cap + i + 1u;   // slot id + 1
-  HIPCK(hipMemcpy(d_q, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice));
-  HIPCK(hipStreamSynchronize(nullptr));
+  HIPCK(hipMemcpyAsync(d_q, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));   // pageable source: staged before the call returns
+  HIPCK(hipStreamSynchronize(c->stream));
   return BJJ_OK;
 }
 static int slot_queue_make(bjj_ctx* c, u32** d_q, u32* have_cap, u32 cap) {
@@ -262,16 +295,38 @@ static int slot_queue_make(bjj_ctx* c, u32** d_q, u32* have_cap, u32 cap) {
   *have_cap = cap;
   return BJJ_OK;
 }
-// After the device is idle: did a pop ever give up waiting for a slot?  (number of such pops; the rings are rebuilt if so)
-static int slot_queue_check(bjj_ctx* c, u32* d_q, u32 cap, unsigned long long* starved) {
-  if (!d_q) return BJJ_OK;
-  const size_t stride = BJJ_SLOTQ_HDR + cap;
-  std::vector<u32> h((size_t)c->xccs * stride, 0u);
-  HIPCK(hipMemcpy(h.data(), d_q, h.size() * sizeof(u32), hipMemcpyDeviceToHost));
-  unsigned long long bad = 0;
-  for (int x = 0; x < c->xccs; x++) bad += h[(size_t)x * stride + BJJ_SLOTQ_ERR];
-  if (bad) { int rc = slot_queue_fill(c, d_q, cap); if (rc) return rc; }
-  *starved += bad;
+// After the launches in question have completed: did a pop ever give up waiting for a slot?  Only the give-up counters travel
+// (one word per XCD and ring: a strided asynchronous copy on the context's own non-blocking stream into pinned memory -- not
+// the whole rings through the legacy null stream, which also made the caller wait for other tenants' blocking streams, ADVICE
+// r04); a ring is read in full and rebuilt only when its counter is non-zero.  Every entry point that synchronises for the
+// caller ends with this check (bjj_sync, the host-pointer pipeline, the multi-GPU pipeline): a launch that worked on the
+// overflow slot must never be reported as BJJ_OK.
+#define BJJ_ERR_WORDS 16   // per ring (>= XCDs)
+static int ctx_check_slot_queues(bjj_ctx* c, const char* who) {
+  struct Ring { u32* q; u32 cap; };
+  Ring rings[2 * BJJ_SCRATCH_SETS];
+  int nr = 0;
+  for (ScratchSet& S : c->set) {
+    if (S.slotq) rings[nr++] = {S.slotq, S.slot_cap};
+    if (S.slotq2) rings[nr++] = {S.slotq2, S.slot_cap2};
+  }
+  if (!nr) return BJJ_OK;
+  if (!c->err_words) HIPCK(hipHostMalloc((void**)&c->err_words, sizeof(u32) * BJJ_ERR_WORDS * 2 * BJJ_SCRATCH_SETS, hipHostMallocDefault));
+  const int nx = c->xccs < BJJ_ERR_WORDS ? c->xccs : BJJ_ERR_WORDS;
+  for (int r = 0; r < nr; r++)
+    HIPCK(hipMemcpy2DAsync(c->err_words + r * BJJ_ERR_WORDS, sizeof(u32), rings[r].q + BJJ_SLOTQ_ERR, (BJJ_SLOTQ_HDR + (size_t)rings[r].cap) * sizeof(u32),
+                           sizeof(u32), (size_t)nx, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  unsigned long long starved = 0;
+  for (int r = 0; r < nr; r++) {
+    unsigned long long bad = 0;
+    for (int x = 0; x < nx; x++) bad += c->err_words[r * BJJ_ERR_WORDS + x];
+    if (bad) { int rc = slot_queue_fill(c, rings[r].q, rings[r].cap); if (rc) return rc; }
+    starved += bad;
+  }
+  if (starved)
+    return set_err(BJJ_E_HIP, std::string(who) + ": " + std::to_string(starved) + " workgroup(s) gave up waiting for a per-lane table slot; the results of "
+                   "the verify / variable-base launches since the last synchronising call are not valid (slot queues rebuilt)");
   return BJJ_OK;
 }
 
@@ -307,13 +362,25 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
   return BJJ_OK;
 }
 // ---------------------------------------------------------------------------
-// Host-pointer API plumbing.  Pageable hipMemcpy runs at ~3 GB/s and would dominate every call
-// (29.8 ms of copies around a 1.1 ms kernel for 2^20 fixed-base multiplications), so batches are
-// cut into chunks that flow through two pinned staging buffers: while the kernels of chunk c run
-// on the context's stream, chunk c+1 is copied in (s_in) and chunk c-1 is copied out (s_out).
-// Kernels of different chunks stay on ONE stream, so the context's scratch is never shared.
+// Host-pointer API plumbing.
+//
+// A call is cut into chunks that flow through a ring of BJJ_PIPE_BUFS device staging buffers:
+//     H2D of chunk c+1 (s_in)  |  kernels of chunk c (stream / stream2, alternating)  |  D2H of chunk c-1 (s_out)
+// * Pinned caller memory (bjj_host_alloc, bjj_host_register, or anything the HIP runtime reports as pinned host memory) is
+//   copied from / to DIRECTLY: no staging copy at all, the bound is the slower PCIe direction (2^20 fixed-base
+//   multiplications: 64 MB of results, 1.19 ms).  Round 4 staged everything through two pinned buffers with a memcpy on the
+//   calling thread and ran at 17 % of the device rate.
+// * A pageable array goes through the ring's pinned twin pinned[b]; the memcpy between it and the caller's memory is done by
+//   the context's copy workers (CopyPool) while the calling thread only enqueues.  (A pageable hipMemcpy runs at ~3 GB/s.)
+// * The chunk kernels alternate over the context's two compute streams, i.e. its two scratch sets: consecutive chunks overlap
+//   on the chip like the two-stream launches of the device-pointer API (verify in 2^18-item chunks on ONE stream ran 6.76 ms
+//   per chunk, on two 4.47 ms: profiles/r04_throughput_vs_batch.txt).
+// * The first chunk is small (2^16 items) and the size doubles up to 2^18: the head of the pipeline -- copy in + compute of
+//   chunk 0, during which the other engines idle -- is short, and the D2H engine never waits for a kernel afterwards.
+//   BJJ_PIPE_FIRST_CHUNK / BJJ_PIPE_CHUNK (items) override the schedule.
 // ---------------------------------------------------------------------------
 #define BJJ_PIPE_CHUNK ((size_t)1 << 18)
+#define BJJ_PIPE_FIRST_CHUNK ((size_t)1 << 16)
 struct PipeSpec {
   int n_in, n_out;
   const uint8_t* in[4]; size_t in_stride[4];
@@ -321,50 +388,91 @@ struct PipeSpec {
   bool secret;          // inputs are key material: wipe the staging buffers when the call is done
 };
 static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
-// Staging copies between the caller's pageable memory and the pinned buffers: one thread moves ~30 GB/s, PCIe 54 GB/s
-// (tools/ubench/pcie_probe.cpp), so copies of 4 MB and more are split over up to four threads.
-static void staged_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
-  const size_t kMin = (size_t)4 << 20;
-  unsigned hw = std::thread::hardware_concurrency();
-  size_t parts = bytes / kMin;
-  if (parts > 4) parts = 4;
-  if (hw && parts > hw) parts = hw;
-  if (parts < 2) { memcpy(dst, src, bytes); return; }
-  const size_t per = (bytes / parts + 63) & ~(size_t)63;
-  std::thread th[3];
-  size_t started = 0;
-  for (size_t i = 1; i < parts; i++) {
-    const size_t lo = i * per, len = (i + 1 == parts) ? bytes - lo : per;
-    try { th[started] = std::thread([=] { memcpy(dst + lo, src + lo, len); }); started++; }
-    catch (...) { memcpy(dst + lo, src + lo, len); }   // no thread available: copy here
-  }
-  memcpy(dst, src, per);
-  for (size_t i = 0; i < started; i++) th[i].join();
-}
 static void secure_bzero(void* p, size_t n) {
   memset(p, 0, n);
   __asm__ __volatile__("" : : "r"(p) : "memory");   // the stores must not be elided as dead
 }
-static int ensure_pipe(bjj_ctx* c, size_t bytes) {
+
+// ---- pinned host memory ---------------------------------------------------------------------------------------------------
+// Ranges handed out by bjj_host_alloc (hipHostMalloc) or pinned in place by bjj_host_register (hipHostRegister): process-wide,
+// any context may copy from / to them.  Memory pinned by somebody else (torch's pin_memory, the caller's own hipHostMalloc) is
+// recognised through the driver's pointer attributes.  A wrong answer can only cost speed: hipMemcpyAsync accepts any host
+// pointer, and every call waits for its copies before it returns.
+struct HostRange { uintptr_t lo, hi; bool owned; };
+static std::mutex g_host_mu;
+static std::vector<HostRange> g_host_ranges;
+static bool host_range_registered(const void* p, size_t bytes) {
+  const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  for (const HostRange& r : g_host_ranges) if (lo >= r.lo && hi <= r.hi) return true;
+  return false;
+}
+static bool driver_attr(const void* p, hipPointerAttribute_t* a) {
+  memset(a, 0, sizeof(*a));
+  if (hipPointerGetAttributes(a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // an ordinary malloc'd pointer
+  return true;
+}
+static bool host_range_pinned(const void* p, size_t bytes) {
+  if (!bytes || host_range_registered(p, bytes)) return true;
+  hipPointerAttribute_t a0, a1;
+  if (!driver_attr(p, &a0) || a0.type != hipMemoryTypeHost) return false;
+  if (!driver_attr((const uint8_t*)p + bytes - 1, &a1) || a1.type != hipMemoryTypeHost) return false;
+  // both ends are pinned: one mapping?  (two pinned allocations with a pageable hole between them would pass the end test)
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (a0.devicePointer && hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a0.devicePointer) == hipSuccess)
+    return (uintptr_t)a0.devicePointer - (uintptr_t)base + bytes <= size;
+  (void)hipGetLastError();
+  return a0.devicePointer && a1.devicePointer && (uintptr_t)a1.devicePointer - (uintptr_t)a0.devicePointer == bytes - 1;
+}
+
+static size_t env_items(const char* name, size_t dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const unsigned long long v = strtoull(e, nullptr, 0);
+  return v >= 64 && v <= ((size_t)1 << 24) ? ((size_t)v + 63) & ~(size_t)63 : dflt;
+}
+// streams / events of the pipeline, the device staging ring (dev_bytes each) and -- only when a pageable array takes part --
+// its pinned twin and the copy workers
+static int ensure_pipe(bjj_ctx* c, size_t dev_bytes, size_t pinned_bytes) {
   ENTER_DEVICE(c->device);
   if (!c->s_in) {
     HIPCK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
     HIPCK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-    for (int b = 0; b < 2; b++) {
+    HIPCK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
       HIPCK(hipEventCreateWithFlags(&c->ev_in[b], hipEventDisableTiming));
       HIPCK(hipEventCreateWithFlags(&c->ev_k[b], hipEventDisableTiming));
       HIPCK(hipEventCreateWithFlags(&c->ev_out[b], hipEventDisableTiming));
     }
+    c->pipe_chunk = env_items("BJJ_PIPE_CHUNK", BJJ_PIPE_CHUNK);
+    c->pipe_first = env_items("BJJ_PIPE_FIRST_CHUNK", BJJ_PIPE_FIRST_CHUNK);
+    if (c->pipe_first > c->pipe_chunk) c->pipe_first = c->pipe_chunk;
+    if (const char* e = getenv("BJJ_HOST_FORCE_STAGED")) c->force_staged = e[0] == '1';
   }
-  if (bytes > c->pipe_bytes) {
+  if (dev_bytes > c->pipe_bytes) {
     HIPCK(hipStreamSynchronize(c->stream));
-    for (int b = 0; b < 2; b++) {
-      if (c->pinned[b]) { HIPCK(hipHostFree(c->pinned[b])); c->pinned[b] = nullptr; }
+    HIPCK(hipStreamSynchronize(c->stream2));
+    for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
       if (c->dstage[b]) { HIPCK(hipFree(c->dstage[b])); c->dstage[b] = nullptr; }
-      HIPCK(hipHostMalloc((void**)&c->pinned[b], bytes, hipHostMallocDefault));
-      HIPCK(hipMalloc((void**)&c->dstage[b], bytes));
+      HIPCK(hipMalloc((void**)&c->dstage[b], dev_bytes));
     }
-    c->pipe_bytes = bytes;
+    c->pipe_bytes = dev_bytes;
+  }
+  if (pinned_bytes > c->pinned_bytes) {
+    for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
+      if (c->pinned[b]) { secure_bzero(c->pinned[b], c->pinned_bytes); HIPCK(hipHostFree(c->pinned[b])); c->pinned[b] = nullptr; }
+      HIPCK(hipHostMalloc((void**)&c->pinned[b], pinned_bytes, hipHostMallocDefault));
+    }
+    c->pinned_bytes = pinned_bytes;
+  }
+  if (pinned_bytes && !c->pool) {
+    int want = 4;
+    if (const char* e = getenv("BJJ_STAGE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 32) want = v; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && (unsigned)want > hw) want = (int)hw;
+    c->pool = new (std::nothrow) CopyPool();
+    if (!c->pool || !c->pool->start(want)) { delete c->pool; c->pool = nullptr; return set_err(BJJ_E_NOMEM, "host-pointer pipeline: cannot start the copy workers"); }
   }
   return BJJ_OK;
 }
@@ -372,50 +480,115 @@ static int ensure_pipe(bjj_ctx* c, size_t bytes) {
 template <typename Launch>
 static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch) {
   ENTER_DEVICE(c->device);
-  const size_t chunk = n < BJJ_PIPE_CHUNK ? n : BJJ_PIPE_CHUNK;
-  size_t off_in[4], off_out[4], tot = 0, in_bytes = 0;
+  { int rc = ensure_pipe(c, 0, 0); if (rc) return rc; }   // streams, events, the chunk schedule
+  // ---- chunk schedule: first, 2 first, 4 first ... capped at pipe_chunk
+  std::vector<size_t> lo_of;     // lo_of[ch] .. lo_of[ch + 1]
+  {
+    size_t lo = 0, sz = c->pipe_first;
+    while (lo < n) { lo_of.push_back(lo); lo += sz < n - lo ? sz : n - lo; if (sz < c->pipe_chunk) sz = sz * 2 < c->pipe_chunk ? sz * 2 : c->pipe_chunk; }
+    lo_of.push_back(n);
+  }
+  const size_t nchunks = lo_of.size() - 1;
+  const size_t chunk = n < c->pipe_chunk ? n : c->pipe_chunk;   // the largest chunk: sizes the ring
+  // ---- which arrays are pinned (copied directly) and which go through the pinned twin
+  bool in_direct[4], out_direct[4];
+  u32 n_direct = 0, n_staged = 0;
+  for (int i = 0; i < sp.n_in; i++) { in_direct[i] = !c->force_staged && host_range_pinned(sp.in[i], n * sp.in_stride[i]); (in_direct[i] ? n_direct : n_staged)++; }
+  for (int i = 0; i < sp.n_out; i++) { out_direct[i] = !c->force_staged && host_range_pinned(sp.out[i], n * sp.out_stride[i]); (out_direct[i] ? n_direct : n_staged)++; }
+  size_t off_in[4], off_out[4], tot = 0;
   for (int i = 0; i < sp.n_in; i++) { off_in[i] = tot; tot += up16(chunk * sp.in_stride[i]); }
-  in_bytes = tot;
   for (int i = 0; i < sp.n_out; i++) { off_out[i] = tot; tot += up16(chunk * sp.out_stride[i]); }
-  int rc = ensure_pipe(c, tot); if (rc) return rc;
-  const size_t nchunks = (n + chunk - 1) / chunk;
-  auto drain = [&](size_t ch) -> int {  // copy the finished outputs of chunk `ch` to user memory
-    const int b = (int)(ch & 1);
-    const size_t lo = ch * chunk, cnt = (lo + chunk <= n ? chunk : n - lo);
-    HIPCK(hipEventSynchronize(c->ev_out[b]));
-    for (int i = 0; i < sp.n_out; i++) staged_copy(sp.out[i] + lo * sp.out_stride[i], c->pinned[b] + off_out[i], cnt * sp.out_stride[i]);
+  { int rc = ensure_pipe(c, tot, n_staged ? tot : 0); if (rc) return rc; }
+  c->last_host_direct = n_direct; c->last_host_staged = n_staged; c->last_host_chunks = (u32)nchunks;
+  CopyPool* pool = c->pool;
+  std::vector<CopyGroup> g_in(nchunks), g_out(nchunks);
+  auto cnt_of = [&](size_t ch) { return lo_of[ch + 1] - lo_of[ch]; };
+  // pageable inputs of chunk ch -> pinned[b] (workers)
+  auto submit_in = [&](size_t ch) {
+    const int b = (int)(ch % BJJ_PIPE_BUFS);
+    for (int i = 0; i < sp.n_in; i++)
+      if (!in_direct[i]) pool->submit(c->pinned[b] + off_in[i], sp.in[i] + lo_of[ch] * sp.in_stride[i], cnt_of(ch) * sp.in_stride[i], &g_in[ch]);
+  };
+  // chunk ch has left the device: pageable outputs pinned[b] -> caller (workers)
+  size_t harvested = 0;           // chunks whose copy-out has been submitted (in order)
+  auto harvest = [&](size_t ch, bool block) -> int {
+    const int b = (int)(ch % BJJ_PIPE_BUFS);
+    if (block) HIPCK(hipEventSynchronize(c->ev_out[b]));
+    else {
+      const hipError_t q = hipEventQuery(c->ev_out[b]);
+      (void)hipGetLastError();
+      if (q != hipSuccess) return 1;   // not yet
+    }
+    for (int i = 0; i < sp.n_out; i++)
+      if (!out_direct[i]) pool->submit(sp.out[i] + lo_of[ch] * sp.out_stride[i], c->pinned[b] + off_out[i], cnt_of(ch) * sp.out_stride[i], &g_out[ch]);
     return BJJ_OK;
   };
-  auto body = [&]() -> int {
-    for (size_t ch = 0; ch < nchunks; ch++) {
-      const int b = (int)(ch & 1);
-      const size_t lo = ch * chunk, cnt = (lo + chunk <= n ? chunk : n - lo);
-      if (ch >= 2) { int r = drain(ch - 2); if (r) return r; }     // frees pinned[b] and dstage[b]
-      for (int i = 0; i < sp.n_in; i++) staged_copy(c->pinned[b] + off_in[i], sp.in[i] + lo * sp.in_stride[i], cnt * sp.in_stride[i]);
-      HIPCK(hipMemcpyAsync(c->dstage[b], c->pinned[b], in_bytes, hipMemcpyHostToDevice, c->s_in));
-      HIPCK(hipEventRecord(c->ev_in[b], c->s_in));
-      HIPCK(hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
-      void* d_in[4]; void* d_out[4];
-      for (int i = 0; i < sp.n_in; i++) d_in[i] = c->dstage[b] + off_in[i];
-      for (int i = 0; i < sp.n_out; i++) d_out[i] = c->dstage[b] + off_out[i];
-      int r = launch(d_in, d_out, cnt, (void*)c->stream); if (r) return r;
-      HIPCK(hipEventRecord(c->ev_k[b], c->stream));
-      HIPCK(hipStreamWaitEvent(c->s_out, c->ev_k[b], 0));
-      HIPCK(hipMemcpyAsync(c->pinned[b] + in_bytes, c->dstage[b] + in_bytes, tot - in_bytes, hipMemcpyDeviceToHost, c->s_out));
-      HIPCK(hipEventRecord(c->ev_out[b], c->s_out));
-    }
-    if (nchunks >= 2) { int r = drain(nchunks - 2); if (r) return r; }
-    return drain(nchunks - 1);
+  // chunk ch is completely done (its results are in the caller's memory): its ring slot is free
+  auto finish = [&](size_t ch) -> int {
+    while (harvested <= ch) { int r = harvest(harvested, true); if (r) return r; harvested++; }
+    if (pool) pool->wait(&g_out[ch]);
+    return BJJ_OK;
   };
-  rc = body();
-  if (sp.secret) {  // key material went through both staging levels: wipe them (also on the error path)
-    hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->s_out);
-    for (int b = 0; b < 2; b++) {
+  auto enqueue = [&](size_t ch) -> int {
+    const int b = (int)(ch % BJJ_PIPE_BUFS);
+    const size_t lo = lo_of[ch], cnt = cnt_of(ch);
+    for (int i = 0; i < sp.n_in; i++)
+      HIPCK(hipMemcpyAsync(c->dstage[b] + off_in[i], in_direct[i] ? sp.in[i] + lo * sp.in_stride[i] : c->pinned[b] + off_in[i], cnt * sp.in_stride[i],
+                           hipMemcpyHostToDevice, c->s_in));
+    HIPCK(hipEventRecord(c->ev_in[b], c->s_in));
+    hipStream_t ks = (ch & 1) ? c->stream2 : c->stream;
+    HIPCK(hipStreamWaitEvent(ks, c->ev_in[b], 0));
+    void* d_in[4]; void* d_out[4];
+    for (int i = 0; i < sp.n_in; i++) d_in[i] = c->dstage[b] + off_in[i];
+    for (int i = 0; i < sp.n_out; i++) d_out[i] = c->dstage[b] + off_out[i];
+    int r = launch(d_in, d_out, cnt, (void*)ks); if (r) return r;
+    HIPCK(hipEventRecord(c->ev_k[b], ks));
+    HIPCK(hipStreamWaitEvent(c->s_out, c->ev_k[b], 0));
+    for (int i = 0; i < sp.n_out; i++)
+      HIPCK(hipMemcpyAsync(out_direct[i] ? sp.out[i] + lo * sp.out_stride[i] : c->pinned[b] + off_out[i], c->dstage[b] + off_out[i], cnt * sp.out_stride[i],
+                           hipMemcpyDeviceToHost, c->s_out));
+    HIPCK(hipEventRecord(c->ev_out[b], c->s_out));
+    return BJJ_OK;
+  };
+  size_t enqueued = 0;
+  auto body = [&]() -> int {
+    size_t next_in = 0;           // next chunk whose pageable inputs are handed to the workers (one chunk ahead of the enqueue)
+    for (size_t ch = 0; ch < nchunks; ch++) {
+      while (next_in < nchunks && next_in <= ch + 1) {
+        if (next_in >= BJJ_PIPE_BUFS) { int r = finish(next_in - BJJ_PIPE_BUFS); if (r) return r; }   // frees ring slot next_in % BJJ_PIPE_BUFS
+        if (n_staged) submit_in(next_in);
+        next_in++;
+      }
+      if (pool) pool->wait(&g_in[ch]);
+      { int r = enqueue(ch); if (r) return r; }
+      enqueued = ch + 1;
+      while (n_staged && harvested < enqueued) {   // results that have already arrived: start their copy-out, do not wait
+        const int r = harvest(harvested, false);
+        if (r == 1) break;
+        if (r) return r;
+        harvested++;
+      }
+    }
+    for (size_t ch = nchunks >= BJJ_PIPE_BUFS ? nchunks - BJJ_PIPE_BUFS : 0; ch < nchunks; ch++) { int r = finish(ch); if (r) return r; }
+    return BJJ_OK;
+  };
+  int rc = body();
+  if (rc) {   // error path: nothing may still be writing into the caller's memory or reading the ring when we return
+    hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->s_out);
+    (void)hipGetLastError();
+    if (pool) for (size_t ch = 0; ch < nchunks; ch++) { pool->wait(&g_in[ch]); pool->wait(&g_out[ch]); }
+  }
+  if (sp.secret) {  // key material went through the staging levels: wipe them (also on the error path)
+    hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->s_out);
+    for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
       if (c->dstage[b]) hipMemsetAsync(c->dstage[b], 0, tot, c->stream);
-      if (c->pinned[b]) secure_bzero(c->pinned[b], tot);
+      if (c->pinned[b]) secure_bzero(c->pinned[b], c->pinned_bytes);
     }
     hipStreamSynchronize(c->stream);
   }
+  // the call has synchronised for the caller: a verify / variable-base workgroup that gave up waiting for a table slot makes
+  // it an error here, not at some later bjj_sync
+  if (!rc) rc = ctx_check_slot_queues(c, "host-pointer call");
   return rc;
 }
 static int ensure_codec(bjj_ctx* c, ScratchSet* S, size_t n) {  // 162 bytes per item of intermediate records
@@ -449,15 +622,19 @@ static void ctx_destroy(bjj_ctx* c) {
   if (c->bases) hipFree(c->bases);
   if (c->ct_table) hipFree(c->ct_table);
   if (c->ct_bases) hipFree(c->ct_bases);
-  for (int b = 0; b < 2; b++) {
-    if (c->pinned[b]) { secure_bzero(c->pinned[b], c->pipe_bytes); hipHostFree(c->pinned[b]); }
+  delete c->pool;   // joins the copy workers
+  c->pool = nullptr;
+  for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
+    if (c->pinned[b]) { secure_bzero(c->pinned[b], c->pinned_bytes); hipHostFree(c->pinned[b]); }
     if (c->dstage[b]) { hipMemset(c->dstage[b], 0, c->pipe_bytes); hipFree(c->dstage[b]); }
     if (c->ev_in[b]) hipEventDestroy(c->ev_in[b]);
     if (c->ev_k[b]) hipEventDestroy(c->ev_k[b]);
     if (c->ev_out[b]) hipEventDestroy(c->ev_out[b]);
   }
+  if (c->err_words) hipHostFree(c->err_words);
   if (c->s_in) hipStreamDestroy(c->s_in);
   if (c->s_out) hipStreamDestroy(c->s_out);
+  if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -571,17 +748,9 @@ int bjj_sync(bjj_ctx* c) {
   for (StreamMark& k : c->marks)
     if (k.used) HIPCK(hipEventSynchronize(k.ev));
   HIPCK(hipStreamSynchronize(c->stream));
-  // everything the context enqueued has run: a slot-queue pop that gave up waiting (k_common.hpp) is an ERROR of the launches
+  // everything the context enqueued has run: a slot-queue pop that gave up waiting (slot_queue.hpp) is an ERROR of the launches
   // just completed -- reported here instead of a hung GPU; the rings are rebuilt so that the context stays usable
-  unsigned long long starved = 0;
-  for (ScratchSet& S : c->set) {
-    int rc = slot_queue_check(c, S.slotq, S.slot_cap, &starved); if (rc) return rc;
-    rc = slot_queue_check(c, S.slotq2, S.slot_cap2, &starved); if (rc) return rc;
-  }
-  if (starved)
-    return set_err(BJJ_E_HIP, "bjj_sync: " + std::to_string(starved) + " workgroup(s) gave up waiting for a per-lane table slot; the results of "
-                   "the verify / variable-base launches since the last bjj_sync are not valid (slot queues rebuilt)");
-  return BJJ_OK;
+  return ctx_check_slot_queues(c, "bjj_sync");
 }
 void* bjj_stream(bjj_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
@@ -605,6 +774,64 @@ int bjj_reserve(bjj_ctx* c, size_t n) {
   if (!c) return set_err(BJJ_E_INVALID, "bjj_reserve: ctx is NULL");
   return reserve_sets(c, n, 1, true);
 }
+// ---- pinned host memory for the host-pointer entry points (include/bjj_hip.h) ----------------------------------------------
+int bjj_host_alloc(bjj_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return set_err(BJJ_E_INVALID, "bjj_host_alloc: NULL argument");
+  *out = nullptr;
+  if (!bytes) return set_err(BJJ_E_INVALID, "bjj_host_alloc: zero bytes");
+  ENTER_DEVICE(c->device);
+  void* p = nullptr;
+  const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+  if (e != hipSuccess) { (void)hipGetLastError(); return set_err(BJJ_E_NOMEM, std::string("bjj_host_alloc: ") + hipGetErrorString(e)); }
+  try {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    g_host_ranges.push_back({(uintptr_t)p, (uintptr_t)p + bytes, true});
+  } catch (...) { hipHostFree(p); return set_err(BJJ_E_NOMEM, "bjj_host_alloc: out of host memory"); }
+  *out = p;
+  return BJJ_OK;
+}
+static int host_range_drop(void* p, bool owned, const char* who) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  for (size_t i = 0; i < g_host_ranges.size(); i++)
+    if (g_host_ranges[i].lo == (uintptr_t)p && g_host_ranges[i].owned == owned) {
+      g_host_ranges.erase(g_host_ranges.begin() + (long)i);
+      return BJJ_OK;
+    }
+  return set_err(BJJ_E_INVALID, std::string(who) + ": not a pointer this library " + (owned ? "allocated" : "registered"));
+}
+int bjj_host_free(bjj_ctx* c, void* p) {
+  if (!c) return set_err(BJJ_E_INVALID, "bjj_host_free: ctx is NULL");
+  if (!p) return BJJ_OK;
+  { int rc = host_range_drop(p, true, "bjj_host_free"); if (rc) return rc; }
+  ENTER_DEVICE(c->device);
+  HIPCK(hipHostFree(p));
+  return BJJ_OK;
+}
+int bjj_host_register(bjj_ctx* c, void* p, size_t bytes) {
+  if (!c || !p || !bytes) return set_err(BJJ_E_INVALID, "bjj_host_register: NULL argument or zero bytes");
+  ENTER_DEVICE(c->device);
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) { (void)hipGetLastError(); return set_err(BJJ_E_HIP, std::string("bjj_host_register: ") + hipGetErrorString(e)); }
+  try {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    g_host_ranges.push_back({(uintptr_t)p, (uintptr_t)p + bytes, false});
+  } catch (...) { hipHostUnregister(p); return set_err(BJJ_E_NOMEM, "bjj_host_register: out of host memory"); }
+  return BJJ_OK;
+}
+int bjj_host_unregister(bjj_ctx* c, void* p) {
+  if (!c) return set_err(BJJ_E_INVALID, "bjj_host_unregister: ctx is NULL");
+  if (!p) return BJJ_OK;
+  { int rc = host_range_drop(p, false, "bjj_host_unregister"); if (rc) return rc; }
+  ENTER_DEVICE(c->device);
+  HIPCK(hipHostUnregister(p));
+  return BJJ_OK;
+}
+int bjj_host_is_pinned(bjj_ctx* c, const void* p, size_t bytes) {
+  if (!c || !p) return set_err(BJJ_E_INVALID, "bjj_host_is_pinned: NULL argument");
+  ENTER_DEVICE(c->device);
+  return host_range_pinned(p, bytes) ? 1 : 0;
+}
+
 int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   if (!c || !out) return set_err(BJJ_E_INVALID, "bjj_get_info: NULL argument");
   const size_t cap = out->struct_size;
@@ -617,7 +844,7 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   info->window_bits = c->W;
   info->n_windows = c->nwin;
   info->table_bytes = c->table_bytes;
-  info->scratch_bytes = 2 * c->pipe_bytes;
+  info->scratch_bytes = BJJ_PIPE_BUFS * (uint64_t)c->pipe_bytes;
   for (const ScratchSet& S : c->set)
     info->scratch_bytes += S.scratch_items * 64 + S.vb_threads * VB_TABLE_WORDS_MAX * sizeof(u32) + S.slow_items * 4 +
                            (S.codec_items ? S.codec_items * 162 + 64 : 0);
@@ -627,6 +854,15 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   info->kernel_verify = "bjj_k_eddsa_verify_groups";
   info->init_ms = c->init_ms;
   info->signer_constant_time = c->ct_signer ? 1 : 0;
+  info->last_fixed_base_shape = c->last_k1;
+  info->last_var_base_form = c->last_k2;
+  info->last_verify_dispatch = c->last_verify_mode;
+  info->last_host_direct_arrays = c->last_host_direct;
+  info->last_host_staged_arrays = c->last_host_staged;
+  info->last_host_chunks = c->last_host_chunks;
+  info->host_copy_threads = c->pool ? (int)c->pool->th.size() : 0;
+  info->kernel_fixed_base_overlap = "bjj_k_mul_fixed_base_2x256";   // the forms overlapping launches get (expect_overlap)
+  info->kernel_var_base_overlap = "bjj_k_mul_var_base";
   const size_t fill = cap < sizeof(full) ? cap : sizeof(full);   // never past the caller's struct
   full.struct_size = (uint32_t)fill;
   memcpy(out, &full, fill);
@@ -697,12 +933,12 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
   if (!d_pts || !d_scalars || !d_out || !aligned16(d_pts) || !aligned16(d_scalars) || !aligned16(d_out))
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   SET_ENTER(c, stream, n, false);
-  // k_var.hip: the two forms of K2.  Like K1's shape the form follows the caller's PATTERN (streams_alternate) first, the racy
-  // look at the device second: a caller that ping-pongs over two streams gets the grid-strided form for every launch of the
-  // run, a one-stream caller the tiles.  A large launch queues behind the other sets and runs alone (tiles).
-  bool overlap = streams_alternate(c, S) || other_launch_in_flight(c, S);
-  if (overlap && c->k2_variant < 0 && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; overlap = false; }
+  // k_var.hip: the two forms of K2 -- tiles for a launch that runs alone, grid-strided for overlapping launches
+  // (expect_overlap).  A large launch queues behind the other sets and runs alone (tiles).
+  bool overlap = c->k2_variant < 0 && expect_overlap(c, S);
+  if (overlap && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; overlap = false; }
   const int kv = c->k2_variant >= 0 ? c->k2_variant : (overlap ? 0 : 1);
+  c->last_k2 = kv;
   LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, kv, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
                               (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)),
            "bjj_mul_var_base_dev");
@@ -735,10 +971,11 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
     HIPCK(hipEventCreateWithFlags(&S->ev_scan_out, hipEventDisableTiming));
   }
   const int scan_grid = grid_for(c, n, c->occ_scan, 64) * 64 / bjjk::verify_scan_block();   // occ_scan counts waves
-  bool busy = other_launch_in_flight(c, S);
+  bool busy = expect_overlap(c, S);
   if (busy && c->verify_mode < 0 && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; busy = false; }
   // k_verify.hip: persistent waves for ONE large launch that runs alone, one group per workgroup otherwise
   const int mode = c->verify_mode >= 0 ? c->verify_mode : ((!busy && n > BJJ_LARGE_LAUNCH) ? 0 : 1);
+  c->last_verify_mode = mode;
   if (busy) {   // the chip is (about to be) full of another launch's workgroups: priority stream
     HIPCK(hipEventRecord(S->ev_scan_in, st));
     HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));

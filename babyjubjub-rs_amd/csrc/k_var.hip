@@ -118,6 +118,7 @@ __device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, c
   const size_t hi = base + BJJ_K2_BLOCK < n ? base + BJJ_K2_BLOCK : n;
   var_base_body<WIDE>(pts, scalars, sc_words, hi, out, scratch, vb_tables + ((size_t)slot * BJJ_K2_BLOCK + threadIdx.x) * VB_TABLE_WORDS, slow,
                       lds, base + threadIdx.x, (size_t)BJJ_K2_BLOCK);
+  slot_release_wave();   // every wave of the tile wrote tables into the slot: all acknowledged before the barrier, the push behind it
   __syncthreads();
   if (threadIdx.x == 0) slot_push_one(q, cap_nx, slot);
 }

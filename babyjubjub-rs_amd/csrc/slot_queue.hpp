@@ -36,17 +36,26 @@ __device__ __forceinline__ u32 slot_overflow_of_this_xcd(u32 cap_nx) {
   const u32 cap = cap_nx & 0xffffu, nx = cap_nx >> 16;
   return nx * cap + xcc_id() % nx;
 }
-// one thread takes / returns a slot.  Hand-over ordering (ADVICE r03): the holder's stores to its table slot are complete
-// before the slot number is published (fence + the push), and the next holder's accesses start after its pop (fence), so that
-// nothing of the previous holder can land on top of the new holder's table.
-// BJJ_SLOT_FENCE_SCOPE = "workgroup" (s_waitcnt vmcnt(0): the stores are acknowledged by the L2) is what ships: a slot never
-// leaves its XCD, i.e. holder and successor share ONE L2 -- the push / pop atomics and all table traffic meet there, vL1D is
-// write-through, and the successor reads only bytes it has itself written in this tenancy.  "agent" -- what the HIP memory model
-// asks for between workgroups in general -- adds an L2 write-back of every resident workgroup's dirty tables per hand-over and
-// costs verify 1.6 % (profiles/r04_ab_slot_fences.txt); it can be selected with -DBJJ_SLOT_FENCE_SCOPE='"agent"'.
+// one thread takes / returns a slot.  Hand-over ordering (ADVICE r03 / r04): the holder's stores to its table slot are complete
+// -- acknowledged by the XCD's L2 -- before the slot number is published, and the next holder's accesses start after its pop
+// has returned, so that nothing of the previous holder can land on top of the new holder's table.
+// What enforces it is the EXPLICIT `s_waitcnt vmcnt(0)` of slot_release_wave() in front of the push: holder and successor may
+// sit on different CUs of the XCD, and a CU's requests to different L2 channels are not ordered among each other, so the table
+// stores must have been acknowledged before the push atomic is issued.  A workgroup-scope release fence alone does NOT emit
+// that wait on gfx950 (outside tgsplit mode the memory model only orders a workgroup's accesses through its own CU: the ISA of
+// `store; fence(release, "workgroup"); atomic` is store, s_waitcnt lgkmcnt(0), atomic -- ADVICE r04 found round 4 shipping
+// exactly that); tests/test_isa_checks.py asserts the wait in the shipped code objects.  Every WAVE that wrote to the slot
+// calls slot_release_wave() (vmcnt counts per wave); in a multi-wave workgroup a barrier follows before one thread pushes.
+// No cache maintenance is needed on top: a slot never leaves its XCD, i.e. holder and successor share ONE L2 -- the push / pop
+// atomics and all table traffic meet there, vL1D is write-through, and the successor reads only bytes it has itself written
+// in this tenancy.  BJJ_SLOT_FENCE_SCOPE = "workgroup" therefore ships (compiler ordering only); "agent" -- what the HIP memory
+// model asks for between workgroups in general -- adds an L2 write-back of every resident workgroup's dirty tables per
+// hand-over and costs verify 1.6 % (profiles/r04_ab_slot_fences.txt, r05_ab_slot_fences.txt); -DBJJ_SLOT_FENCE_SCOPE='"agent"'.
 #ifndef BJJ_SLOT_FENCE_SCOPE
 #define BJJ_SLOT_FENCE_SCOPE "workgroup"
 #endif
+// all outstanding vector-memory operations of THIS wave (its table stores among them) have been acknowledged
+__device__ __forceinline__ void slot_release_wave() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ u32 slot_pop_one(u32* q, u32 cap_nx) {
   const u32 cap = cap_nx & 0xffffu;
   const u32 t = atomicInc(&q[0], cap - 1u);            // ticket in [0, cap): wraps by itself
@@ -61,6 +70,7 @@ __device__ __forceinline__ u32 slot_pop_one(u32* q, u32 cap_nx) {
 }
 __device__ __forceinline__ void slot_push_one(u32* q, u32 cap_nx, u32 slot) {
   const u32 cap = cap_nx & 0xffffu, nx = cap_nx >> 16;
+  slot_release_wave();                                 // the pushing wave's own stores: acknowledged by the L2
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, BJJ_SLOT_FENCE_SCOPE);
   if (slot >= nx * cap) return;                        // the overflow slot is never queued
   const u32 t = atomicInc(&q[1], cap - 1u);

@@ -78,10 +78,18 @@
  * return, and bjj_free zeroes what is left.  They are NOT constant-time: the
  * fixed-base table is indexed with digits of the secret scalar.
  *
- * Host entry points take host pointers and do H2D / kernel / D2H synchronously.
+ * Host entry points take host pointers and do H2D / kernel / D2H synchronously, as a chunked pipeline (copy in, kernels and
+ * copy out of consecutive chunks overlap).  Arrays in PINNED host memory -- bjj_host_alloc, bjj_host_register, or any range the
+ * HIP runtime knows as pinned (hipHostMalloc, hipHostRegister, torch's pin_memory) -- are copied from / to directly; pageable
+ * arrays are staged through pinned buffers by worker threads of the context (BJJ_STAGE_THREADS, default 4).  The choice is per
+ * array and per call; results are identical.  2^20 fixed-base multiplications: about 1.5 ms pinned (the 64 MB of results
+ * crossing PCIe are the bound), about 2.5 ms pageable, 0.6 ms on device pointers.
  * *_dev entry points take DEVICE pointers (16-byte aligned) plus a hipStream_t
  * (passed as void*; NULL = the context's stream), enqueue the work and return
  * without synchronising -- they are what bench.py times.
+ * More environment knobs (read when the context first runs a host-pointer call): BJJ_PIPE_CHUNK / BJJ_PIPE_FIRST_CHUNK
+ * (items per pipeline chunk: the first chunk, doubling up to the cap; defaults 65536 / 262144), BJJ_HOST_FORCE_STAGED=1
+ * (treat every host array as pageable), BJJ_STAGE_THREADS.
  */
 #ifndef BJJ_HIP_H
 #define BJJ_HIP_H
@@ -127,12 +135,29 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx);
 void bjj_free(bjj_ctx* ctx);
 /* Blocks until everything the context has enqueued -- on its own stream and on the callers' streams -- has finished.
  * Returns BJJ_E_HIP if a verify / variable-base workgroup had to give up waiting for a slot of per-lane table scratch since
- * the last bjj_sync (it cannot happen unless a kernel was aborted while it held slots): the wait is bounded, the launch ends,
- * and this call reports that the results of those launches are not valid instead of the GPU hanging; the slot queues are
- * rebuilt, the context stays usable. */
+ * the last synchronising call (it cannot happen unless a kernel was aborted while it held slots): the wait is bounded, the
+ * launch ends, and this call reports that the results of those launches are not valid instead of the GPU hanging; the slot
+ * queues are rebuilt, the context stays usable.  The host-pointer entry points and the *_multi_dev entry points, which
+ * synchronise for the caller, end with the same check and return BJJ_E_HIP themselves. */
 int bjj_sync(bjj_ctx* ctx);
 /* The context's own stream (hipStream_t as void*). */
 void* bjj_stream(bjj_ctx* ctx);
+
+/* ---- pinned host memory ------------------------------------------------------
+ * The reference's callers hold their data in ordinary Rust values (Point { x, y }: Fr, BigInt scalars; src/lib.rs:134-138,
+ * 149, 239-243, 395): a batch wrapper has to marshal them into the byte records of this boundary anyway, and it should
+ * marshal them straight into memory the GPU's copy engines can read -- then the host-pointer entry points below move every
+ * byte exactly once (PCIe) instead of staging it through a second buffer.
+ *   bjj_host_alloc / bjj_host_free         page-locked memory owned by the library (hipHostMalloc, portable to all devices)
+ *   bjj_host_register / bjj_host_unregister pin a range the caller owns (e.g. a Rust Vec<u8> that lives across calls;
+ *                                           hipHostRegister: costs ~60 us per MB once, pays off from the second call on)
+ *   bjj_host_is_pinned                     1 / 0: would a host-pointer call copy this range directly?
+ * Ranges are process-wide (any context may use them); free / unregister them before the last context is released. */
+int bjj_host_alloc(bjj_ctx* ctx, size_t bytes, void** out_ptr);
+int bjj_host_free(bjj_ctx* ctx, void* ptr);
+int bjj_host_register(bjj_ctx* ctx, void* ptr, size_t bytes);
+int bjj_host_unregister(bjj_ctx* ctx, void* ptr);
+int bjj_host_is_pinned(bjj_ctx* ctx, const void* ptr, size_t bytes);
 
 /* ---- host-pointer batch API ------------------------------------------------ */
 int bjj_mul_fixed_base(bjj_ctx* ctx, const uint8_t* scalars /* n*32 */, size_t n,
@@ -249,6 +274,16 @@ typedef struct {
   const char* kernel_verify;
   double init_ms;           /* wall time of bjj_init (allocation + table build on the GPU) */
   int signer_constant_time; /* bjj_set_signer_constant_time: 1 = the signer entry points scan a small table (see there) */
+  /* since 0.5.0 -- what the context's LAST calls did (-1 = no such call yet); for tests, profiles and the bench line */
+  int last_fixed_base_shape;   /* 0 = one 512-lane workgroup per CU (a launch that runs alone), 1 = two of 256 (overlapping launches) */
+  int last_var_base_form;      /* 1 = tiles (alone), 0 = grid-strided (overlapping) */
+  int last_verify_dispatch;    /* 0 = persistent waves (one launch > 2^21 items that runs alone), 1 = one group per workgroup */
+  uint32_t last_host_direct_arrays;  /* last host-pointer call: arrays copied straight from / to pinned caller memory ... */
+  uint32_t last_host_staged_arrays;  /* ... arrays staged through the context's pinned buffers (pageable caller memory) ... */
+  uint32_t last_host_chunks;         /* ... and the chunks it was cut into */
+  int host_copy_threads;       /* copy workers of the staged path (0 until a pageable array has been seen) */
+  const char* kernel_fixed_base_overlap; /* kernel symbols of the forms overlapping launches get (two streams) */
+  const char* kernel_var_base_overlap;
 } bjj_info;
 int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
 

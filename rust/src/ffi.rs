@@ -30,6 +30,15 @@ pub struct BjjInfo {
     pub kernel_verify: *const c_char,
     pub init_ms: f64,
     pub signer_constant_time: c_int,
+    pub last_fixed_base_shape: c_int,
+    pub last_var_base_form: c_int,
+    pub last_verify_dispatch: c_int,
+    pub last_host_direct_arrays: u32,
+    pub last_host_staged_arrays: u32,
+    pub last_host_chunks: u32,
+    pub host_copy_threads: c_int,
+    pub kernel_fixed_base_overlap: *const c_char,
+    pub kernel_var_base_overlap: *const c_char,
 }
 
 pub const BJJ_OK: c_int = 0;
@@ -52,6 +61,11 @@ extern "C" {
     pub fn bjj_free(ctx: *mut BjjCtx);
     pub fn bjj_sync(ctx: *mut BjjCtx) -> c_int;
     pub fn bjj_stream(ctx: *mut BjjCtx) -> *mut c_void;
+    pub fn bjj_host_alloc(ctx: *mut BjjCtx, bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
+    pub fn bjj_host_free(ctx: *mut BjjCtx, ptr: *mut c_void) -> c_int;
+    pub fn bjj_host_register(ctx: *mut BjjCtx, ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn bjj_host_unregister(ctx: *mut BjjCtx, ptr: *mut c_void) -> c_int;
+    pub fn bjj_host_is_pinned(ctx: *mut BjjCtx, ptr: *const c_void, bytes: usize) -> c_int;
     pub fn bjj_mul_fixed_base(ctx: *mut BjjCtx, scalars: *const u8, n: usize, out_xy: *mut u8) -> c_int;
     pub fn bjj_mul_var_base(ctx: *mut BjjCtx, pts_xy: *const u8, scalars: *const u8, n: usize, out_xy: *mut u8) -> c_int;
     pub fn bjj_mul_var_base_wide(ctx: *mut BjjCtx, pts_xy: *const u8, scalars: *const u8, scalar_bytes: usize, n: usize, out_xy: *mut u8) -> c_int;

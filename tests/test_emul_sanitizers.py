@@ -41,3 +41,21 @@ def test_c_oracle_under_asan_and_ubsan():
     assert r.returncode == 0, tail
     assert "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout, tail
     assert " passed" in r.stdout and os.path.exists(os.path.join(ROOT, "oracle", "libbjj_oracle_san.so"))
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_copy_workers_of_the_host_pipeline_under_tsan_and_asan(san, tmp_path):
+    """babyjubjub-rs_amd/csrc/copy_pool.hpp driven like run_pipelined drives it (groups one chunk ahead, ordered harvest, a
+    recycled 4-deep ring), with 1, 4 and 7 workers: no data race, no out-of-bounds slice, every byte delivered"""
+    exe = str(tmp_path / "emul_copy_pool")
+    src = os.path.join(ROOT, "tests", "emul", "emul_copy_pool.cpp")
+    c = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + san, "-fno-sanitize-recover=all", "-o", exe, src, "-lpthread"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if c.returncode != 0 and "sanitize" in c.stdout:
+        pytest.skip("sanitizer runtime not available: " + c.stdout[-300:])
+    assert c.returncode == 0, c.stdout
+    for workers, nbytes in ((4, (37 << 20) + 12345), (1, 1000), (7, (11 << 20) + 1)):
+        r = subprocess.run([exe, str(workers), str(nbytes)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                           env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"))
+        assert r.returncode == 0 and "copy_pool ok %d" % nbytes in r.stdout, r.stdout[-3000:]
+        assert "ThreadSanitizer" not in r.stdout and "AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout, r.stdout[-3000:]

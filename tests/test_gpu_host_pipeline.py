@@ -1,0 +1,239 @@
+"""The host-pointer boundary (what a caller of Point::mul_scalar / verify holding its data on the host binds to,
+/root/reference src/lib.rs:149, :395): chunked pipeline, pinned arrays copied directly, pageable arrays staged by the
+context's copy workers -- every byte compared with the oracle on both paths, mixed pinned / pageable arrays, ragged sizes
+around the chunk schedule, and the kernel-form heuristic for callers that alternate over streams with and without a
+synchronisation between their launches.  Needs a real MI355X: run with `pytest -m gpu`."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx16():
+    import babyjubjub_rs_amd as bjj
+    c = bjj.Context(0, 16)
+    yield c
+    c.close()
+
+
+def _pinned_copy(ctx, a):
+    p = ctx.host_empty(a.size)
+    p[:] = np.ascontiguousarray(a).reshape(-1)
+    return p
+
+
+# 1 item .. beyond the first three chunks of the schedule (2^16, 2^17, 2^18, 2^18 ...), ragged by one item on both sides
+SIZES = [1, 63, 4096 + 5, (1 << 16) - 1, (1 << 16) + 1, (1 << 16) + (1 << 17) + 1, (1 << 19) + 333]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_fixed_base_pinned_and_pageable_agree_with_the_oracle(ctx16, oracle, n):
+    from babyjubjub_rs_amd import workload as w
+    sc = np.ascontiguousarray(w.scalars_254(n, offset=n)).reshape(-1)
+    # (a) pageable in, pageable out: staged by the copy workers
+    out_a = np.zeros(n * 64, np.uint8)
+    ctx16._ck(ctx16.lib.bjj_mul_fixed_base(ctx16.handle, sc.ctypes.data, n, out_a.ctypes.data), "bjj_mul_fixed_base")
+    ia = ctx16.info()
+    assert (ia.last_host_direct_arrays, ia.last_host_staged_arrays) == (0, 2) and ia.host_copy_threads >= 1
+    # (b) pinned in, pinned out: no staging at all
+    psc, pout = _pinned_copy(ctx16, sc), ctx16.host_empty(n * 64)
+    pout[:] = 0
+    assert ctx16.host_is_pinned(psc) and ctx16.host_is_pinned(pout) and not ctx16.host_is_pinned(out_a)
+    ctx16._ck(ctx16.lib.bjj_mul_fixed_base(ctx16.handle, psc.ctypes.data, n, pout.ctypes.data), "bjj_mul_fixed_base")
+    ib = ctx16.info()
+    assert (ib.last_host_direct_arrays, ib.last_host_staged_arrays) == (2, 0)
+    assert ib.last_host_chunks == ia.last_host_chunks >= 1
+    # (c) mixed: pinned in, pageable out
+    out_c = np.zeros(n * 64, np.uint8)
+    ctx16._ck(ctx16.lib.bjj_mul_fixed_base(ctx16.handle, psc.ctypes.data, n, out_c.ctypes.data), "bjj_mul_fixed_base")
+    ic = ctx16.info()
+    assert (ic.last_host_direct_arrays, ic.last_host_staged_arrays) == (1, 1)
+    assert (out_a == pout).all() and (out_a == out_c).all()
+    idx = np.unique(np.concatenate([np.arange(0, n, max(1, n // 300)), np.arange(max(0, n - 70), n)]))   # every chunk boundary region
+    for edge in (1 << 16, (1 << 16) + (1 << 17), (1 << 16) + (1 << 17) + (1 << 18)):
+        if edge < n:
+            idx = np.unique(np.concatenate([idx, np.arange(edge - 2, min(n, edge + 2))]))
+    assert (out_a.reshape(n, 64)[idx] == oracle.mul_fixed_base(sc.reshape(n, 32)[idx])).all()
+    ctx16.host_free(psc)
+    ctx16.host_free(pout)
+
+
+def test_verify_pinned_registered_and_pageable_every_verdict(ctx16, oracle):
+    """verify through the pipeline: chunk kernels alternate over the context's two compute streams (two scratch sets).
+    Arrays: pk pinned by the library, R registered in place (bjj_host_register), s and msg pageable -> 2 direct + 2 staged
+    inputs; the verdicts land in pinned memory.  Every verdict against the corruption mask, a sample against the oracle."""
+    from babyjubjub_rs_amd import workload as w
+    n = (1 << 18) + (1 << 16) + 123
+    A, R, S, msg = w.make_signatures(ctx16.mul_fixed_base, ctx16.poseidon5, n)
+    bad = w.corrupt(A, R, S, msg, n)
+    pA = _pinned_copy(ctx16, A)
+    Rr = np.ascontiguousarray(R).reshape(-1).copy()
+    ctx16.host_register(Rr)
+    assert ctx16.host_is_pinned(Rr)
+    Sp, Mp = np.ascontiguousarray(S).reshape(-1), np.ascontiguousarray(msg).reshape(-1)
+    ok = ctx16.host_empty(n)
+    ok[:] = 7
+    ctx16._ck(ctx16.lib.bjj_eddsa_verify(ctx16.handle, pA.ctypes.data, Rr.ctypes.data, Sp.ctypes.data, Mp.ctypes.data, n, ok.ctypes.data),
+              "bjj_eddsa_verify")
+    i = ctx16.info()
+    assert (i.last_host_direct_arrays, i.last_host_staged_arrays) == (3, 2)
+    assert (np.asarray(ok) == (~bad).astype(np.uint8)).all()
+    idx = np.arange(0, n, 997)
+    assert (np.asarray(ok)[idx] == oracle.verify(A[idx], R[idx], S[idx], msg[idx])).all()
+    # the same call with everything pageable gives the same bytes
+    ok2 = np.full(n, 7, np.uint8)
+    ctx16._ck(ctx16.lib.bjj_eddsa_verify(ctx16.handle, np.ascontiguousarray(A).ctypes.data, np.ascontiguousarray(R).ctypes.data, Sp.ctypes.data,
+                                         Mp.ctypes.data, n, ok2.ctypes.data), "bjj_eddsa_verify")
+    assert (ok2 == np.asarray(ok)).all()
+    ctx16.host_unregister(Rr)
+    assert not ctx16.host_is_pinned(Rr)
+    ctx16.host_free(pA)
+    ctx16.host_free(ok)
+
+
+def test_memory_pinned_by_somebody_else_is_recognised(ctx16, oracle):
+    """torch's pin_memory (hipHostMalloc behind the library's back): found through the driver's pointer attributes"""
+    import torch
+    from babyjubjub_rs_amd import workload as w
+    n = 70001
+    sc = w.scalars_254(n, offset=3)
+    t_in = torch.from_numpy(np.ascontiguousarray(sc).reshape(-1).copy()).pin_memory()
+    t_out = torch.zeros(n * 64, dtype=torch.uint8).pin_memory()
+    ctx16._ck(ctx16.lib.bjj_mul_fixed_base(ctx16.handle, t_in.data_ptr(), n, t_out.data_ptr()), "bjj_mul_fixed_base")
+    i = ctx16.info()
+    assert (i.last_host_direct_arrays, i.last_host_staged_arrays) == (2, 0)
+    idx = np.arange(0, n, 211)
+    assert (t_out.numpy().reshape(n, 64)[idx] == oracle.mul_fixed_base(sc[idx])).all()
+
+
+def test_host_memory_api_argument_checks(ctx16):
+    from babyjubjub_rs_amd import _lib
+    lib, h = ctx16.lib, ctx16.handle
+    p = ctypes.c_void_p()
+    assert lib.bjj_host_alloc(None, 64, ctypes.byref(p)) == _lib.BJJ_E_INVALID
+    assert lib.bjj_host_alloc(h, 0, ctypes.byref(p)) == _lib.BJJ_E_INVALID
+    assert lib.bjj_host_alloc(h, 64, None) == _lib.BJJ_E_INVALID
+    assert lib.bjj_host_free(h, None) == _lib.BJJ_OK
+    a = np.zeros(4096, np.uint8)
+    assert lib.bjj_host_free(h, a.ctypes.data) == _lib.BJJ_E_INVALID          # not ours
+    assert lib.bjj_host_unregister(h, a.ctypes.data) == _lib.BJJ_E_INVALID    # never registered
+    assert lib.bjj_host_alloc(h, 1 << 20, ctypes.byref(p)) == _lib.BJJ_OK and p.value
+    assert lib.bjj_host_is_pinned(h, p.value, 1 << 20) == 1
+    assert lib.bjj_host_is_pinned(h, p.value + 4096, (1 << 20) - 4096) == 1   # a sub-range
+    assert lib.bjj_host_unregister(h, p.value) == _lib.BJJ_E_INVALID          # allocated, not registered
+    assert lib.bjj_host_free(h, p.value) == _lib.BJJ_OK
+    assert lib.bjj_host_free(h, p.value) == _lib.BJJ_E_INVALID                # twice
+
+
+def test_forced_staging_and_chunk_schedule_from_the_environment(oracle):
+    """BJJ_HOST_FORCE_STAGED / BJJ_PIPE_CHUNK / BJJ_PIPE_FIRST_CHUNK / BJJ_STAGE_THREADS, in a child process (the knobs are
+    read when a context first runs a host-pointer call): pinned arrays are then staged too, 10 000 items in 1 024 / 2 048 /
+    2 048 ... chunks recycle the 4-deep ring, and the bytes do not change."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import babyjubjub_rs_amd as bjj
+from babyjubjub_rs_amd import workload as w
+c = bjj.Context(0, 16)
+n = 10000
+sc = np.ascontiguousarray(w.scalars_254(n, offset=9)).reshape(-1)
+p_in, p_out = c.host_empty(n * 32), c.host_empty(n * 64)
+p_in[:] = sc
+c._ck(c.lib.bjj_mul_fixed_base(c.handle, p_in.ctypes.data, n, p_out.ctypes.data), "fb")
+i = c.info()
+print("INFO", i.last_host_direct_arrays, i.last_host_staged_arrays, i.last_host_chunks, i.host_copy_threads)
+np.save(sys.argv[1], np.asarray(p_out).copy())
+c.close()
+''' % ROOT
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        outp = os.path.join(td, "out.npy")
+        env = dict(os.environ, BJJ_HOST_FORCE_STAGED="1", BJJ_PIPE_CHUNK="2048", BJJ_PIPE_FIRST_CHUNK="1024", BJJ_STAGE_THREADS="2")
+        r = subprocess.run([sys.executable, "-c", code, outp], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout
+        info = [l for l in r.stdout.splitlines() if l.startswith("INFO")][0].split()[1:]
+        assert [int(x) for x in info] == [0, 2, 6, 2], r.stdout      # 1024 + 2048 x 4 + 784 = 10 000: six chunks, two workers
+        got = np.load(outp).reshape(10000, 64)
+    from babyjubjub_rs_amd import workload as w
+    assert (got == oracle.mul_fixed_base(w.scalars_254(10000, offset=9))).all()
+
+
+def test_kernel_form_follows_pattern_and_state(oracle):
+    """expect_overlap (bjj_hip.hip): launches that alternate over two streams WITHOUT a synchronisation between them get the
+    forms for overlapping launches (K1: two 256-lane workgroups per CU, K2: grid-strided); the same alternation WITH a
+    synchronisation after every launch -- nothing ever overlaps -- settles on the forms of a launch that runs alone from the
+    second launch on; one stream never leaves them.  Results are checked in every regime."""
+    import torch
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    dev = torch.device("cuda", 0)
+    ctx = bjj.Context(0, 16)
+    try:
+        n = 1 << 18
+        sc = w.scalars_254(n, offset=77)
+        d_sc = torch.from_numpy(np.ascontiguousarray(sc).reshape(-1)).to(dev)
+        d_pts = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        ctx.mul_fixed_base_dev(d_sc.data_ptr(), n, d_pts.data_ptr(), 0)
+        ctx.sync()
+        outs = [torch.zeros(n * 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+        sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        idx = np.arange(0, n, 1013)
+        want_fb = oracle.mul_fixed_base(sc[idx])
+        want_vb = oracle.mul_var_base(d_pts.cpu().numpy().reshape(n, 64)[idx], sc[idx])
+
+        def fb(st, k):
+            ctx.mul_fixed_base_dev(d_sc.data_ptr(), n, outs[k].data_ptr(), st.cuda_stream)
+            return ctx.info().last_fixed_base_shape
+
+        def vb(st, k):
+            ctx.mul_var_base_dev(d_pts.data_ptr(), d_sc.data_ptr(), n, outs[k].data_ptr(), st.cuda_stream)
+            return ctx.info().last_var_base_form
+
+        # one stream: the form of a launch that runs alone (the very first launch on `sa` follows a call on the context's own
+        # stream -- the set-up above -- which looks like the start of a ping-pong for exactly one launch)
+        assert [fb(sa, 0) for _ in range(5)][1:] == [0, 0, 0, 0]
+        ctx.sync()
+        assert (outs[0].cpu().numpy().reshape(n, 64)[idx] == want_fb).all()
+        assert [vb(sa, 0) for _ in range(3)] == [1, 1, 1]
+        ctx.sync()
+        assert (outs[0].cpu().numpy().reshape(n, 64)[idx] == want_vb).all()
+        # ping-pong without synchronisation: from the second launch on the other set is busy, the pattern holds the shape
+        shapes = [fb((sa, sb)[k & 1], k & 1) for k in range(8)]
+        ctx.sync()
+        assert shapes[1:] == [1] * 7, shapes
+        # the first launch behind a synchronisation point of a caller that ping-pongs keeps the overlap shape (the pattern says
+        # the next launch follows at once) ...
+        assert fb(sa, 0) == 1
+        assert fb(sb, 1) == 1
+        ctx.sync()
+        for o in outs:
+            assert (o.cpu().numpy().reshape(n, 64)[idx] == want_fb).all()
+        # ... but ping-pong WITH a synchronisation after every launch: the second call in a row that finds the other set idle
+        # switches to the alone shape and stays there
+        shapes = []
+        for k in range(6):
+            shapes.append(fb((sa, sb)[k & 1], k & 1))
+            ctx.sync()
+        assert shapes[0] == 1 and shapes[1:] == [0] * 5, shapes
+        for o in outs:
+            assert (o.cpu().numpy().reshape(n, 64)[idx] == want_fb).all()
+        forms = []
+        for k in range(5):
+            forms.append(vb((sa, sb)[k & 1], k & 1))
+            ctx.sync()
+        assert forms[1:] == [1] * 4, forms
+        for o in outs:
+            assert (o.cpu().numpy().reshape(n, 64)[idx] == want_vb).all()
+        # and back: without the synchronisation the overlap forms return
+        forms = [vb((sa, sb)[k & 1], k & 1) for k in range(6)]
+        ctx.sync()
+        assert forms[1:] == [0] * 5, forms
+    finally:
+        ctx.close()
