@@ -152,17 +152,19 @@ struct bjj_ctx {
   // calls that use no scratch (Poseidon, point add, codec, sign) are not ordered behind anything; their completion
   // events are only kept so that bjj_sync can wait for them: one slot per distinct caller stream
   StreamMark marks[BJJ_STREAM_MARKS];
-  // host-pointer API (run_pipelined): chunked pipeline over a ring of BJJ_PIPE_BUFS device staging buffers
-  //   caller's array -[H2D, s_in]-> dstage[b] -[kernels, stream / stream2 alternating]-> dstage[b] -[D2H, s_out]-> caller's array
+  // host-pointer API (run_pipelined): chunked pipeline
+  //   caller's array -[H2D, s_in]-> dstage -[kernels on the lanes stream / stream2, chunks alternating]-> dstage -[D2H, s_out]-> caller's array
   // straight from / to the caller's memory when that is pinned (bjj_host_alloc / bjj_host_register / any hipHostMalloc'd or
-  // hipHostRegister'ed range); a PAGEABLE array goes through pinned[b], moved by the context's copy workers (CopyPool), never by
-  // the enqueueing thread
+  // hipHostRegister'ed range); a PAGEABLE array goes through the rings pin_in[] / pin_out[], moved by the context's copy workers
+  // (CopyPool), never by the enqueueing thread
   hipStream_t s_in = nullptr, s_out = nullptr, stream2 = nullptr;
-  hipEvent_t ev_in[BJJ_PIPE_BUFS] = {}, ev_k[BJJ_PIPE_BUFS] = {}, ev_out[BJJ_PIPE_BUFS] = {};
-  uint8_t* pinned[BJJ_PIPE_BUFS] = {};
-  uint8_t* dstage[BJJ_PIPE_BUFS] = {};
-  size_t pipe_bytes = 0;       // bytes of each dstage[b]
-  size_t pinned_bytes = 0;     // bytes of each pinned[b] (allocated on the first call that has a pageable array)
+  std::vector<hipEvent_t> ev_in, ev_k, ev_out;   // per chunk of a super-batch (grown on demand)
+  uint8_t* dstage = nullptr;   // device staging for one super-batch: every array contiguous
+  size_t pipe_bytes = 0;
+  uint8_t* pin_in[BJJ_PIPE_BUFS] = {};     // pinned rings of the staged path (allocated on the first call that has a pageable array)
+  uint8_t* pin_out[BJJ_PIPE_BUFS] = {};
+  size_t pin_in_bytes = 0, pin_out_bytes = 0;
+  size_t pipe_budget = 0;                  // bytes of device staging a call may take (BJJ_PIPE_STAGING_MB)
   CopyPool* pool = nullptr;
   size_t pipe_chunk = 0, pipe_first = 0;   // chunk schedule (items): first chunk, doubling up to pipe_chunk
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
@@ -170,7 +172,10 @@ struct bjj_ctx {
   int last_k1 = -1, last_k2 = -1, last_verify_mode = -1;
   int idle_alternations = 0;               // expect_overlap: consecutive alternating calls that found the other set idle
   u32 last_host_direct = 0, last_host_staged = 0, last_host_chunks = 0;
-  u32* err_words = nullptr;                // pinned: the slot queues' give-up counters as read back by ctx_check_slot_queues
+  u32* slot_block = nullptr;               // all slot-queue rings of the context in one device allocation (slot_block_make)
+  size_t slot_block_words = 0;
+  u32* err_words = nullptr;                // pinned: the ring block as read back by ctx_check_slot_queues
+  bool rings_used = false;                 // a kernel that pops / pushes slots has been launched since the last check
 };
 
 static int grid_for(const bjj_ctx* c, size_t n, int blocks_per_cu, int block = BJJ_BLOCK) {
@@ -286,43 +291,53 @@ static int slot_queue_fill(bjj_ctx* c, u32* d_q, u32 cap) {
   HIPCK(hipStreamSynchronize(c->stream));
   return BJJ_OK;
 }
-static int slot_queue_make(bjj_ctx* c, u32** d_q, u32* have_cap, u32 cap) {
-  if (*d_q && *have_cap == cap) return BJJ_OK;
-  if (*d_q) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(*d_q)); *d_q = nullptr; *have_cap = 0; }
-  HIPCK(hipMalloc((void**)d_q, (size_t)c->xccs * (BJJ_SLOTQ_HDR + cap) * sizeof(u32)));
-  int rc = slot_queue_fill(c, *d_q, cap);
-  if (rc) { (void)hipFree(*d_q); *d_q = nullptr; return rc; }
-  *have_cap = cap;
+// All rings of a context -- two per scratch set: verify's (cap slots per XCD) and the variable-base tiles' (cap2) -- live in ONE
+// device block, so that the check below reads them back with a single copy.  The capacities are constants of the context
+// (occupancy x CUs per XCD): the block is made once, when the first scratch set is sized.
+static size_t slot_ring_words(const bjj_ctx* c, u32 cap) { return (size_t)c->xccs * (BJJ_SLOTQ_HDR + cap); }
+static int slot_block_make(bjj_ctx* c, u32 cap, u32 cap2) {
+  if (c->slot_block) return BJJ_OK;
+  const size_t per_set = slot_ring_words(c, cap) + slot_ring_words(c, cap2);
+  u32* blk = nullptr;
+  HIPCK(hipMalloc((void**)&blk, BJJ_SCRATCH_SETS * per_set * sizeof(u32)));
+  u32* host = nullptr;
+  if (hipHostMalloc((void**)&host, BJJ_SCRATCH_SETS * per_set * sizeof(u32), hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(blk);
+    return set_err(BJJ_E_NOMEM, "slot queues: no pinned memory for the read-back buffer");
+  }
+  for (int k = 0; k < BJJ_SCRATCH_SETS; k++) {
+    ScratchSet& S = c->set[k];
+    S.slotq = blk + (size_t)k * per_set;           S.slot_cap = cap;
+    S.slotq2 = S.slotq + slot_ring_words(c, cap);  S.slot_cap2 = cap2;
+    int rc = slot_queue_fill(c, S.slotq, cap);
+    if (!rc) rc = slot_queue_fill(c, S.slotq2, cap2);
+    if (rc) { for (ScratchSet& T : c->set) { T.slotq = T.slotq2 = nullptr; T.slot_cap = T.slot_cap2 = 0; } (void)hipFree(blk); (void)hipHostFree(host); return rc; }
+  }
+  c->slot_block = blk; c->slot_block_words = BJJ_SCRATCH_SETS * per_set; c->err_words = host;
   return BJJ_OK;
 }
-// After the launches in question have completed: did a pop ever give up waiting for a slot?  Only the give-up counters travel
-// (one word per XCD and ring: a strided asynchronous copy on the context's own non-blocking stream into pinned memory -- not
-// the whole rings through the legacy null stream, which also made the caller wait for other tenants' blocking streams, ADVICE
-// r04); a ring is read in full and rebuilt only when its counter is non-zero.  Every entry point that synchronises for the
-// caller ends with this check (bjj_sync, the host-pointer pipeline, the multi-GPU pipeline): a launch that worked on the
-// overflow slot must never be reported as BJJ_OK.
-#define BJJ_ERR_WORDS 16   // per ring (>= XCDs)
+// After the launches in question have completed: did a pop ever give up waiting for a slot?  ONE asynchronous copy of the ring
+// block (35 KB) on the context's own non-blocking stream into pinned memory -- not four synchronous pageable copies through
+// the legacy null stream, which also made the caller wait for other tenants' blocking streams -- and only when a
+// kernel that uses the rings has been launched since the last check (rings_used: 2^20 fixed-base multiplications on host
+// pointers take 1.5 ms, a check that costs 0.17 ms has no business there).  A ring is rebuilt only when its counter is
+// non-zero.  Every entry point that synchronises for the caller ends with this check (bjj_sync, the host-pointer pipeline, the
+// multi-GPU pipeline): a launch that worked on the overflow slot must never be reported as BJJ_OK.
 static int ctx_check_slot_queues(bjj_ctx* c, const char* who) {
-  struct Ring { u32* q; u32 cap; };
-  Ring rings[2 * BJJ_SCRATCH_SETS];
-  int nr = 0;
-  for (ScratchSet& S : c->set) {
-    if (S.slotq) rings[nr++] = {S.slotq, S.slot_cap};
-    if (S.slotq2) rings[nr++] = {S.slotq2, S.slot_cap2};
-  }
-  if (!nr) return BJJ_OK;
-  if (!c->err_words) HIPCK(hipHostMalloc((void**)&c->err_words, sizeof(u32) * BJJ_ERR_WORDS * 2 * BJJ_SCRATCH_SETS, hipHostMallocDefault));
-  const int nx = c->xccs < BJJ_ERR_WORDS ? c->xccs : BJJ_ERR_WORDS;
-  for (int r = 0; r < nr; r++)
-    HIPCK(hipMemcpy2DAsync(c->err_words + r * BJJ_ERR_WORDS, sizeof(u32), rings[r].q + BJJ_SLOTQ_ERR, (BJJ_SLOTQ_HDR + (size_t)rings[r].cap) * sizeof(u32),
-                           sizeof(u32), (size_t)nx, hipMemcpyDeviceToHost, c->stream));
+  if (!c->slot_block || !c->rings_used) return BJJ_OK;
+  HIPCK(hipMemcpyAsync(c->err_words, c->slot_block, c->slot_block_words * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIPCK(hipStreamSynchronize(c->stream));
+  c->rings_used = false;
   unsigned long long starved = 0;
-  for (int r = 0; r < nr; r++) {
-    unsigned long long bad = 0;
-    for (int x = 0; x < nx; x++) bad += c->err_words[r * BJJ_ERR_WORDS + x];
-    if (bad) { int rc = slot_queue_fill(c, rings[r].q, rings[r].cap); if (rc) return rc; }
-    starved += bad;
+  for (ScratchSet& S : c->set) {
+    struct Ring { u32* q; u32 cap; } rings[2] = {{S.slotq, S.slot_cap}, {S.slotq2, S.slot_cap2}};
+    for (const Ring& r : rings) {
+      const u32* h = c->err_words + (r.q - c->slot_block);
+      unsigned long long bad = 0;
+      for (int x = 0; x < c->xccs; x++) bad += h[(size_t)x * (BJJ_SLOTQ_HDR + r.cap) + BJJ_SLOTQ_ERR];
+      if (bad) { int rc = slot_queue_fill(c, r.q, r.cap); if (rc) return rc; }
+      starved += bad;
+    }
   }
   if (starved)
     return set_err(BJJ_E_HIP, std::string(who) + ": " + std::to_string(starved) + " workgroup(s) gave up waiting for a per-lane table slot; the results of "
@@ -352,8 +367,7 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
   const size_t te = (size_t)c->xccs * ((size_t)cap + 1) * 64 * 2;
   size_t threads = tv > te ? tv : te;
   if (tv_strided > threads) threads = tv_strided;
-  { int rc = slot_queue_make(c, &S->slotq2, &S->slot_cap2, cap2); if (rc) return rc; }
-  { int rc = slot_queue_make(c, &S->slotq, &S->slot_cap, cap); if (rc) return rc; }
+  { int rc = slot_block_make(c, cap, cap2); if (rc) return rc; }
   if (threads > S->vb_threads) {
     if (S->vb_tables) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->vb_tables)); S->vb_tables = nullptr; S->vb_threads = 0; }
     HIPCK(hipMalloc((void**)&S->vb_tables, threads * VB_TABLE_WORDS_MAX * sizeof(u32)));
@@ -364,23 +378,33 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
 // ---------------------------------------------------------------------------
 // Host-pointer API plumbing.
 //
-// A call is cut into chunks that flow through a ring of BJJ_PIPE_BUFS device staging buffers:
-//     H2D of chunk c+1 (s_in)  |  kernels of chunk c (stream / stream2, alternating)  |  D2H of chunk c-1 (s_out)
+// A call is cut into chunks; chunk k flows
+//     H2D (copy stream s_in)  ->  kernels on lane k % 2 (stream / stream2)  ->  D2H (copy stream s_out)
+// through device staging that holds the WHOLE batch (every array contiguous, up to BJJ_PIPE_STAGING_MB = 1 GB per call; a
+// larger batch runs as consecutive super-batches), so nothing on the device is ever reused inside a call.
 // * Pinned caller memory (bjj_host_alloc, bjj_host_register, or anything the HIP runtime reports as pinned host memory) is
 //   copied from / to DIRECTLY: no staging copy at all, the bound is the slower PCIe direction (2^20 fixed-base
 //   multiplications: 64 MB of results, 1.19 ms).  Round 4 staged everything through two pinned buffers with a memcpy on the
 //   calling thread and ran at 17 % of the device rate.
-// * A pageable array goes through the ring's pinned twin pinned[b]; the memcpy between it and the caller's memory is done by
-//   the context's copy workers (CopyPool) while the calling thread only enqueues.  (A pageable hipMemcpy runs at ~3 GB/s.)
-// * The chunk kernels alternate over the context's two compute streams, i.e. its two scratch sets: consecutive chunks overlap
-//   on the chip like the two-stream launches of the device-pointer API (verify in 2^18-item chunks on ONE stream ran 6.76 ms
-//   per chunk, on two 4.47 ms: profiles/r04_throughput_vs_batch.txt).
-// * The first chunk is small (2^16 items) and the size doubles up to 2^18: the head of the pipeline -- copy in + compute of
-//   chunk 0, during which the other engines idle -- is short, and the D2H engine never waits for a kernel afterwards.
-//   BJJ_PIPE_FIRST_CHUNK / BJJ_PIPE_CHUNK (items) override the schedule.
+// * A pageable array goes through a ring of pinned buffers; the memcpy between ring and caller memory is done by the
+//   context's copy workers (CopyPool) while the calling thread only enqueues.  (A pageable hipMemcpy runs at ~3 GB/s.)
+// * Two lanes = the context's two scratch sets: the kernels of consecutive chunks overlap on the chip like the two-stream
+//   launches of the device-pointer API (verify in 2^18-item chunks on ONE stream ran 6.76 ms per chunk, on two 4.47 ms:
+//   profiles/r04_throughput_vs_batch.txt).  The lanes carry kernels only.
+// * The copy streams live in the HIGH-priority queue pool.  On this runtime an event record or a cross-stream wait behind an
+//   SDMA copy becomes a barrier packet in the stream's HARDWARE queue; HIP maps the streams of one priority onto four hardware
+//   queues, and a kernel of another stream that lands behind such a packet waits for that copy.  The first form of this
+//   pipeline (normal-priority copy streams, one event per chunk and direction) ran every kernel behind the previous chunk's
+//   D2H: 2.7 ms for 2^20 fixed-base multiplications; the second (D2H in stream order behind the kernels: no events, but the
+//   runtime then copies with a shader blit at half the SDMA rate) 1.65 ms; this one 1.4 (profiles/r05_host_pipeline.txt).
+//   High-priority streams have their own queue pool (where the verify scan streams live as well), so no kernel of a lane --
+//   or of the caller's own streams -- can ever sit behind one of the pipeline's copy barriers.
+// * The first chunk is small (2^15 items: the copy-out engine, which bounds a copy-bound call, starts 0.1 ms after the call)
+//   and the size doubles up to 2^18; a remainder below half a chunk is merged into the
+//   last chunk (a small last launch leaves the chip half empty).  BJJ_PIPE_FIRST_CHUNK / BJJ_PIPE_CHUNK (items) override.
 // ---------------------------------------------------------------------------
 #define BJJ_PIPE_CHUNK ((size_t)1 << 18)
-#define BJJ_PIPE_FIRST_CHUNK ((size_t)1 << 16)
+#define BJJ_PIPE_FIRST_CHUNK ((size_t)1 << 15)
 struct PipeSpec {
   int n_in, n_out;
   const uint8_t* in[4]; size_t in_stride[4];
@@ -388,6 +412,7 @@ struct PipeSpec {
   bool secret;          // inputs are key material: wipe the staging buffers when the call is done
 };
 static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 static void secure_bzero(void* p, size_t n) {
   memset(p, 0, n);
   __asm__ __volatile__("" : : "r"(p) : "memory");   // the stores must not be elided as dead
@@ -432,41 +457,58 @@ static size_t env_items(const char* name, size_t dflt) {
   const unsigned long long v = strtoull(e, nullptr, 0);
   return v >= 64 && v <= ((size_t)1 << 24) ? ((size_t)v + 63) & ~(size_t)63 : dflt;
 }
-// streams / events of the pipeline, the device staging ring (dev_bytes each) and -- only when a pageable array takes part --
-// its pinned twin and the copy workers
-static int ensure_pipe(bjj_ctx* c, size_t dev_bytes, size_t pinned_bytes) {
+// streams of the pipeline, events for `chunks` chunks, dev_bytes of device staging and -- only when a pageable array takes
+// part -- the pinned rings (in_ring / out_ring bytes per slot) and the copy workers
+static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ring, size_t out_ring) {
   ENTER_DEVICE(c->device);
   if (!c->s_in) {
-    HIPCK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
-    HIPCK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-    HIPCK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
-      HIPCK(hipEventCreateWithFlags(&c->ev_in[b], hipEventDisableTiming));
-      HIPCK(hipEventCreateWithFlags(&c->ev_k[b], hipEventDisableTiming));
-      HIPCK(hipEventCreateWithFlags(&c->ev_out[b], hipEventDisableTiming));
+    int least = 0, greatest = 0;
+    HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int prio_in = greatest, prio_out = greatest;
+    if (const char* e = getenv("BJJ_PIPE_COPY_PRIORITY")) {   // developer: "nn" / "hn" / "nh" / "hh" = normal / high for s_in, s_out
+      if (e[0] == 'n') prio_in = 0;
+      if (e[0] && e[1] == 'n') prio_out = 0;
     }
+    HIPCK(hipStreamCreateWithPriority(&c->s_in, hipStreamNonBlocking, prio_in));
+    HIPCK(hipStreamCreateWithPriority(&c->s_out, hipStreamNonBlocking, prio_out));
+    HIPCK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     c->pipe_chunk = env_items("BJJ_PIPE_CHUNK", BJJ_PIPE_CHUNK);
     c->pipe_first = env_items("BJJ_PIPE_FIRST_CHUNK", BJJ_PIPE_FIRST_CHUNK);
     if (c->pipe_first > c->pipe_chunk) c->pipe_first = c->pipe_chunk;
+    c->pipe_budget = (size_t)1 << 30;
+    if (const char* e = getenv("BJJ_PIPE_STAGING_MB")) { const long v = atol(e); if (v >= 1 && v <= 65536) c->pipe_budget = (size_t)v << 20; }
     if (const char* e = getenv("BJJ_HOST_FORCE_STAGED")) c->force_staged = e[0] == '1';
   }
+  try {
+    while (c->ev_in.size() < chunks) {
+      hipEvent_t e = nullptr;
+      HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_in.push_back(e);
+      e = nullptr;
+      HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_k.push_back(e);
+      e = nullptr;
+      HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_out.push_back(e);
+    }
+  } catch (...) { return set_err(BJJ_E_NOMEM, "host-pointer pipeline: out of host memory"); }
   if (dev_bytes > c->pipe_bytes) {
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipStreamSynchronize(c->stream2));
-    for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
-      if (c->dstage[b]) { HIPCK(hipFree(c->dstage[b])); c->dstage[b] = nullptr; }
-      HIPCK(hipMalloc((void**)&c->dstage[b], dev_bytes));
-    }
+    if (c->dstage) { HIPCK(hipFree(c->dstage)); c->dstage = nullptr; c->pipe_bytes = 0; }
+    HIPCK(hipMalloc((void**)&c->dstage, dev_bytes));
     c->pipe_bytes = dev_bytes;
   }
-  if (pinned_bytes > c->pinned_bytes) {
+  auto grow_ring = [&](uint8_t** ring, size_t* have, size_t want) -> int {
+    if (want <= *have) return BJJ_OK;
     for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
-      if (c->pinned[b]) { secure_bzero(c->pinned[b], c->pinned_bytes); HIPCK(hipHostFree(c->pinned[b])); c->pinned[b] = nullptr; }
-      HIPCK(hipHostMalloc((void**)&c->pinned[b], pinned_bytes, hipHostMallocDefault));
+      if (ring[b]) { secure_bzero(ring[b], *have); HIPCK(hipHostFree(ring[b])); ring[b] = nullptr; }
     }
-    c->pinned_bytes = pinned_bytes;
-  }
-  if (pinned_bytes && !c->pool) {
+    *have = 0;
+    for (int b = 0; b < BJJ_PIPE_BUFS; b++) HIPCK(hipHostMalloc((void**)&ring[b], want, hipHostMallocDefault));
+    *have = want;
+    return BJJ_OK;
+  };
+  { int rc = grow_ring(c->pin_in, &c->pin_in_bytes, in_ring); if (rc) return rc; }
+  { int rc = grow_ring(c->pin_out, &c->pin_out_bytes, out_ring); if (rc) return rc; }
+  if ((in_ring || out_ring) && !c->pool) {
     int want = 4;
     if (const char* e = getenv("BJJ_STAGE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 32) want = v; }
     const unsigned hw = std::thread::hardware_concurrency();
@@ -476,116 +518,163 @@ static int ensure_pipe(bjj_ctx* c, size_t dev_bytes, size_t pinned_bytes) {
   }
   return BJJ_OK;
 }
-// launch(d_in[], d_out[], count, stream) enqueues the kernels of one chunk on `stream`
+// One super-batch of at most `cap` items (everything fits in the device staging).  launch(d_in[], d_out[], count, stream)
+// enqueues the kernels of one chunk on `stream`.
 template <typename Launch>
-static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch) {
-  ENTER_DEVICE(c->device);
-  { int rc = ensure_pipe(c, 0, 0); if (rc) return rc; }   // streams, events, the chunk schedule
-  // ---- chunk schedule: first, 2 first, 4 first ... capped at pipe_chunk
+static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool* in_direct, const bool* out_direct, u32 n_staged, Launch& launch,
+                           u32* chunks_out) {
+  // ---- chunk schedule: first, 2 first, 4 first ... capped at pipe_chunk; a remainder below half a chunk joins the last chunk
   std::vector<size_t> lo_of;     // lo_of[ch] .. lo_of[ch + 1]
   {
     size_t lo = 0, sz = c->pipe_first;
-    while (lo < n) { lo_of.push_back(lo); lo += sz < n - lo ? sz : n - lo; if (sz < c->pipe_chunk) sz = sz * 2 < c->pipe_chunk ? sz * 2 : c->pipe_chunk; }
+    while (lo < n) {
+      size_t take = sz < n - lo ? sz : n - lo;
+      if (n - lo - take < sz / 2) take = n - lo;          // what would be left is small: take it along
+      lo_of.push_back(lo);
+      lo += take;
+      if (sz < c->pipe_chunk) sz = sz * 2 < c->pipe_chunk ? sz * 2 : c->pipe_chunk;
+    }
     lo_of.push_back(n);
   }
   const size_t nchunks = lo_of.size() - 1;
-  const size_t chunk = n < c->pipe_chunk ? n : c->pipe_chunk;   // the largest chunk: sizes the ring
-  // ---- which arrays are pinned (copied directly) and which go through the pinned twin
-  bool in_direct[4], out_direct[4];
-  u32 n_direct = 0, n_staged = 0;
-  for (int i = 0; i < sp.n_in; i++) { in_direct[i] = !c->force_staged && host_range_pinned(sp.in[i], n * sp.in_stride[i]); (in_direct[i] ? n_direct : n_staged)++; }
-  for (int i = 0; i < sp.n_out; i++) { out_direct[i] = !c->force_staged && host_range_pinned(sp.out[i], n * sp.out_stride[i]); (out_direct[i] ? n_direct : n_staged)++; }
-  size_t off_in[4], off_out[4], tot = 0;
-  for (int i = 0; i < sp.n_in; i++) { off_in[i] = tot; tot += up16(chunk * sp.in_stride[i]); }
-  for (int i = 0; i < sp.n_out; i++) { off_out[i] = tot; tot += up16(chunk * sp.out_stride[i]); }
-  { int rc = ensure_pipe(c, tot, n_staged ? tot : 0); if (rc) return rc; }
-  c->last_host_direct = n_direct; c->last_host_staged = n_staged; c->last_host_chunks = (u32)nchunks;
+  size_t max_chunk = 0;
+  for (size_t ch = 0; ch < nchunks; ch++) if (lo_of[ch + 1] - lo_of[ch] > max_chunk) max_chunk = lo_of[ch + 1] - lo_of[ch];
+  // device staging: array i of the whole super-batch at d_off[i]; pinned ring slots: the staged arrays of ONE chunk
+  size_t d_in_off[4], d_out_off[4], r_in_off[4], r_out_off[4], dev_tot = 0, in_ring = 0, out_ring = 0;
+  for (int i = 0; i < sp.n_in; i++) { d_in_off[i] = dev_tot; dev_tot += up256(n * sp.in_stride[i]); }
+  for (int i = 0; i < sp.n_out; i++) { d_out_off[i] = dev_tot; dev_tot += up256(n * sp.out_stride[i]); }
+  for (int i = 0; i < sp.n_in; i++) if (!in_direct[i]) { r_in_off[i] = in_ring; in_ring += up16(max_chunk * sp.in_stride[i]); }
+  for (int i = 0; i < sp.n_out; i++) if (!out_direct[i]) { r_out_off[i] = out_ring; out_ring += up16(max_chunk * sp.out_stride[i]); }
+  { int rc = ensure_pipe(c, nchunks, dev_tot, in_ring, out_ring); if (rc) return rc; }
+  *chunks_out += (u32)nchunks;
   CopyPool* pool = c->pool;
   std::vector<CopyGroup> g_in(nchunks), g_out(nchunks);
   auto cnt_of = [&](size_t ch) { return lo_of[ch + 1] - lo_of[ch]; };
-  // pageable inputs of chunk ch -> pinned[b] (workers)
-  auto submit_in = [&](size_t ch) {
-    const int b = (int)(ch % BJJ_PIPE_BUFS);
-    for (int i = 0; i < sp.n_in; i++)
-      if (!in_direct[i]) pool->submit(c->pinned[b] + off_in[i], sp.in[i] + lo_of[ch] * sp.in_stride[i], cnt_of(ch) * sp.in_stride[i], &g_in[ch]);
+  // BJJ_PIPE_TRACE=1 (developer): host-side timestamps of every enqueue step on stderr -- tells a host thread that blocks inside
+  // an "asynchronous" runtime call from a device-side dependency, which a kernel / copy trace cannot
+  static const bool trace = [] { const char* e = getenv("BJJ_PIPE_TRACE"); return e && e[0] == '1'; }();
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto tr = [&](const char* what, size_t ch) {
+    if (trace) fprintf(stderr, "[pipe] %8.1f us  chunk %zu  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(), ch, what);
   };
-  // chunk ch has left the device: pageable outputs pinned[b] -> caller (workers)
+  // pageable inputs of chunk ch -> pin_in[ch % BUFS] (workers); the slot is free once the H2D of chunk ch - BUFS has run
+  auto submit_in = [&](size_t ch) -> int {
+    const int b = (int)(ch % BJJ_PIPE_BUFS);
+    if (!in_ring) return BJJ_OK;
+    if (ch >= BJJ_PIPE_BUFS) HIPCK(hipEventSynchronize(c->ev_in[ch - BJJ_PIPE_BUFS]));
+    for (int i = 0; i < sp.n_in; i++)
+      if (!in_direct[i]) pool->submit(c->pin_in[b] + r_in_off[i], sp.in[i] + lo_of[ch] * sp.in_stride[i], cnt_of(ch) * sp.in_stride[i], &g_in[ch]);
+    return BJJ_OK;
+  };
+  // chunk ch has left the device: pageable outputs pin_out[ch % BUFS] -> caller (workers)
   size_t harvested = 0;           // chunks whose copy-out has been submitted (in order)
   auto harvest = [&](size_t ch, bool block) -> int {
     const int b = (int)(ch % BJJ_PIPE_BUFS);
-    if (block) HIPCK(hipEventSynchronize(c->ev_out[b]));
+    if (block) HIPCK(hipEventSynchronize(c->ev_out[ch]));
     else {
-      const hipError_t q = hipEventQuery(c->ev_out[b]);
+      const hipError_t q = hipEventQuery(c->ev_out[ch]);
       (void)hipGetLastError();
       if (q != hipSuccess) return 1;   // not yet
     }
     for (int i = 0; i < sp.n_out; i++)
-      if (!out_direct[i]) pool->submit(sp.out[i] + lo_of[ch] * sp.out_stride[i], c->pinned[b] + off_out[i], cnt_of(ch) * sp.out_stride[i], &g_out[ch]);
+      if (!out_direct[i]) pool->submit(sp.out[i] + lo_of[ch] * sp.out_stride[i], c->pin_out[b] + r_out_off[i], cnt_of(ch) * sp.out_stride[i], &g_out[ch]);
     return BJJ_OK;
   };
-  // chunk ch is completely done (its results are in the caller's memory): its ring slot is free
-  auto finish = [&](size_t ch) -> int {
+  // the pageable results of chunk ch are in the caller's memory: its pin_out slot is free
+  auto finish_out = [&](size_t ch) -> int {
     while (harvested <= ch) { int r = harvest(harvested, true); if (r) return r; harvested++; }
-    if (pool) pool->wait(&g_out[ch]);
+    pool->wait(&g_out[ch]);
     return BJJ_OK;
   };
   auto enqueue = [&](size_t ch) -> int {
     const int b = (int)(ch % BJJ_PIPE_BUFS);
     const size_t lo = lo_of[ch], cnt = cnt_of(ch);
+    tr("enqueue begin", ch);
     for (int i = 0; i < sp.n_in; i++)
-      HIPCK(hipMemcpyAsync(c->dstage[b] + off_in[i], in_direct[i] ? sp.in[i] + lo * sp.in_stride[i] : c->pinned[b] + off_in[i], cnt * sp.in_stride[i],
-                           hipMemcpyHostToDevice, c->s_in));
-    HIPCK(hipEventRecord(c->ev_in[b], c->s_in));
-    hipStream_t ks = (ch & 1) ? c->stream2 : c->stream;
-    HIPCK(hipStreamWaitEvent(ks, c->ev_in[b], 0));
+      HIPCK(hipMemcpyAsync(c->dstage + d_in_off[i] + lo * sp.in_stride[i], in_direct[i] ? sp.in[i] + lo * sp.in_stride[i] : c->pin_in[b] + r_in_off[i],
+                           cnt * sp.in_stride[i], hipMemcpyHostToDevice, c->s_in));
+    HIPCK(hipEventRecord(c->ev_in[ch], c->s_in));
+    hipStream_t lane = (ch & 1) ? c->stream2 : c->stream;
+    HIPCK(hipStreamWaitEvent(lane, c->ev_in[ch], 0));
     void* d_in[4]; void* d_out[4];
-    for (int i = 0; i < sp.n_in; i++) d_in[i] = c->dstage[b] + off_in[i];
-    for (int i = 0; i < sp.n_out; i++) d_out[i] = c->dstage[b] + off_out[i];
-    int r = launch(d_in, d_out, cnt, (void*)ks); if (r) return r;
-    HIPCK(hipEventRecord(c->ev_k[b], ks));
-    HIPCK(hipStreamWaitEvent(c->s_out, c->ev_k[b], 0));
+    for (int i = 0; i < sp.n_in; i++) d_in[i] = c->dstage + d_in_off[i] + lo * sp.in_stride[i];
+    for (int i = 0; i < sp.n_out; i++) d_out[i] = c->dstage + d_out_off[i] + lo * sp.out_stride[i];
+    int r = launch(d_in, d_out, cnt, (void*)lane); if (r) return r;
+    HIPCK(hipEventRecord(c->ev_k[ch], lane));                  // behind a kernel: its completion signal, no extra packet
+    tr("kernels enqueued", ch);
+    if (out_ring && ch >= BJJ_PIPE_BUFS) { r = finish_out(ch - BJJ_PIPE_BUFS); if (r) return r; }   // frees pin_out[b]
+    HIPCK(hipStreamWaitEvent(c->s_out, c->ev_k[ch], 0));
     for (int i = 0; i < sp.n_out; i++)
-      HIPCK(hipMemcpyAsync(out_direct[i] ? sp.out[i] + lo * sp.out_stride[i] : c->pinned[b] + off_out[i], c->dstage[b] + off_out[i], cnt * sp.out_stride[i],
-                           hipMemcpyDeviceToHost, c->s_out));
-    HIPCK(hipEventRecord(c->ev_out[b], c->s_out));
+      HIPCK(hipMemcpyAsync(out_direct[i] ? sp.out[i] + lo * sp.out_stride[i] : c->pin_out[b] + r_out_off[i], c->dstage + d_out_off[i] + lo * sp.out_stride[i],
+                           cnt * sp.out_stride[i], hipMemcpyDeviceToHost, c->s_out));
+    if (out_ring) HIPCK(hipEventRecord(c->ev_out[ch], c->s_out));   // only the staged path needs to know when ONE chunk has arrived
+    tr("D2H enqueued", ch);
     return BJJ_OK;
   };
   size_t enqueued = 0;
   auto body = [&]() -> int {
     size_t next_in = 0;           // next chunk whose pageable inputs are handed to the workers (one chunk ahead of the enqueue)
     for (size_t ch = 0; ch < nchunks; ch++) {
-      while (next_in < nchunks && next_in <= ch + 1) {
-        if (next_in >= BJJ_PIPE_BUFS) { int r = finish(next_in - BJJ_PIPE_BUFS); if (r) return r; }   // frees ring slot next_in % BJJ_PIPE_BUFS
-        if (n_staged) submit_in(next_in);
-        next_in++;
-      }
-      if (pool) pool->wait(&g_in[ch]);
+      while (next_in < nchunks && next_in <= ch + 1) { int r = submit_in(next_in); if (r) return r; next_in++; }
+      if (in_ring) pool->wait(&g_in[ch]);
       { int r = enqueue(ch); if (r) return r; }
       enqueued = ch + 1;
-      while (n_staged && harvested < enqueued) {   // results that have already arrived: start their copy-out, do not wait
+      while (out_ring && harvested < enqueued) {   // results that have already arrived: start their copy-out, do not wait
         const int r = harvest(harvested, false);
         if (r == 1) break;
         if (r) return r;
         harvested++;
       }
     }
-    for (size_t ch = nchunks >= BJJ_PIPE_BUFS ? nchunks - BJJ_PIPE_BUFS : 0; ch < nchunks; ch++) { int r = finish(ch); if (r) return r; }
+    if (out_ring) for (size_t ch = harvested; ch < nchunks; ch++) { int r = finish_out(ch); if (r) return r; }
+    if (out_ring) for (size_t ch = 0; ch < nchunks; ch++) pool->wait(&g_out[ch]);
+    HIPCK(hipStreamSynchronize(c->s_out));      // behind every chunk's kernels
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipStreamSynchronize(c->stream2));
     return BJJ_OK;
   };
   int rc = body();
-  if (rc) {   // error path: nothing may still be writing into the caller's memory or reading the ring when we return
+  tr("all chunks finished", nchunks);
+  if (rc) {   // error path: nothing may still be writing into the caller's memory or reading the rings when we return
     hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->s_out);
     (void)hipGetLastError();
     if (pool) for (size_t ch = 0; ch < nchunks; ch++) { pool->wait(&g_in[ch]); pool->wait(&g_out[ch]); }
   }
   if (sp.secret) {  // key material went through the staging levels: wipe them (also on the error path)
     hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->s_out);
+    if (c->dstage) hipMemsetAsync(c->dstage, 0, dev_tot, c->stream);
     for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
-      if (c->dstage[b]) hipMemsetAsync(c->dstage[b], 0, tot, c->stream);
-      if (c->pinned[b]) secure_bzero(c->pinned[b], c->pinned_bytes);
+      if (c->pin_in[b]) secure_bzero(c->pin_in[b], c->pin_in_bytes);
+      if (c->pin_out[b]) secure_bzero(c->pin_out[b], c->pin_out_bytes);
     }
     hipStreamSynchronize(c->stream);
   }
+  (void)n_staged;
+  return rc;
+}
+template <typename Launch>
+static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch) {
+  ENTER_DEVICE(c->device);
+  { int rc = ensure_pipe(c, 0, 0, 0, 0); if (rc) return rc; }   // streams, the chunk schedule, the knobs
+  // ---- which arrays are pinned (copied directly) and which go through the pinned rings
+  bool in_direct[4], out_direct[4];
+  u32 n_direct = 0, n_staged = 0;
+  size_t per_item = 0;
+  for (int i = 0; i < sp.n_in; i++) { in_direct[i] = !c->force_staged && host_range_pinned(sp.in[i], n * sp.in_stride[i]); (in_direct[i] ? n_direct : n_staged)++; per_item += sp.in_stride[i]; }
+  for (int i = 0; i < sp.n_out; i++) { out_direct[i] = !c->force_staged && host_range_pinned(sp.out[i], n * sp.out_stride[i]); (out_direct[i] ? n_direct : n_staged)++; per_item += sp.out_stride[i]; }
+  // ---- super-batches: what fits into the device staging budget at once (2^20 verifications are 202 MB)
+  size_t cap = c->pipe_budget / per_item;
+  cap = cap > c->pipe_chunk ? cap / c->pipe_chunk * c->pipe_chunk : c->pipe_chunk;
+  u32 chunks = 0;
+  int rc = BJJ_OK;
+  for (size_t lo = 0; lo < n && !rc; lo += cap) {
+    const size_t cnt = n - lo < cap ? n - lo : cap;
+    PipeSpec sub = sp;
+    for (int i = 0; i < sp.n_in; i++) sub.in[i] = sp.in[i] + lo * sp.in_stride[i];
+    for (int i = 0; i < sp.n_out; i++) sub.out[i] = sp.out[i] + lo * sp.out_stride[i];
+    rc = run_super_batch(c, cnt, sub, in_direct, out_direct, n_staged, launch, &chunks);
+  }
+  c->last_host_direct = n_direct; c->last_host_staged = n_staged; c->last_host_chunks = chunks;
   // the call has synchronised for the caller: a verify / variable-base workgroup that gave up waiting for a table slot makes
   // it an error here, not at some later bjj_sync
   if (!rc) rc = ctx_check_slot_queues(c, "host-pointer call");
@@ -610,8 +699,6 @@ static void ctx_destroy(bjj_ctx* c) {
     if (S.scratch) hipFree(S.scratch);
     if (S.vb_tables) hipFree(S.vb_tables);
     if (S.slow) hipFree(S.slow);
-    if (S.slotq) hipFree(S.slotq);
-    if (S.slotq2) hipFree(S.slotq2);
     if (S.ev_scan_in) hipEventDestroy(S.ev_scan_in);
     if (S.ev_scan_out) hipEventDestroy(S.ev_scan_out);
     if (S.scan_stream) hipStreamDestroy(S.scan_stream);
@@ -625,13 +712,15 @@ static void ctx_destroy(bjj_ctx* c) {
   delete c->pool;   // joins the copy workers
   c->pool = nullptr;
   for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
-    if (c->pinned[b]) { secure_bzero(c->pinned[b], c->pinned_bytes); hipHostFree(c->pinned[b]); }
-    if (c->dstage[b]) { hipMemset(c->dstage[b], 0, c->pipe_bytes); hipFree(c->dstage[b]); }
-    if (c->ev_in[b]) hipEventDestroy(c->ev_in[b]);
-    if (c->ev_k[b]) hipEventDestroy(c->ev_k[b]);
-    if (c->ev_out[b]) hipEventDestroy(c->ev_out[b]);
+    if (c->pin_in[b]) { secure_bzero(c->pin_in[b], c->pin_in_bytes); hipHostFree(c->pin_in[b]); }
+    if (c->pin_out[b]) { secure_bzero(c->pin_out[b], c->pin_out_bytes); hipHostFree(c->pin_out[b]); }
   }
+  if (c->dstage) { hipMemset(c->dstage, 0, c->pipe_bytes); hipFree(c->dstage); }
+  for (hipEvent_t e : c->ev_in) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_out) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_k) hipEventDestroy(e);
   if (c->err_words) hipHostFree(c->err_words);
+  if (c->slot_block) hipFree(c->slot_block);
   if (c->s_in) hipStreamDestroy(c->s_in);
   if (c->s_out) hipStreamDestroy(c->s_out);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -844,7 +933,7 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   info->window_bits = c->W;
   info->n_windows = c->nwin;
   info->table_bytes = c->table_bytes;
-  info->scratch_bytes = BJJ_PIPE_BUFS * (uint64_t)c->pipe_bytes;
+  info->scratch_bytes = (uint64_t)c->pipe_bytes;
   for (const ScratchSet& S : c->set)
     info->scratch_bytes += S.scratch_items * 64 + S.vb_threads * VB_TABLE_WORDS_MAX * sizeof(u32) + S.slow_items * 4 +
                            (S.codec_items ? S.codec_items * 162 + 64 : 0);
@@ -939,6 +1028,7 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
   if (overlap && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; overlap = false; }
   const int kv = c->k2_variant >= 0 ? c->k2_variant : (overlap ? 0 : 1);
   c->last_k2 = kv;
+  if (kv == 1) c->rings_used = true;      // the tiles take their table scratch from the slot queues
   LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, kv, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
                               (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)),
            "bjj_mul_var_base_dev");
@@ -976,6 +1066,7 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
   // k_verify.hip: persistent waves for ONE large launch that runs alone, one group per workgroup otherwise
   const int mode = c->verify_mode >= 0 ? c->verify_mode : ((!busy && n > BJJ_LARGE_LAUNCH) ? 0 : 1);
   c->last_verify_mode = mode;
+  if (mode == 1) c->rings_used = true;    // one group per workgroup: table scratch from the slot queues
   if (busy) {   // the chip is (about to be) full of another launch's workgroups: priority stream
     HIPCK(hipEventRecord(S->ev_scan_in, st));
     HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));

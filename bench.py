@@ -785,8 +785,14 @@ def host_api_block(ctx, n, orc):
     m = np.ascontiguousarray(w.random_u256(w.SEED_MSGS, n, 0, top_bits_cleared=3)).reshape(-1)
     idx = np.unique(np.linspace(0, n - 1, 64).astype(np.int64))
 
-    def best(f, reps):
+    def best(f, reps, warm_s=0.5):
+        # calls back to back for warm_s first: the section before this one leaves the GPU idle for a few hundred milliseconds
+        # (a context torn down, inputs generated on the host), and the first calls after that run during the DVFS ramp --
+        # 2.7 ms instead of 1.6 for 2^20 fixed-base multiplications (tools/host_api_probe.py, profiles/r05_host_pipeline.txt)
+        t_w = time.perf_counter()
         f()
+        while time.perf_counter() - t_w < warm_s:
+            f()
         ts = []
         for _ in range(reps):
             t = time.perf_counter()
@@ -831,9 +837,10 @@ def host_api_block(ctx, n, orc):
     pinned = run("pinned")
     pageable = run("pageable")
     return {"note": "PCIe-inclusive: host pointers in, host pointers out, synchronous call.  fixed_base / verify = caller arrays in "
-                    "pinned memory (bjj_host_alloc): copied directly, chunked pipeline (2^16 items first, doubling to 2^18), chunk "
+                    "pinned memory (bjj_host_alloc): copied directly, chunked pipeline (2^15 items first, doubling to 2^18), chunk "
                     "kernels alternating over the context's two compute streams; `pageable` = the same calls on ordinary memory, "
-                    "staged through pinned buffers by %d copy workers.  Reported beside the line, never as `value`."
+                    "staged through pinned buffers by %d copy workers.  Calls back to back for 0.5 s before the timed ones (sustained "
+                    "clocks), then best of 7 (fixed_base) / 3 (verify) and the median.  Reported beside the line, never as `value`."
                     % ctx.info().host_copy_threads,
             "fixed_base": pinned["fixed_base"], "verify": pinned["verify"], "pageable": {"fixed_base": pageable["fixed_base"], "verify": pageable["verify"]},
             "copy_threads": ctx.info().host_copy_threads,

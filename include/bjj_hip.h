@@ -82,13 +82,14 @@
  * copy out of consecutive chunks overlap).  Arrays in PINNED host memory -- bjj_host_alloc, bjj_host_register, or any range the
  * HIP runtime knows as pinned (hipHostMalloc, hipHostRegister, torch's pin_memory) -- are copied from / to directly; pageable
  * arrays are staged through pinned buffers by worker threads of the context (BJJ_STAGE_THREADS, default 4).  The choice is per
- * array and per call; results are identical.  2^20 fixed-base multiplications: about 1.5 ms pinned (the 64 MB of results
- * crossing PCIe are the bound), about 2.5 ms pageable, 0.6 ms on device pointers.
+ * array and per call; results are identical.  2^20 fixed-base multiplications: about 1.6 ms pinned (the 64 MB of results
+ * crossing PCIe take 1.19 ms), about 2.1 ms pageable, 0.6 ms on device pointers.
  * *_dev entry points take DEVICE pointers (16-byte aligned) plus a hipStream_t
  * (passed as void*; NULL = the context's stream), enqueue the work and return
  * without synchronising -- they are what bench.py times.
  * More environment knobs (read when the context first runs a host-pointer call): BJJ_PIPE_CHUNK / BJJ_PIPE_FIRST_CHUNK
- * (items per pipeline chunk: the first chunk, doubling up to the cap; defaults 65536 / 262144), BJJ_HOST_FORCE_STAGED=1
+ * (items per pipeline chunk: the first chunk, doubling up to the cap; defaults 32768 / 262144), BJJ_PIPE_STAGING_MB
+ * (device staging a call may take, default 1024; larger batches run as consecutive super-batches), BJJ_HOST_FORCE_STAGED=1
  * (treat every host array as pageable), BJJ_STAGE_THREADS.
  */
 #ifndef BJJ_HIP_H

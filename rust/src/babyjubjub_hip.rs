@@ -317,32 +317,44 @@ pub fn mul_scalar_batch(points: &[Point], scalars: &[BigInt]) -> Vec<Point> {
     }
     let width = scalars.iter().map(|n| ((n.bits() as usize + 255) / 256).max(1) * 32).max().unwrap();
     let all_b8 = points.iter().all(|p| p.x == B8.x && p.y == B8.y);
-    let mut sc = Vec::with_capacity(scalars.len() * width);
-    for n in scalars {
-        sc.extend_from_slice(&bigint_to_le(n, width));
-    }
-    let out = if all_b8 && width == 32 {
-        with_gpu(|gpu| gpu.mul_fixed_base(&sc))
-    } else {
-        let mut pts = Vec::with_capacity(points.len() * 64);
-        for p in points {
-            pts.extend_from_slice(&point_bytes(p));
+    let n = points.len();
+    // records are written straight into pinned memory: the library then moves every byte once, over PCIe (include/bjj_hip.h)
+    with_gpu(|gpu| {
+        let mut sc = gpu.pinned(n * width).expect("mul_scalar_batch");
+        for (i, k) in scalars.iter().enumerate() {
+            sc[i * width..(i + 1) * width].copy_from_slice(&bigint_to_le(k, width));
         }
-        with_gpu(|gpu| gpu.mul_var_base(&pts, &sc, width))
-    }
-    .expect("mul_scalar_batch");
-    out.chunks(64).map(point_from_bytes).collect()
+        let mut out = gpu.pinned(n * 64).expect("mul_scalar_batch");
+        if all_b8 && width == 32 {
+            gpu.mul_fixed_base_into(&sc, &mut out)
+        } else {
+            let mut pts = gpu.pinned(n * 64).expect("mul_scalar_batch");
+            for (i, p) in points.iter().enumerate() {
+                pts[i * 64..(i + 1) * 64].copy_from_slice(&point_bytes(p));
+            }
+            gpu.mul_var_base_into(&pts, &sc, width, &mut out)
+        }
+        .expect("mul_scalar_batch");
+        out.chunks(64).map(point_from_bytes).collect()
+    })
 }
 
 /// `B8.mul_scalar(&n)` for every n (the engine of `PrivateKey::public`, lib.rs:304-306)
 pub fn mul_fixed_base_batch(scalars: &[BigInt]) -> Vec<Point> {
-    let mut sc = Vec::with_capacity(scalars.len() * 32);
-    for n in scalars {
-        // B8 is on the curve: n * B8 == (|n| mod 8l) * B8 exactly, which also brings any n into the 32-byte record
-        sc.extend_from_slice(&bigint_to_le(&b8_scalar(n), 32));
+    let n = scalars.len();
+    if n == 0 {
+        return Vec::new();
     }
-    let out = with_gpu(|g| g.mul_fixed_base(&sc)).expect("mul_fixed_base_batch");
-    out.chunks(64).map(point_from_bytes).collect()
+    with_gpu(|g| {
+        let mut sc = g.pinned(n * 32).expect("mul_fixed_base_batch");
+        for (i, k) in scalars.iter().enumerate() {
+            // B8 is on the curve: n * B8 == (|n| mod 8l) * B8 exactly, which also brings any n into the 32-byte record
+            sc[i * 32..(i + 1) * 32].copy_from_slice(&bigint_to_le(&b8_scalar(k), 32));
+        }
+        let mut out = g.pinned(n * 64).expect("mul_fixed_base_batch");
+        g.mul_fixed_base_into(&sc, &mut out).expect("mul_fixed_base_batch");
+        out.chunks(64).map(point_from_bytes).collect()
+    })
 }
 
 /// `verify(pks[i], sigs[i], msgs[i])` for all i.  A batch cannot panic for one item: a NEGATIVE msg -- where the
@@ -351,21 +363,28 @@ pub fn verify_batch(pks: &[Point], sigs: &[Signature], msgs: &[BigInt]) -> Vec<b
     assert!(pks.len() == sigs.len() && sigs.len() == msgs.len());
     let n = pks.len();
     let qq = &*Q;
-    let (mut pk, mut r, mut s, mut m) = (Vec::with_capacity(n * 64), Vec::with_capacity(n * 64), Vec::with_capacity(n * 32), Vec::with_capacity(n * 32));
-    let mut early_false = vec![false; n];
-    for i in 0..n {
-        pk.extend_from_slice(&point_bytes(&pks[i]));
-        r.extend_from_slice(&point_bytes(&sigs[i].r_b8));
-        // msg > Q is `false` before anything else (lib.rs:396-398); s wider than 256 bits only multiplies B8: reduce mod 8l
-        early_false[i] = msgs[i] > *qq || msgs[i].sign() == Sign::Minus;
-        let msg = if early_false[i] { BigInt::zero() } else { msgs[i].clone() };
-        // s only multiplies B8 (:405) and its sign is dropped there: any s, of any width, as |s| mod 8l
-        let sv = if sigs[i].s.bits() > 256 { b8_scalar(&sigs[i].s) } else { sigs[i].s.clone() };
-        s.extend_from_slice(&bigint_to_le(&sv, 32));
-        m.extend_from_slice(&bigint_to_le(&msg, 32));
+    if n == 0 {
+        return Vec::new();
     }
-    let ok = with_gpu(|g| g.eddsa_verify(&pk, &r, &s, &m)).expect("verify_batch");
-    (0..n).map(|i| !early_false[i] && ok[i] == 1).collect()
+    with_gpu(|g| {
+        let (mut pk, mut r) = (g.pinned(n * 64).expect("verify_batch"), g.pinned(n * 64).expect("verify_batch"));
+        let (mut s, mut m) = (g.pinned(n * 32).expect("verify_batch"), g.pinned(n * 32).expect("verify_batch"));
+        let mut early_false = vec![false; n];
+        for i in 0..n {
+            pk[i * 64..(i + 1) * 64].copy_from_slice(&point_bytes(&pks[i]));
+            r[i * 64..(i + 1) * 64].copy_from_slice(&point_bytes(&sigs[i].r_b8));
+            // msg > Q is `false` before anything else (lib.rs:396-398); s wider than 256 bits only multiplies B8: reduce mod 8l
+            early_false[i] = msgs[i] > *qq || msgs[i].sign() == Sign::Minus;
+            let msg = if early_false[i] { BigInt::zero() } else { msgs[i].clone() };
+            // s only multiplies B8 (:405) and its sign is dropped there: any s, of any width, as |s| mod 8l
+            let sv = if sigs[i].s.bits() > 256 { b8_scalar(&sigs[i].s) } else { sigs[i].s.clone() };
+            s[i * 32..(i + 1) * 32].copy_from_slice(&bigint_to_le(&sv, 32));
+            m[i * 32..(i + 1) * 32].copy_from_slice(&bigint_to_le(&msg, 32));
+        }
+        let mut ok = g.pinned(n).expect("verify_batch");
+        g.eddsa_verify_into(&pk, &r, &s, &m, &mut ok).expect("verify_batch");
+        (0..n).map(|i| !early_false[i] && ok[i] == 1).collect()
+    })
 }
 
 /// `PrivateKey::public` for every key

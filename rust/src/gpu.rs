@@ -13,6 +13,37 @@ use std::rc::Rc;
 pub struct Gpu {
     ctx: *mut ffi::BjjCtx,
     owned: bool,
+    /// released pinned buffers, reused by `pinned()` (page-locking memory costs ~60 us per MB: never per call)
+    pool: RefCell<Vec<(*mut u8, usize)>>,
+}
+
+/// Page-locked host memory from `bjj_host_alloc`: the host-pointer entry points copy such arrays straight over PCIe
+/// (no staging copy inside the library).  The `*_batch` functions marshal their `BigInt` / `Fr` records directly into
+/// these buffers.  Returned to the context's pool on drop.
+pub struct PinnedBuf<'a> {
+    gpu: &'a Gpu,
+    ptr: *mut u8,
+    cap: usize,
+    len: usize,
+}
+
+impl<'a> std::ops::Deref for PinnedBuf<'a> {
+    type Target = [u8];
+    fn deref(&self) -> &[u8] {
+        unsafe { std::slice::from_raw_parts(self.ptr, self.len) }
+    }
+}
+
+impl<'a> std::ops::DerefMut for PinnedBuf<'a> {
+    fn deref_mut(&mut self) -> &mut [u8] {
+        unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) }
+    }
+}
+
+impl<'a> Drop for PinnedBuf<'a> {
+    fn drop(&mut self) {
+        self.gpu.pool.borrow_mut().push((self.ptr, self.cap));
+    }
 }
 
 pub(crate) fn last_error() -> String {
@@ -32,12 +63,31 @@ impl Gpu {
     pub fn new(device: i32, window_bits: i32) -> Result<Gpu, String> {
         let mut ctx: *mut ffi::BjjCtx = ptr::null_mut();
         check(unsafe { ffi::bjj_init(device as c_int, window_bits as c_int, &mut ctx) }, "bjj_init")?;
-        Ok(Gpu { ctx, owned: true })
+        Ok(Gpu { ctx, owned: true, pool: RefCell::new(Vec::new()) })
     }
 
     /// A context owned by a `multi::MultiGpu` handle.
     pub(crate) fn borrowed(ctx: *mut ffi::BjjCtx) -> Gpu {
-        Gpu { ctx, owned: false }
+        Gpu { ctx, owned: false, pool: RefCell::new(Vec::new()) }
+    }
+
+    /// `len` bytes of pinned memory (contents unspecified): the smallest released buffer that fits, else a new allocation.
+    pub fn pinned(&self, len: usize) -> Result<PinnedBuf<'_>, String> {
+        let mut pool = self.pool.borrow_mut();
+        let mut best: Option<usize> = None;
+        for (i, &(_, cap)) in pool.iter().enumerate() {
+            if cap >= len && best.map_or(true, |b| cap < pool[b].1) {
+                best = Some(i);
+            }
+        }
+        if let Some(i) = best {
+            let (ptr, cap) = pool.swap_remove(i);
+            return Ok(PinnedBuf { gpu: self, ptr, cap, len });
+        }
+        let cap = len.max(4096).next_power_of_two();
+        let mut p: *mut std::os::raw::c_void = ptr::null_mut();
+        check(unsafe { ffi::bjj_host_alloc(self.ctx, cap, &mut p) }, "bjj_host_alloc")?;
+        Ok(PinnedBuf { gpu: self, ptr: p as *mut u8, cap, len })
     }
 
     pub fn info(&self) -> Result<ffi::BjjInfo, String> {
@@ -61,6 +111,41 @@ impl Gpu {
         let mut out = vec![0u8; n * 64];
         check(unsafe { ffi::bjj_mul_fixed_base(self.ctx, scalars.as_ptr(), n, out.as_mut_ptr()) }, "bjj_mul_fixed_base")?;
         Ok(out)
+    }
+
+    /// The same on caller-provided buffers (pinned ones are copied directly): `out` holds n * 64 bytes.
+    pub fn mul_fixed_base_into(&self, scalars: &[u8], out: &mut [u8]) -> Result<(), String> {
+        let n = records(scalars, 32, "scalars")?;
+        if out.len() != n * 64 {
+            return Err("mul_fixed_base_into: out must hold 64 bytes per scalar".into());
+        }
+        check(unsafe { ffi::bjj_mul_fixed_base(self.ctx, scalars.as_ptr(), n, out.as_mut_ptr()) }, "bjj_mul_fixed_base")
+    }
+
+    pub fn mul_var_base_into(&self, points: &[u8], scalars: &[u8], scalar_bytes: usize, out: &mut [u8]) -> Result<(), String> {
+        let n = records(points, 64, "points")?;
+        if scalar_bytes == 0 || scalar_bytes % 32 != 0 || scalars.len() != n * scalar_bytes || out.len() != n * 64 {
+            return Err("mul_var_base_into: array lengths disagree".into());
+        }
+        let rc = unsafe {
+            if scalar_bytes == 32 {
+                ffi::bjj_mul_var_base(self.ctx, points.as_ptr(), scalars.as_ptr(), n, out.as_mut_ptr())
+            } else {
+                ffi::bjj_mul_var_base_wide(self.ctx, points.as_ptr(), scalars.as_ptr(), scalar_bytes, n, out.as_mut_ptr())
+            }
+        };
+        check(rc, "bjj_mul_var_base")
+    }
+
+    pub fn eddsa_verify_into(&self, pk: &[u8], r_b8: &[u8], s: &[u8], msg: &[u8], ok: &mut [u8]) -> Result<(), String> {
+        let n = records(s, 32, "s")?;
+        if pk.len() != n * 64 || r_b8.len() != n * 64 || msg.len() != n * 32 || ok.len() != n {
+            return Err("eddsa_verify_into: array lengths disagree".into());
+        }
+        check(
+            unsafe { ffi::bjj_eddsa_verify(self.ctx, pk.as_ptr(), r_b8.as_ptr(), s.as_ptr(), msg.as_ptr(), n, ok.as_mut_ptr()) },
+            "bjj_eddsa_verify",
+        )
     }
 
     /// `P.mul_scalar(n)`; `scalar_bytes` per scalar record (a multiple of 32; 32 takes the fast entry point).
@@ -200,6 +285,9 @@ impl Gpu {
 
 impl Drop for Gpu {
     fn drop(&mut self) {
+        for (p, _) in self.pool.borrow_mut().drain(..) {
+            unsafe { ffi::bjj_host_free(self.ctx, p as *mut std::os::raw::c_void) };
+        }
         if self.owned && !self.ctx.is_null() {
             unsafe { ffi::bjj_free(self.ctx) }
         }

@@ -131,7 +131,7 @@ def test_host_memory_api_argument_checks(ctx16):
 def test_forced_staging_and_chunk_schedule_from_the_environment(oracle):
     """BJJ_HOST_FORCE_STAGED / BJJ_PIPE_CHUNK / BJJ_PIPE_FIRST_CHUNK / BJJ_STAGE_THREADS, in a child process (the knobs are
     read when a context first runs a host-pointer call): pinned arrays are then staged too, 10 000 items in 1 024 / 2 048 /
-    2 048 ... chunks recycle the 4-deep ring, and the bytes do not change."""
+    2 048 ... chunks recycle the 4-deep pinned rings, and the bytes do not change."""
     import os
     import subprocess
     import sys
@@ -159,7 +159,7 @@ c.close()
         r = subprocess.run([sys.executable, "-c", code, outp], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0, r.stdout
         info = [l for l in r.stdout.splitlines() if l.startswith("INFO")][0].split()[1:]
-        assert [int(x) for x in info] == [0, 2, 6, 2], r.stdout      # 1024 + 2048 x 4 + 784 = 10 000: six chunks, two workers
+        assert [int(x) for x in info] == [0, 2, 5, 2], r.stdout      # 1024 + 2048 x 3 + 2832 (the 784-item remainder joins the last chunk): five chunks, two workers
         got = np.load(outp).reshape(10000, 64)
     from babyjubjub_rs_amd import workload as w
     assert (got == oracle.mul_fixed_base(w.scalars_254(10000, offset=9))).all()
