@@ -167,6 +167,7 @@ struct bjj_ctx {
   size_t pipe_budget = 0;                  // bytes of device staging a call may take (BJJ_PIPE_STAGING_MB)
   CopyPool* pool = nullptr;
   size_t pipe_chunk = 0, pipe_first = 0;   // chunk schedule (items): first chunk, doubling up to pipe_chunk
+  bool in_pipeline = false;                // a host-pointer call is enqueueing: the verify scans run in line (enqueue_verify)
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
   // what the last calls did (bjj_get_info; tests and the bench line read these)
   int last_k1 = -1, last_k2 = -1, last_verify_mode = -1;
@@ -391,14 +392,17 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
 // * Two lanes = the context's two scratch sets: the kernels of consecutive chunks overlap on the chip like the two-stream
 //   launches of the device-pointer API (verify in 2^18-item chunks on ONE stream ran 6.76 ms per chunk, on two 4.47 ms:
 //   profiles/r04_throughput_vs_batch.txt).  The lanes carry kernels only.
-// * The copy streams live in the HIGH-priority queue pool.  On this runtime an event record or a cross-stream wait behind an
-//   SDMA copy becomes a barrier packet in the stream's HARDWARE queue; HIP maps the streams of one priority onto four hardware
-//   queues, and a kernel of another stream that lands behind such a packet waits for that copy.  The first form of this
-//   pipeline (normal-priority copy streams, one event per chunk and direction) ran every kernel behind the previous chunk's
-//   D2H: 2.7 ms for 2^20 fixed-base multiplications; the second (D2H in stream order behind the kernels: no events, but the
-//   runtime then copies with a shader blit at half the SDMA rate) 1.65 ms; this one 1.4 (profiles/r05_host_pipeline.txt).
-//   High-priority streams have their own queue pool (where the verify scan streams live as well), so no kernel of a lane --
-//   or of the caller's own streams -- can ever sit behind one of the pipeline's copy barriers.
+// * The copy streams and the second lane live in the HIGH-priority queue pool.  HIP gives the streams of one priority four
+//   hardware queues (bound at a stream's first use; a fifth stream shares one), packets of a hardware queue run in order, and
+//   an event record or a cross-stream wait behind an SDMA copy is a barrier packet there -- so a kernel of ANOTHER stream that
+//   lands behind such a packet waits for that copy.  The first form of this pipeline (normal-priority copy streams, one event
+//   per chunk and direction) ran every kernel behind the previous chunk's D2H: 2.7 ms for 2^20 fixed-base multiplications;
+//   the second (D2H in stream order behind the kernels: no events, but the runtime then copies with a shader blit at half the
+//   SDMA rate) 1.65 ms; this one 1.6 (profiles/r05_host_pipeline.txt).  Apart from the context's own stream the pipeline
+//   occupies no normal-priority queue: a library that parks streams there leaves the caller's streams to share what is left
+//   (two torch streams first used after a host-pointer call landed on ONE hardware queue and their launches ran one after the
+//   other).  On the direct path no event sits behind a D2H at all; the event behind each H2D is one a kernel that lands behind
+//   it needs anyway (copies on s_in complete in order).
 // * The first chunk is small (2^15 items: the copy-out engine, which bounds a copy-bound call, starts 0.1 ms after the call)
 //   and the size doubles up to 2^18; a remainder below half a chunk is merged into the
 //   last chunk (a small last launch leaves the chip half empty).  BJJ_PIPE_FIRST_CHUNK / BJJ_PIPE_CHUNK (items) override.
@@ -471,7 +475,11 @@ static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ri
     }
     HIPCK(hipStreamCreateWithPriority(&c->s_in, hipStreamNonBlocking, prio_in));
     HIPCK(hipStreamCreateWithPriority(&c->s_out, hipStreamNonBlocking, prio_out));
-    HIPCK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    // the second lane is a high-priority stream as well: HIP gives the streams of one priority FOUR hardware queues, and a
+    // library that parks two normal-priority streams in them (the context's own stream is one) leaves the caller's streams to
+    // share what is left -- two torch streams first used after a host-pointer call landed on ONE hardware queue and their
+    // launches ran one after the other (tools/queue_map_probe.py, profiles/r05_host_pipeline.txt)
+    HIPCK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
     c->pipe_chunk = env_items("BJJ_PIPE_CHUNK", BJJ_PIPE_CHUNK);
     c->pipe_first = env_items("BJJ_PIPE_FIRST_CHUNK", BJJ_PIPE_FIRST_CHUNK);
     if (c->pipe_first > c->pipe_chunk) c->pipe_first = c->pipe_chunk;
@@ -586,6 +594,15 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
     pool->wait(&g_out[ch]);
     return BJJ_OK;
   };
+  // ... and, in the same developer mode, timing events around every stage (device-side timeline of the call, printed at its end;
+  // the extra event records behind copies sit in the high-priority pool)
+  std::vector<hipEvent_t> tev;
+  auto tmark = [&](hipStream_t st) {
+    if (!trace) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) == hipSuccess) { hipEventRecord(e, st); tev.push_back(e); }
+  };
+  tmark(c->s_in);   // t = 0
   auto enqueue = [&](size_t ch) -> int {
     const int b = (int)(ch % BJJ_PIPE_BUFS);
     const size_t lo = lo_of[ch], cnt = cnt_of(ch);
@@ -594,6 +611,7 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
       HIPCK(hipMemcpyAsync(c->dstage + d_in_off[i] + lo * sp.in_stride[i], in_direct[i] ? sp.in[i] + lo * sp.in_stride[i] : c->pin_in[b] + r_in_off[i],
                            cnt * sp.in_stride[i], hipMemcpyHostToDevice, c->s_in));
     HIPCK(hipEventRecord(c->ev_in[ch], c->s_in));
+    tmark(c->s_in);                                            // [1 + 4 ch]: H2D done
     hipStream_t lane = (ch & 1) ? c->stream2 : c->stream;
     HIPCK(hipStreamWaitEvent(lane, c->ev_in[ch], 0));
     void* d_in[4]; void* d_out[4];
@@ -601,13 +619,17 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
     for (int i = 0; i < sp.n_out; i++) d_out[i] = c->dstage + d_out_off[i] + lo * sp.out_stride[i];
     int r = launch(d_in, d_out, cnt, (void*)lane); if (r) return r;
     HIPCK(hipEventRecord(c->ev_k[ch], lane));                  // behind a kernel: its completion signal, no extra packet
+    tmark(lane);                                               // [2 + 4 ch]: kernels done
     tr("kernels enqueued", ch);
     if (out_ring && ch >= BJJ_PIPE_BUFS) { r = finish_out(ch - BJJ_PIPE_BUFS); if (r) return r; }   // frees pin_out[b]
-    HIPCK(hipStreamWaitEvent(c->s_out, c->ev_k[ch], 0));
+    hipStream_t so = c->s_out;   // (copy-outs alternating over two streams were measured: 1.61-1.63 ms against 1.62-1.64, not worth a hardware queue)
+    HIPCK(hipStreamWaitEvent(so, c->ev_k[ch], 0));
+    tmark(so);                                                 // [3 + 4 ch]: D2H may begin
     for (int i = 0; i < sp.n_out; i++)
       HIPCK(hipMemcpyAsync(out_direct[i] ? sp.out[i] + lo * sp.out_stride[i] : c->pin_out[b] + r_out_off[i], c->dstage + d_out_off[i] + lo * sp.out_stride[i],
-                           cnt * sp.out_stride[i], hipMemcpyDeviceToHost, c->s_out));
-    if (out_ring) HIPCK(hipEventRecord(c->ev_out[ch], c->s_out));   // only the staged path needs to know when ONE chunk has arrived
+                           cnt * sp.out_stride[i], hipMemcpyDeviceToHost, so));
+    if (out_ring) HIPCK(hipEventRecord(c->ev_out[ch], so));    // only the staged path needs to know when ONE chunk has arrived
+    tmark(so);                                                 // [4 + 4 ch]: D2H done
     tr("D2H enqueued", ch);
     return BJJ_OK;
   };
@@ -635,6 +657,15 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
   };
   int rc = body();
   tr("all chunks finished", nchunks);
+  if (trace && tev.size() == 1 + 4 * nchunks) {
+    for (size_t ch = 0; ch < nchunks; ch++) {
+      float t[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 4; k++) hipEventElapsedTime(&t[k], tev[0], tev[1 + 4 * ch + k]);
+      fprintf(stderr, "[pipe-dev] chunk %zu (%7zu items)  H2D done %7.1f us  kernels done %7.1f us  D2H %7.1f .. %7.1f us\n", ch, cnt_of(ch), t[0] * 1e3, t[1] * 1e3,
+              t[2] * 1e3, t[3] * 1e3);
+    }
+  }
+  for (hipEvent_t e : tev) hipEventDestroy(e);
   if (rc) {   // error path: nothing may still be writing into the caller's memory or reading the rings when we return
     hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->s_out);
     (void)hipGetLastError();
@@ -667,6 +698,7 @@ static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch
   cap = cap > c->pipe_chunk ? cap / c->pipe_chunk * c->pipe_chunk : c->pipe_chunk;
   u32 chunks = 0;
   int rc = BJJ_OK;
+  c->in_pipeline = true;
   for (size_t lo = 0; lo < n && !rc; lo += cap) {
     const size_t cnt = n - lo < cap ? n - lo : cap;
     PipeSpec sub = sp;
@@ -674,6 +706,7 @@ static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch
     for (int i = 0; i < sp.n_out; i++) sub.out[i] = sp.out[i] + lo * sp.out_stride[i];
     rc = run_super_batch(c, cnt, sub, in_direct, out_direct, n_staged, launch, &chunks);
   }
+  c->in_pipeline = false;
   c->last_host_direct = n_direct; c->last_host_staged = n_staged; c->last_host_chunks = chunks;
   // the call has synchronised for the caller: a verify / variable-base workgroup that gave up waiting for a table slot makes
   // it an error here, not at some later bjj_sync
@@ -1067,7 +1100,10 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
   const int mode = c->verify_mode >= 0 ? c->verify_mode : ((!busy && n > BJJ_LARGE_LAUNCH) ? 0 : 1);
   c->last_verify_mode = mode;
   if (mode == 1) c->rings_used = true;    // one group per workgroup: table scratch from the slot queues
-  if (busy) {   // the chip is (about to be) full of another launch's workgroups: priority stream
+  // inside the host-pointer pipeline the scan stays in line: its lanes, copy streams and the scan streams would be five
+  // co-active high-priority streams on four hardware queues, and a scan that lands behind the copy-out stream's wait for the
+  // previous chunk's kernels would serialise the lanes
+  if (busy && !c->in_pipeline) {   // the chip is (about to be) full of another launch's workgroups: priority stream
     HIPCK(hipEventRecord(S->ev_scan_in, st));
     HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));
     LAUNCHCK(bjjk::verify_scan(S->scan_stream, scan_grid, pk, r, msg, n, S->slow), "verify scan");

@@ -1033,6 +1033,13 @@ def main():
     ctx.reserve(max(n, 1))
     stream = torch.cuda.Stream(device=dev)
     stream_b = torch.cuda.Stream(device=dev)
+    # HIP binds a stream to one of the four hardware queues of its priority when the stream is first USED: both timing streams
+    # are touched now, before anything else creates streams, so that they get a queue each (two streams that end up on one
+    # hardware queue run their launches one after the other: profiles/r05_host_pipeline.txt)
+    for st_ in (stream, stream_b):
+        with torch.cuda.stream(st_):
+            torch.zeros(64, device=dev).add_(1)
+    torch.cuda.synchronize()
 
     def second_stream(k):
         ns = args.streams if args.streams is not None else DEFAULT_STREAMS.get(k, 1)

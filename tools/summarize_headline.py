@@ -17,7 +17,7 @@ K = 20
 src = os.path.join(ROOT, "gpurun_out", tag)
 P = os.path.join(src, "ts_" + wl)
 FAMILY = {"fixed_base": ("bjj_k_mul_fixed_base",), "var_base": ("bjj_k_mul_var_base",), "verify": ("bjj_k_eddsa_verify",)}[wl]
-HELPERS = {"verify": ("bjj_k_eddsa_verify_scan",)}.get(wl, ())
+HELPERS = {"verify": ("bjj_k_eddsa_verify_scan",), "var_base": ("bjj_k_mul_var_base_exact",)}.get(wl, ())   # per-launch companions of the main kernel
 
 
 def short(name):

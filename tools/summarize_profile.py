@@ -81,8 +81,11 @@ if traffic:
         raise SystemExit("csrc/ changed since %s was profiled (%s != %s): re-profile" % (tag, profiled, srchash.tree_hash()))
     d[wl] = {"bytes_per_launch": traffic, "source": "profiles/%s_%s_summary.md" % (tag, wl), "batch": int(meta.get("Grid_Size", 0)) and 1 << 20,
              "source_hash": profiled or srchash.tree_hash()}
+    d[wl]["kernel"] = KERNEL
     if "SQ_INSTS_VALU" in counters:
         d[wl]["valu_insts_per_launch"] = counters["SQ_INSTS_VALU"][0]
+    if "SQ_BUSY_CYCLES" in counters:    # bench.py: counter-derived VALU utilisation (instructions per SIMD per busy cycle)
+        d[wl]["sq_busy_cycles"] = counters["SQ_BUSY_CYCLES"][0]
     try:  # the window width the counters were collected with (bench.py only quotes them for the same configuration)
         bl = [l for l in open(os.path.join(src, "bench_%s.json" % wl)).read().splitlines() if l.startswith("{")][-1]
         d[wl]["window_bits"] = json.loads(bl)["config"]["window_bits"]
