@@ -167,7 +167,8 @@ struct bjj_ctx {
   size_t pipe_budget = 0;                  // bytes of device staging a call may take (BJJ_PIPE_STAGING_MB)
   CopyPool* pool = nullptr;
   size_t pipe_chunk = 0, pipe_first = 0;   // chunk schedule (items): first chunk, doubling up to pipe_chunk
-  bool in_pipeline = false;                // a host-pointer call is enqueueing: the verify scans run in line (enqueue_verify)
+  bool in_pipeline = false;                // a host-pointer call is enqueueing (enqueue_verify: where the scans run)
+  bool pipe_scan_inline = true;            // BJJ_PIPE_SCAN=prio (developer): scans of the pipeline's chunks on the priority streams
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
   // what the last calls did (bjj_get_info; tests and the bench line read these)
   int last_k1 = -1, last_k2 = -1, last_verify_mode = -1;
@@ -392,17 +393,23 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
 // * Two lanes = the context's two scratch sets: the kernels of consecutive chunks overlap on the chip like the two-stream
 //   launches of the device-pointer API (verify in 2^18-item chunks on ONE stream ran 6.76 ms per chunk, on two 4.47 ms:
 //   profiles/r04_throughput_vs_batch.txt).  The lanes carry kernels only.
-// * The copy streams and the second lane live in the HIGH-priority queue pool.  HIP gives the streams of one priority four
-//   hardware queues (bound at a stream's first use; a fifth stream shares one), packets of a hardware queue run in order, and
-//   an event record or a cross-stream wait behind an SDMA copy is a barrier packet there -- so a kernel of ANOTHER stream that
-//   lands behind such a packet waits for that copy.  The first form of this pipeline (normal-priority copy streams, one event
-//   per chunk and direction) ran every kernel behind the previous chunk's D2H: 2.7 ms for 2^20 fixed-base multiplications;
-//   the second (D2H in stream order behind the kernels: no events, but the runtime then copies with a shader blit at half the
-//   SDMA rate) 1.65 ms; this one 1.6 (profiles/r05_host_pipeline.txt).  Apart from the context's own stream the pipeline
-//   occupies no normal-priority queue: a library that parks streams there leaves the caller's streams to share what is left
-//   (two torch streams first used after a host-pointer call landed on ONE hardware queue and their launches ran one after the
-//   other).  On the direct path no event sits behind a D2H at all; the event behind each H2D is one a kernel that lands behind
-//   it needs anyway (copies on s_in complete in order).
+// * What orders the stages is chosen so that NO mapping of streams onto hardware queues can hurt.  HIP binds a stream, at its
+//   first use, to one of FOUR hardware queues of its priority (a fifth stream shares one), packets of a hardware queue run in
+//   order, and an event record or a cross-stream wait behind an SDMA copy -- or a wait for a kernel on a copy stream -- is a
+//   barrier packet there: a kernel of ANOTHER stream that lands behind such a packet waits for whatever the packet waits for.
+//   The forms of this pipeline, in the order they were measured (profiles/r05_host_pipeline.txt; 2^20 fixed-base, pinned):
+//     normal-priority copy streams, one event per chunk and stage: every kernel ran behind the previous chunk's D2H   2.7 ms
+//     D2H in stream order behind the kernels (no events; the runtime then copies with a shader blit at half rate)       1.65 ms
+//     copy streams and second lane of the HIGHEST priority (their own queue pool), s_out waiting for the kernels'
+//     events on the device: 1.62 ms in a fresh process, but 12 % slower verifications in a process whose other
+//     high-priority streams (the verify scan streams) had pushed the second lane onto s_out's hardware queue
+//     the same with the wait moved to the HOST (ships): the calling thread, idle anyway, watches the chunks' kernel
+//     events in order and enqueues each D2H when its kernels are done -- s_out's queue holds no packet at all          1.58 ms
+//   What remains on the device: one event per chunk behind the H2D on s_in, which completes early (copies on s_in run in
+//   order and far ahead of the kernels), and the lanes' kernels.  Apart from the context's own stream the pipeline occupies
+//   no normal-priority queue: a library that parks streams there leaves the caller's streams to share what is left (two torch
+//   streams first used after a host-pointer call landed on ONE hardware queue and their launches ran one after the other).
+//   The verify scans of the pipeline's chunks run in line (on their priority streams they were no faster here: 19.0 vs 19.1 ms).
 // * The first chunk is small (2^15 items: the copy-out engine, which bounds a copy-bound call, starts 0.1 ms after the call)
 //   and the size doubles up to 2^18; a remainder below half a chunk is merged into the
 //   last chunk (a small last launch leaves the chip half empty).  BJJ_PIPE_FIRST_CHUNK / BJJ_PIPE_CHUNK (items) override.
@@ -486,6 +493,7 @@ static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ri
     c->pipe_budget = (size_t)1 << 30;
     if (const char* e = getenv("BJJ_PIPE_STAGING_MB")) { const long v = atol(e); if (v >= 1 && v <= 65536) c->pipe_budget = (size_t)v << 20; }
     if (const char* e = getenv("BJJ_HOST_FORCE_STAGED")) c->force_staged = e[0] == '1';
+    if (const char* e = getenv("BJJ_PIPE_SCAN")) c->pipe_scan_inline = e[0] != 'p';
   }
   try {
     while (c->ev_in.size() < chunks) {
@@ -594,16 +602,15 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
     pool->wait(&g_out[ch]);
     return BJJ_OK;
   };
-  // ... and, in the same developer mode, timing events around every stage (device-side timeline of the call, printed at its end;
-  // the extra event records behind copies sit in the high-priority pool)
-  std::vector<hipEvent_t> tev;
-  auto tmark = [&](hipStream_t st) {
+  // ... and, in the same developer mode, timing events behind every stage (device-side timeline of the call, printed at its end)
+  std::vector<hipEvent_t> tev(1 + 3 * nchunks, nullptr);
+  auto tmark = [&](size_t slot, hipStream_t st) {
     if (!trace) return;
-    hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) == hipSuccess) { hipEventRecord(e, st); tev.push_back(e); }
+    if (hipEventCreate(&tev[slot]) == hipSuccess) hipEventRecord(tev[slot], st);
   };
-  tmark(c->s_in);   // t = 0
-  auto enqueue = [&](size_t ch) -> int {
+  tmark(0, c->s_in);   // t = 0
+  // H2D of chunk ch on s_in, its kernels on lane ch % 2 behind the copy's event, ev_k[ch] behind the kernels
+  auto enqueue_front = [&](size_t ch) -> int {
     const int b = (int)(ch % BJJ_PIPE_BUFS);
     const size_t lo = lo_of[ch], cnt = cnt_of(ch);
     tr("enqueue begin", ch);
@@ -611,7 +618,7 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
       HIPCK(hipMemcpyAsync(c->dstage + d_in_off[i] + lo * sp.in_stride[i], in_direct[i] ? sp.in[i] + lo * sp.in_stride[i] : c->pin_in[b] + r_in_off[i],
                            cnt * sp.in_stride[i], hipMemcpyHostToDevice, c->s_in));
     HIPCK(hipEventRecord(c->ev_in[ch], c->s_in));
-    tmark(c->s_in);                                            // [1 + 4 ch]: H2D done
+    tmark(1 + 3 * ch, c->s_in);                                // H2D done
     hipStream_t lane = (ch & 1) ? c->stream2 : c->stream;
     HIPCK(hipStreamWaitEvent(lane, c->ev_in[ch], 0));
     void* d_in[4]; void* d_out[4];
@@ -619,53 +626,72 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
     for (int i = 0; i < sp.n_out; i++) d_out[i] = c->dstage + d_out_off[i] + lo * sp.out_stride[i];
     int r = launch(d_in, d_out, cnt, (void*)lane); if (r) return r;
     HIPCK(hipEventRecord(c->ev_k[ch], lane));                  // behind a kernel: its completion signal, no extra packet
-    tmark(lane);                                               // [2 + 4 ch]: kernels done
+    tmark(2 + 3 * ch, lane);                                   // kernels done
     tr("kernels enqueued", ch);
-    if (out_ring && ch >= BJJ_PIPE_BUFS) { r = finish_out(ch - BJJ_PIPE_BUFS); if (r) return r; }   // frees pin_out[b]
-    hipStream_t so = c->s_out;   // (copy-outs alternating over two streams were measured: 1.61-1.63 ms against 1.62-1.64, not worth a hardware queue)
-    HIPCK(hipStreamWaitEvent(so, c->ev_k[ch], 0));
-    tmark(so);                                                 // [3 + 4 ch]: D2H may begin
+    return BJJ_OK;
+  };
+  // D2H of chunk ch, enqueued by the HOST once it has seen the chunk's kernels complete: the copy carries no device-side wait,
+  // so s_out's hardware queue never holds a packet that another stream's kernel could get stuck behind
+  auto enqueue_out = [&](size_t ch) -> int {
+    const int b = (int)(ch % BJJ_PIPE_BUFS);
+    const size_t lo = lo_of[ch], cnt = cnt_of(ch);
+    if (out_ring && ch >= BJJ_PIPE_BUFS) { int r = finish_out(ch - BJJ_PIPE_BUFS); if (r) return r; }   // frees pin_out[b]
     for (int i = 0; i < sp.n_out; i++)
       HIPCK(hipMemcpyAsync(out_direct[i] ? sp.out[i] + lo * sp.out_stride[i] : c->pin_out[b] + r_out_off[i], c->dstage + d_out_off[i] + lo * sp.out_stride[i],
-                           cnt * sp.out_stride[i], hipMemcpyDeviceToHost, so));
-    if (out_ring) HIPCK(hipEventRecord(c->ev_out[ch], so));    // only the staged path needs to know when ONE chunk has arrived
-    tmark(so);                                                 // [4 + 4 ch]: D2H done
+                           cnt * sp.out_stride[i], hipMemcpyDeviceToHost, c->s_out));
+    if (out_ring) HIPCK(hipEventRecord(c->ev_out[ch], c->s_out));   // only the staged path needs to know when ONE chunk has arrived
+    tmark(3 + 3 * ch, c->s_out);                               // D2H done
     tr("D2H enqueued", ch);
     return BJJ_OK;
   };
-  size_t enqueued = 0;
-  auto body = [&]() -> int {
-    size_t next_in = 0;           // next chunk whose pageable inputs are handed to the workers (one chunk ahead of the enqueue)
-    for (size_t ch = 0; ch < nchunks; ch++) {
-      while (next_in < nchunks && next_in <= ch + 1) { int r = submit_in(next_in); if (r) return r; next_in++; }
-      if (in_ring) pool->wait(&g_in[ch]);
-      { int r = enqueue(ch); if (r) return r; }
-      enqueued = ch + 1;
-      while (out_ring && harvested < enqueued) {   // results that have already arrived: start their copy-out, do not wait
+  size_t outs = 0;                // chunks whose D2H has been enqueued (in order)
+  auto drain_kernels = [&](bool block, size_t upto) -> int {   // D2H for the chunks < upto whose kernels have completed; block: wait for them
+    while (outs < upto) {
+      if (block) HIPCK(hipEventSynchronize(c->ev_k[outs]));
+      else {
+        const hipError_t q = hipEventQuery(c->ev_k[outs]);
+        (void)hipGetLastError();
+        if (q != hipSuccess) break;
+      }
+      { int r = enqueue_out(outs); if (r) return r; }
+      outs++;
+      while (out_ring && harvested < outs) {   // results that have already arrived: start their copy-out, do not wait
         const int r = harvest(harvested, false);
         if (r == 1) break;
         if (r) return r;
         harvested++;
       }
     }
+    return BJJ_OK;
+  };
+  size_t fronts = 0;              // chunks whose H2D + kernels have been enqueued
+  auto body = [&]() -> int {
+    size_t next_in = 0;           // next chunk whose pageable inputs are handed to the workers (one chunk ahead of the enqueue)
+    for (size_t ch = 0; ch < nchunks; ch++) {
+      while (next_in < nchunks && next_in <= ch + 1) { int r = submit_in(next_in); if (r) return r; next_in++; }
+      if (in_ring) pool->wait(&g_in[ch]);
+      { int r = enqueue_front(ch); if (r) return r; }
+      fronts = ch + 1;
+      { int r = drain_kernels(false, fronts); if (r) return r; }   // only chunks that are enqueued can be drained
+    }
+    { int r = drain_kernels(true, nchunks); if (r) return r; }
     if (out_ring) for (size_t ch = harvested; ch < nchunks; ch++) { int r = finish_out(ch); if (r) return r; }
     if (out_ring) for (size_t ch = 0; ch < nchunks; ch++) pool->wait(&g_out[ch]);
-    HIPCK(hipStreamSynchronize(c->s_out));      // behind every chunk's kernels
+    HIPCK(hipStreamSynchronize(c->s_out));
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipStreamSynchronize(c->stream2));
     return BJJ_OK;
   };
   int rc = body();
   tr("all chunks finished", nchunks);
-  if (trace && tev.size() == 1 + 4 * nchunks) {
+  if (trace && !rc) {
     for (size_t ch = 0; ch < nchunks; ch++) {
-      float t[4] = {0, 0, 0, 0};
-      for (int k = 0; k < 4; k++) hipEventElapsedTime(&t[k], tev[0], tev[1 + 4 * ch + k]);
-      fprintf(stderr, "[pipe-dev] chunk %zu (%7zu items)  H2D done %7.1f us  kernels done %7.1f us  D2H %7.1f .. %7.1f us\n", ch, cnt_of(ch), t[0] * 1e3, t[1] * 1e3,
-              t[2] * 1e3, t[3] * 1e3);
+      float t[3] = {0, 0, 0};
+      for (int k = 0; k < 3; k++) if (tev[0] && tev[1 + 3 * ch + k]) hipEventElapsedTime(&t[k], tev[0], tev[1 + 3 * ch + k]);
+      fprintf(stderr, "[pipe-dev] chunk %zu (%7zu items)  H2D done %7.1f us  kernels done %7.1f us  D2H done %7.1f us\n", ch, cnt_of(ch), t[0] * 1e3, t[1] * 1e3, t[2] * 1e3);
     }
   }
-  for (hipEvent_t e : tev) hipEventDestroy(e);
+  for (hipEvent_t e : tev) if (e) hipEventDestroy(e);
   if (rc) {   // error path: nothing may still be writing into the caller's memory or reading the rings when we return
     hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->s_out);
     (void)hipGetLastError();
@@ -1103,7 +1129,7 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
   // inside the host-pointer pipeline the scan stays in line: its lanes, copy streams and the scan streams would be five
   // co-active high-priority streams on four hardware queues, and a scan that lands behind the copy-out stream's wait for the
   // previous chunk's kernels would serialise the lanes
-  if (busy && !c->in_pipeline) {   // the chip is (about to be) full of another launch's workgroups: priority stream
+  if (busy && !(c->in_pipeline && c->pipe_scan_inline)) {   // the chip is (about to be) full of another launch's workgroups: priority stream
     HIPCK(hipEventRecord(S->ev_scan_in, st));
     HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));
     LAUNCHCK(bjjk::verify_scan(S->scan_stream, scan_grid, pk, r, msg, n, S->slow), "verify scan");

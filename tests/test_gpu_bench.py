@@ -94,6 +94,24 @@ def test_bench_one_gpu_line_has_every_block():
     assert j["roofline"]["traffic"] is None          # 2^16-item batch / 16-bit table: the committed counters describe another configuration
     h = j["also"]["host_api"]
     assert h["parity_sample_ok"] and h["fixed_base"]["value"] > 0 and h["verify"]["value"] > 0 and "never" in h["note"]
+    # round 5: the kernel that makes `value` is named and has its own roofline block next to the one-stream one; the host-pointer
+    # rows are measured on pinned caller memory (copied directly) and on pageable memory (staged by the copy workers)
+    assert j["config"]["streams"] == 2 and j["config"]["kernel"] == "bjj_k_mul_fixed_base_2x256" == j["kernel"]
+    assert j["roofline"]["kernel"] == "bjj_k_mul_fixed_base" == j["single_stream"]["kernel"]
+    ro = j["roofline_overlapped"]
+    assert ro["kernel"] == "bjj_k_mul_fixed_base_2x256" and ro["streams"] == 2 and ro["frac"] > 0
+    assert abs(ro["span_ms_per_launch"] - j["device_ms_per_launch"]) < 1e-9
+    # one overlapped launch takes longer than the span per launch (two are co-resident); the separate per-launch pass agrees with the timed region
+    assert ro["kernel_ms_avg"] > 0.8 * ro["span_ms_per_launch"] and 0.5 < ro["per_launch_pass"]["span_ms_per_launch"] / ro["span_ms_per_launch"] < 2.0
+    assert j["also"]["var_base"]["roofline_overlapped"]["kernel"] == "bjj_k_mul_var_base" and j["also"]["var_base"]["roofline"]["kernel"] == "bjj_k_mul_var_base_tiles"
+    assert j["also"]["verify"]["roofline_overlapped"]["kernel"] == "bjj_k_eddsa_verify_groups"
+    assert (h["fixed_base"]["arrays_direct"], h["fixed_base"]["arrays_staged"]) == (2, 0) and (h["verify"]["arrays_direct"], h["verify"]["arrays_staged"]) == (5, 0)
+    hp = h["pageable"]
+    assert (hp["fixed_base"]["arrays_direct"], hp["fixed_base"]["arrays_staged"]) == (0, 2) and hp["verify"]["arrays_staged"] == 5 and h["copy_threads"] >= 1
+    w23 = j["also"]["fixed_base_window_bits_23"]
+    assert w23["kernel"] == "bjj_k_mul_fixed_base" and w23["streams"] == 1 and "clock_mhz" in w23 and w23["init_ms"] > 0
+    if j["clock"].get("available"):
+        assert j["clock"]["poll_period_ms"] >= 1.0 and j["clock"]["polled_during_timed_region"] is True
 
 
 def test_bench_point_add_and_compress_workloads():

@@ -165,6 +165,64 @@ c.close()
     assert (got == oracle.mul_fixed_base(w.scalars_254(10000, offset=9))).all()
 
 
+def _schedule(n, first, cap_chunk):
+    """the chunk schedule of run_super_batch (bjj_hip.hip): first, doubling up to the cap, a remainder below half a chunk joins the last one"""
+    out, lo, sz = [], 0, first
+    while lo < n:
+        take = min(sz, n - lo)
+        if n - lo - take < sz // 2:
+            take = n - lo
+        out.append(take)
+        lo += take
+        if sz < cap_chunk:
+            sz = min(sz * 2, cap_chunk)
+    return out
+
+
+def test_super_batches_when_the_device_staging_budget_is_small(oracle):
+    """BJJ_PIPE_STAGING_MB=1: 50 000 fixed-base items (96 B each) no longer fit into the device staging at once and run as five
+    consecutive super-batches of 10 240 items; pinned and pageable callers, every byte against the oracle."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import ROOT
+    from babyjubjub_rs_amd import workload as w
+    n = 50000
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import babyjubjub_rs_amd as bjj
+from babyjubjub_rs_amd import workload as w
+c = bjj.Context(0, 16)
+n = %d
+sc = np.ascontiguousarray(w.scalars_254(n, offset=11)).reshape(-1)
+p_in, p_out = c.host_empty(n * 32), c.host_empty(n * 64)
+p_in[:] = sc
+c._ck(c.lib.bjj_mul_fixed_base(c.handle, p_in.ctypes.data, n, p_out.ctypes.data), "fb")
+i = c.info()
+print("INFO", i.last_host_direct_arrays, i.last_host_staged_arrays, i.last_host_chunks)
+out2 = np.zeros(n * 64, np.uint8)
+c._ck(c.lib.bjj_mul_fixed_base(c.handle, sc.ctypes.data, n, out2.ctypes.data), "fb")
+i = c.info()
+print("INFO", i.last_host_direct_arrays, i.last_host_staged_arrays, i.last_host_chunks)
+assert (np.asarray(p_out) == out2).all()
+np.save(sys.argv[1], out2)
+c.close()
+''' % (ROOT, n)
+    with tempfile.TemporaryDirectory() as td:
+        outp = os.path.join(td, "out.npy")
+        env = dict(os.environ, BJJ_PIPE_STAGING_MB="1", BJJ_PIPE_CHUNK="2048", BJJ_PIPE_FIRST_CHUNK="1024")
+        r = subprocess.run([sys.executable, "-c", code, outp], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout
+        cap = (1 << 20) // 96 // 2048 * 2048                      # items per super-batch: 10 240
+        want = sum(len(_schedule(min(cap, n - lo), 1024, 2048)) for lo in range(0, n, cap))
+        infos = [[int(x) for x in l.split()[1:]] for l in r.stdout.splitlines() if l.startswith("INFO")]
+        assert infos == [[2, 0, want], [0, 2, want]] and want > 20, (infos, want)
+        got = np.load(outp).reshape(n, 64)
+    assert (got == oracle.mul_fixed_base(w.scalars_254(n, offset=11))).all()
+
+
 def test_kernel_form_follows_pattern_and_state(oracle):
     """expect_overlap (bjj_hip.hip): launches that alternate over two streams WITHOUT a synchronisation between them get the
     forms for overlapping launches (K1: two 256-lane workgroups per CU, K2: grid-strided); the same alternation WITH a
