@@ -83,7 +83,7 @@
  * HIP runtime knows as pinned (hipHostMalloc, hipHostRegister, torch's pin_memory) -- are copied from / to directly; pageable
  * arrays are staged through pinned buffers by worker threads of the context (BJJ_STAGE_THREADS, default 4).  The choice is per
  * array and per call; results are identical.  2^20 fixed-base multiplications: about 1.6 ms pinned (the 64 MB of results
- * crossing PCIe take 1.19 ms), about 2.1 ms pageable, 0.6 ms on device pointers.
+ * crossing PCIe take 1.19 ms), 2.0 to 2.6 ms pageable, 0.6 ms on device pointers.
  * *_dev entry points take DEVICE pointers (16-byte aligned) plus a hipStream_t
  * (passed as void*; NULL = the context's stream), enqueue the work and return
  * without synchronising -- they are what bench.py times.
