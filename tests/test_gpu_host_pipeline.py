@@ -165,6 +165,93 @@ c.close()
     assert (got == oracle.mul_fixed_base(w.scalars_254(10000, offset=9))).all()
 
 
+def test_every_host_entry_point_on_pinned_memory_equals_the_staged_path(ctx16, oracle):
+    """The 16 host-pointer batch entry points with EVERY array in pinned memory (several inputs, up to three outputs, key material that
+    is wiped behind the call) against the same call on pageable memory, 140 001 items = three chunks over both lanes; the
+    staged results of the multiplications, the hash, the signer and the verifier are checked against the oracle on a sample."""
+    import ctypes as C
+    from babyjubjub_rs_amd import workload as w
+    n = 140001
+    assert _schedule(n, 1 << 15, 1 << 18) == [32768, 65536, 41697]
+    rng = np.random.default_rng(0x70696e)
+    keys = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msgs[:, 31] &= 0x1f
+    msgs[::97, 31] = 0xff                                        # a few msg > Q: Err rows
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    nonces = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+    wide = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    h5 = rng.integers(0, 256, (n, 160), dtype=np.uint8)
+    pk = ctx16.public_keys(keys)
+    pts = pk.copy()
+    pts[::53, 7] ^= 4                                            # some off-curve points (exact path)
+    proj = np.concatenate([pts, rng.integers(0, 256, (n, 32), dtype=np.uint8)], axis=1)
+    proj[::101, 64:] = 0                                         # z == 0
+    r, s, okf = ctx16.sign(keys, msgs)
+    comp = ctx16.compress_points(pk)
+    comp[::71, 3] ^= 1                                           # some that do not decompress
+    sig = np.concatenate([ctx16.compress_points(r), s], axis=1)
+    lib, hnd = ctx16.lib, ctx16.handle
+    calls = [   # (function, inputs [(array, row bytes)], scalar args before n, output row bytes)
+        ("bjj_mul_fixed_base", [(sc, 32)], [], [64]),
+        ("bjj_mul_var_base", [(pts, 64), (sc, 32)], [], [64]),
+        ("bjj_mul_var_base_wide", [(pts, 64), (wide, 64)], [64], [64]),
+        ("bjj_poseidon5", [(h5, 160)], [], [32]),
+        ("bjj_eddsa_verify", [(pk, 64), (r, 64), (s, 32), (msgs, 32)], [], [1]),
+        ("bjj_schnorr_verify", [(pk, 64), (r, 64), (s, 32), (msgs, 32)], [], [1]),
+        ("bjj_point_add", [(pts, 64), (pk, 64)], [], [64]),
+        ("bjj_proj_add", [(proj, 96), (proj[::-1].copy(), 96)], [], [96]),
+        ("bjj_proj_affine", [(proj, 96)], [], [64]),
+        ("bjj_compress_points", [(pk, 64)], [], [32]),
+        ("bjj_decompress_points", [(comp, 32)], [], [64, 1]),
+        ("bjj_eddsa_verify_compressed", [(comp, 32), (sig, 64), (msgs, 32)], [], [1]),
+        ("bjj_scalar_keys", [(keys, 32)], [], [32]),
+        ("bjj_public_keys", [(keys, 32)], [], [64]),
+        ("bjj_sign", [(keys, 32), (msgs, 32)], [], [64, 32, 1]),
+        ("bjj_sign_schnorr", [(keys, 32), (msgs, 32), (nonces, 128)], [], [64, 160, 1]),
+    ]
+    results = {}
+    for name, ins, extra, outs in calls:
+        got = {}
+        for mem in ("pageable", "pinned"):
+            alloc = ctx16.host_empty if mem == "pinned" else (lambda nb: np.zeros(nb, np.uint8))
+            a_in = []
+            for arr, wdt in ins:
+                b = alloc(n * wdt)
+                b[:] = np.ascontiguousarray(arr).reshape(-1)
+                a_in.append(b)
+            a_out = [alloc(n * wdt) for wdt in outs]
+            for b in a_out:
+                b[:] = 0xAB
+            args = [hnd] + [b.ctypes.data for b in a_in]
+            if name == "bjj_mul_var_base_wide":
+                args += [C.c_size_t(64)]
+            args += [C.c_size_t(n)] + [b.ctypes.data for b in a_out]
+            rc = getattr(lib, name)(*args)
+            assert rc == 0, (name, mem, lib.bjj_last_error())
+            i = ctx16.info()
+            want = (len(ins) + len(outs), 0) if mem == "pinned" else (0, len(ins) + len(outs))
+            assert (i.last_host_direct_arrays, i.last_host_staged_arrays) == want and i.last_host_chunks == 3, (name, mem)
+            got[mem] = [np.asarray(b).copy() for b in a_out]
+            if mem == "pinned":
+                for b in a_in + a_out:
+                    ctx16.host_free(b)
+        for x, y in zip(got["pageable"], got["pinned"]):
+            assert (x == y).all(), name
+        results[name] = got["pageable"]
+    idx = np.unique(np.concatenate([np.arange(0, n, 499), [32767, 32768, 98303, 98304, n - 1]]))   # incl. both chunk seams
+    assert (results["bjj_mul_fixed_base"][0].reshape(n, 64)[idx] == oracle.mul_fixed_base(sc[idx])).all()
+    assert (results["bjj_mul_var_base"][0].reshape(n, 64)[idx] == oracle.mul_var_base(pts[idx], sc[idx])).all()
+    assert (results["bjj_poseidon5"][0].reshape(n, 32)[idx] == oracle.poseidon5(h5[idx])).all()
+    assert (results["bjj_eddsa_verify"][0][idx] == oracle.verify(pk[idx], r[idx], s[idx], msgs[idx])).all()
+    assert (results["bjj_public_keys"][0].reshape(n, 64)[idx] == oracle.public_keys(keys[idx])).all()
+    ro, so, oko = oracle.sign(keys[idx], msgs[idx])
+    rs = results["bjj_sign"]
+    assert (rs[0].reshape(n, 64)[idx] == ro).all() and (rs[1].reshape(n, 32)[idx] == so).all() and (rs[2][idx] == oko).all()
+    dp, dok = oracle.decompress(comp[idx])
+    assert (results["bjj_decompress_points"][0].reshape(n, 64)[idx] == dp).all() and (results["bjj_decompress_points"][1][idx] == dok).all()
+
+
 def _schedule(n, first, cap_chunk):
     """the chunk schedule of run_super_batch (bjj_hip.hip): first, doubling up to the cap, a remainder below half a chunk joins the last one"""
     out, lo, sz = [], 0, first
