@@ -1158,7 +1158,8 @@ def optional_sections(args, hl, ctx, bjj, kind, n, rank, local_rank, world, dev,
             c23.close()
 
         # PCIe-inclusive rates of the host-pointer API -- what a host holding its data in ordinary (pageable) memory gets from
-        # bjj_mul_fixed_base / bjj_eddsa_verify: chunked pinned-staging pipeline around the same kernels.  NEVER `value`.
+        # bjj_mul_fixed_base / bjj_eddsa_verify: the chunked host-pointer pipeline around the same kernels (pinned memory copied directly,
+        # pageable memory staged by copy workers).  NEVER `value`.
         if one_gpu and rank == 0:
             also["host_api"] = host_api_block(ctx, n, orc)
             parity = parity and also["host_api"]["parity_sample_ok"]
