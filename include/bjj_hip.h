@@ -294,7 +294,7 @@ int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
  * the contiguous block [i*ceil(n/G), min(n, (i+1)*ceil(n/G))) -- bjj_shard_bounds.  One process,
  * all devices: this is the form a Rust host calls.
  *   host-pointer form    arrays in host memory; one host thread per device drives that device's
- *                        pinned-staging pipeline over its block.  No inter-GPU traffic.
+ *                        host-pointer pipeline over its block (pinned arrays copied directly).  No inter-GPU traffic.
  *   *_multi_dev form     arrays resident in the HBM of the handle's FIRST device (rank 0 holds all
  *                        inputs, as in BASELINE cfg 5).  Transfers over xGMI and kernels are pipelined:
  *                        the root's block is processed in place from t = 0 while its sends run on a
