@@ -676,6 +676,20 @@ def roofline_overlapped_block(kind, span_ms, detail, n, info, kernel):
     if detail:
         out["kernel_ms_avg"] = detail["kernel_ms_avg"]
         out["per_launch_pass"] = detail
+    # VALU utilisation of the overlap-form kernel from its own PMC pass (counters of one dispatch; the profiler serialises
+    # dispatches) and its own static instruction mix -- the same two figures `valu` gives for the one-stream kernel
+    mixj = load_profile_json("isa_mix.json")
+    mix = mixj.get(kernel or "", {})
+    if quote and mix and tr.get("valu_insts_per_launch") and tr.get("sq_busy_cycles") and profile_is_current(mixj.get("_source_hash")):
+        cyc = mix["avg_issue_cycles_per_valu_inst"]
+        ipc = tr["valu_insts_per_launch"] / 1024.0 / (tr["sq_busy_cycles"] / 32.0)
+        peak = 1024 * 2.4 / cyc
+        va = tr["valu_insts_per_launch"] / (span_ms * 1e-3) / 1e9
+        out["valu"] = {"insts_per_launch": tr["valu_insts_per_launch"], "achieved": va, "peak": peak, "frac": va / peak,
+                       "unit": "G wave-instructions/s", "avg_issue_cycles_per_inst": cyc,
+                       "counter_derived": {"valu_insts_per_simd_per_busy_cycle": ipc, "frac": ipc * cyc,
+                                           "note": "counters of ONE dispatch of the overlap form running alone (PMC pass)"},
+                       "note": "achieved = instructions per launch / (span of the K timed launches / K): two co-resident launches share the SIMDs"}
     if stale:
         out["stale_profile"] = True
     return out
