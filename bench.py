@@ -648,10 +648,11 @@ def roofline_block(kind, kernel_ms, n, info, kernel=None):
 
 def kernel_that_ran(kind, info, overlapped):
     """the kernel symbol the context's LAST launch of this workload used (bjj_get_info: last_* fields)"""
+    dec = lambda b, alt: b.decode() if b else alt   # noqa: E731  (an older A/B build fills fewer fields of bjj_info)
     if kind == "fixed_base":
-        return (info.kernel_fixed_base_overlap if info.last_fixed_base_shape == 1 else info.kernel_fixed_base).decode()
+        return dec(info.kernel_fixed_base_overlap, "bjj_k_mul_fixed_base_2x256") if info.last_fixed_base_shape == 1 else dec(info.kernel_fixed_base, KERNEL[kind])
     if kind == "var_base":
-        return (info.kernel_var_base_overlap if info.last_var_base_form == 0 else info.kernel_var_base).decode()
+        return dec(info.kernel_var_base_overlap, "bjj_k_mul_var_base") if info.last_var_base_form == 0 else dec(info.kernel_var_base, KERNEL[kind])
     if kind in ("verify", "verify_compressed"):
         return "bjj_k_eddsa_verify" if info.last_verify_dispatch == 0 else "bjj_k_eddsa_verify_groups"
     return KERNEL[kind]
