@@ -137,12 +137,37 @@ inline const Point& B8() {  // lib.rs:37-46
   return p;
 }
 
+// ---- page-locked storage for the batch forms ---------------------------------------------
+// A std::vector whose memory comes from bjj_host_alloc: the host-pointer entry points copy such arrays straight over PCIe
+// instead of staging them (include/bjj_hip.h, "pinned host memory").  Marshal records into a PinnedVector once and reuse it:
+// page-locking costs ~60 us per MB.  The memory belongs to the process (any Context may use it).
+template <class T>
+struct PinnedAllocator {
+  using value_type = T;
+  PinnedAllocator() = default;
+  template <class U> PinnedAllocator(const PinnedAllocator<U>&) {}
+  T* allocate(size_t n) {
+    void* p = nullptr;
+    check(bjj_host_alloc(Context::global().handle(), n * sizeof(T), &p), "bjj_host_alloc");
+    return (T*)p;
+  }
+  void deallocate(T* p, size_t) noexcept { bjj_host_free(Context::global().handle(), p); }
+  template <class U> bool operator==(const PinnedAllocator<U>&) const { return true; }
+  template <class U> bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+template <class T> using PinnedVector = std::vector<T, PinnedAllocator<T>>;
+
 // ---- batch forms --------------------------------------------------------------------
+// (each has a PinnedVector overload below: same call, arrays copied directly)
 inline std::vector<Point> mul_fixed_base_batch(const std::vector<U256>& n, Context& c = Context::global()) {
   std::vector<Point> out(n.size());
   static_assert(sizeof(U256) == 32 && sizeof(Point) == 64, "records must be tightly packed");
   check(bjj_mul_fixed_base(c.handle(), (const uint8_t*)n.data(), n.size(), (uint8_t*)out.data()), "bjj_mul_fixed_base");
   return out;
+}
+inline void mul_fixed_base_batch(const PinnedVector<U256>& n, PinnedVector<Point>& out, Context& c = Context::global()) {
+  out.resize(n.size());
+  check(bjj_mul_fixed_base(c.handle(), (const uint8_t*)n.data(), n.size(), (uint8_t*)out.data()), "bjj_mul_fixed_base");
 }
 inline std::vector<Point> mul_scalar_batch(const std::vector<Point>& p, const std::vector<U256>& n,
                                            Context& c = Context::global()) {
@@ -167,6 +192,15 @@ inline std::vector<uint8_t> verify_batch(const std::vector<Point>& pk, const std
   check(bjj_eddsa_verify(c.handle(), (const uint8_t*)pk.data(), (const uint8_t*)r.data(), (const uint8_t*)s.data(),
                          (const uint8_t*)msg.data(), n, ok.data()), "bjj_eddsa_verify");
   return ok;
+}
+// the same on page-locked arrays (R and s of the signatures as arrays of their own: no re-packing, no staging)
+inline void verify_batch(const PinnedVector<Point>& pk, const PinnedVector<Point>& r_b8, const PinnedVector<U256>& s,
+                         const PinnedVector<U256>& msg, PinnedVector<uint8_t>& ok, Context& c = Context::global()) {
+  const size_t n = pk.size();
+  if (r_b8.size() != n || s.size() != n || msg.size() != n) throw std::runtime_error("verify_batch: length mismatch");
+  ok.resize(n);
+  check(bjj_eddsa_verify(c.handle(), (const uint8_t*)pk.data(), (const uint8_t*)r_b8.data(), (const uint8_t*)s.data(),
+                         (const uint8_t*)msg.data(), n, ok.data()), "bjj_eddsa_verify");
 }
 
 // wire format, batch: ok[i] == 0 where decompress_point returns Err

@@ -243,8 +243,9 @@ static int wait_for_other_sets(bjj_ctx* c, const ScratchSet* mine, hipStream_t s
 }
 // Will this launch share the chip with another launch of the context?  The kernels come in a form for a launch that runs alone
 // and a form for overlapping launches (K1: one 512-lane workgroup per CU / two of 256 lanes; K2: tiles / grid-strided; verify:
-// scan in line / on the priority stream), and the wrong form costs: K1's two-workgroup shape run ALONE takes 0.86 ms instead of
-// 0.61 ms (profiles/r05_fixed_base_two_stream_summary.md).  Pattern AND state decide:
+// scan in line / on the priority stream), and the wrong form costs: K1's two-workgroup shape run ALONE takes 0.611-0.623 ms instead
+// of 0.602-0.605 ms (+1.5 ... 3 %), K2's grid-strided form alone 14.63 instead of 14.13 ms (+3.5 %; profiles/r05_driver_protocol.txt,
+// r05_host_pipeline.txt).  Pattern AND state decide:
 //   * another set's launch is still queued or running (event query)          -> overlap
 //   * else the caller alternates over streams (streams_alternate) and this is the FIRST such call that finds the other set
 //     idle -- the first launch behind a synchronisation point of a caller that ping-pongs, e.g. launch 0 of a timed region:

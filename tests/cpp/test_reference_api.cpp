@@ -132,9 +132,40 @@ static void test_multi() {  // the single-process multi-GPU handle (bjj_multi_*)
   std::vector<Point> a = m.mul_fixed_base_batch(n), b = mul_fixed_base_batch(n);
   for (size_t i = 0; i < n.size(); i++) ASSERT_TRUE(a[i].equals(b[i]));
 }
+static void test_batch_pinned() {  // the batch forms on page-locked vectors: copied directly, same bytes as the staged path
+  const size_t n = 70001;
+  PinnedVector<U256> sc(n);
+  for (size_t i = 0; i < n; i++) { U256 v(i * 2654435761ull + 17); v.le[20] = (uint8_t)(i >> 3); v.le[31] = (uint8_t)(i & 0x1f); sc[i] = v; }
+  PinnedVector<Point> out;
+  mul_fixed_base_batch(sc, out);
+  bjj_info info; info.struct_size = sizeof(info);
+  ASSERT_EQ(bjj_get_info(Context::global().handle(), &info), 0);
+  ASSERT_EQ(info.last_host_direct_arrays, 2u);
+  ASSERT_EQ(info.last_host_staged_arrays, 0u);
+  std::vector<U256> sc2(sc.begin(), sc.end());
+  std::vector<Point> want = mul_fixed_base_batch(sc2);
+  ASSERT_EQ(bjj_get_info(Context::global().handle(), &info), 0);
+  ASSERT_EQ(info.last_host_staged_arrays, 2u);
+  size_t bad = 0;
+  for (size_t i = 0; i < n; i++) if (!(out[i].x == want[i].x) || !(out[i].y == want[i].y)) bad++;
+  ASSERT_EQ(bad, (size_t)0);
+  // verify on pinned arrays: the points above as public keys AND as R, the scalars as s and msg -- verdicts only have to agree
+  PinnedVector<U256> msg(sc.begin(), sc.end());
+  PinnedVector<uint8_t> ok;
+  verify_batch(out, out, sc, msg, ok);
+  ASSERT_EQ(bjj_get_info(Context::global().handle(), &info), 0);
+  ASSERT_EQ(info.last_host_direct_arrays, 5u);
+  std::vector<Signature> sigs(n);
+  for (size_t i = 0; i < n; i++) { sigs[i].r_b8 = want[i]; sigs[i].s = sc2[i]; }
+  std::vector<uint8_t> ok2 = verify_batch(want, sigs, sc2);
+  bad = 0;
+  for (size_t i = 0; i < n; i++) if (ok[i] != ok2[i]) bad++;
+  ASSERT_EQ(bad, (size_t)0);
+}
+
 int main() {
   try {
-    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_point_compress_decompress(); test_schnorr_signature(); test_batch(); test_multi();
+    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_point_compress_decompress(); test_schnorr_signature(); test_batch(); test_batch_pinned(); test_multi();
   } catch (const std::exception& e) { printf("EXCEPTION %s\n", e.what()); return 2; }
   printf(failures ? "FAILED %d\n" : "ok (reference tests re-stated in C++)\n", failures);
   return failures ? 1 : 0;
