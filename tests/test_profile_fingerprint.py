@@ -16,20 +16,55 @@ class _Info:
     window_bits = 28
 
 
-def test_one_flipped_byte_of_a_kernel_source_changes_the_fingerprint(tmp_path):
+def _copy_csrc(tmp_path):
+    import glob
     dst = tmp_path / "csrc"
     dst.mkdir()
     for pat in srchash.PATTERNS:
-        import glob
         for f in glob.glob(os.path.join(srchash.CSRC, pat)):
             shutil.copy(f, dst)
+    return dst
+
+
+def test_one_changed_token_of_a_kernel_source_or_one_flag_changes_the_fingerprint(tmp_path):
+    dst = _copy_csrc(tmp_path)
     h0 = srchash.tree_hash(str(dst))
     assert h0 == srchash.tree_hash()                       # same files, same fingerprint
     p = dst / "k_fixed.hip"
-    b = bytearray(p.read_bytes())
-    b[len(b) // 2] ^= 1
-    p.write_bytes(bytes(b))
+    src = p.read_text()
+    code = srchash.strip_comments(src)
+    # one character of CODE: the first identifier character of the last non-comment line that also occurs verbatim in the file
+    line = [l for l in code.split("\n") if l.strip() and src.count(l) == 1][-1]
+    at = src.index(line) + (len(line) - len(line.lstrip()))
+    p.write_text(src[:at] + ("X" if src[at] != "X" else "Y") + src[at + 1:])
     assert srchash.tree_hash(str(dst)) != h0
+    p.write_text(src)
+    assert srchash.tree_hash(str(dst)) == h0
+    # a string literal is code even when it looks like a comment
+    p.write_text(src + '\nstatic const char* bjj_note = "// not a comment";\n')
+    h1 = srchash.tree_hash(str(dst))
+    p.write_text(src + '\nstatic const char* bjj_note = "// not a comment!";\n')
+    assert len({h0, h1, srchash.tree_hash(str(dst))}) == 3
+    p.write_text(src)
+    # the Makefile is hashed as it is: its `#` lines are not C comments, and a flag is a different build
+    mk = dst / "Makefile"
+    mk.write_text(mk.read_text().replace("-O3", "-O2", 1))
+    assert srchash.tree_hash(str(dst)) != h0
+
+
+def test_a_comment_only_edit_keeps_the_fingerprint(tmp_path):
+    """the counters describe the code objects; a corrected sentence in a header comment is the same build"""
+    dst = _copy_csrc(tmp_path)
+    h0 = srchash.tree_hash(str(dst))
+    for name in ("k_fixed.hip", "bjj_device.hpp", "bjj_multi.inc"):
+        p = dst / name
+        src = p.read_text()
+        lines = src.split("\n")
+        k = len(lines) // 2
+        edited = lines[:k] + ["// a new remark", "/* and a block", "   over two lines */", ""] + lines[k:]
+        p.write_text("\n".join(edited) + "\n// trailing remark\n")
+        assert srchash.tree_hash(str(dst)) == h0, name
+    assert srchash.strip_comments('a = "/*"; b = \'"\'; /* x */ c = 1; // y\n\n  \nd;') == 'a = "/*"; b = \'"\';   c = 1;\nd;'
 
 
 def test_bench_does_not_quote_counters_of_another_build(monkeypatch):
