@@ -159,6 +159,9 @@ struct bjj_ctx {
   // (CopyPool), never by the enqueueing thread
   hipStream_t s_in = nullptr, s_out = nullptr, stream2 = nullptr;
   std::vector<hipEvent_t> ev_in, ev_k, ev_out;   // per chunk of a super-batch (grown on demand)
+  hipEvent_t ev_tail = nullptr;            // behind the extra stages of a call (PipeExtra: verify's batch-wide exact launch)
+  u32* pipe_wl = nullptr;                  // verify through the pipeline: ONE list of off-curve items per super-batch (VerifyPipe)
+  size_t pipe_wl_items = 0;
   uint8_t* dstage = nullptr;   // device staging for one super-batch: every array contiguous
   size_t pipe_bytes = 0;
   uint8_t* pin_in[BJJ_PIPE_BUFS] = {};     // pinned rings of the staged path (allocated on the first call that has a pageable array)
@@ -167,6 +170,7 @@ struct bjj_ctx {
   size_t pipe_budget = 0;                  // bytes of device staging a call may take (BJJ_PIPE_STAGING_MB)
   CopyPool* pool = nullptr;
   size_t pipe_chunk = 0, pipe_first = 0;   // chunk schedule (items): first chunk, doubling up to pipe_chunk
+  bool pipe_env_schedule = false;          // ... given in the environment: it overrides the entry points' own schedules too
   bool in_pipeline = false;                // a host-pointer call is enqueueing (enqueue_verify: where the scans run)
   bool pipe_scan_inline = true;            // BJJ_PIPE_SCAN=prio (developer): scans of the pipeline's chunks on the priority streams
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
@@ -422,6 +426,20 @@ struct PipeSpec {
   const uint8_t* in[4]; size_t in_stride[4];
   uint8_t* out[4];      size_t out_stride[4];
   bool secret;          // inputs are key material: wipe the staging buffers when the call is done
+  struct PipeExtra* extra = nullptr;   // stages beside the chunk launches (below)
+  bool out_at_end = false;             // outputs leave the device once, after everything (they are not final chunk by chunk)
+  size_t first_chunk = 0, max_chunk = 0;   // chunk schedule of this entry point (items; 0 = the context's, which the environment overrides)
+};
+// Work of a pipelined call that does not belong to ONE chunk.  All three run on the calling thread while it enqueues:
+//   begin          once per super-batch, before the first copy; d_in / d_out = the staging arrays of the whole super-batch
+//   chunk_arrived  behind the H2D of items lo .. lo+cnt-1 (ev_in of the chunk has been recorded: make a stream wait for it)
+//   all_arrived    behind the last chunk; whatever it enqueues is covered by ev_tail, which the call waits for before it copies
+//                  `out_at_end` outputs and returns
+struct PipeExtra {
+  virtual int begin(size_t n, void** d_in, void** d_out) = 0;
+  virtual int chunk_arrived(size_t lo, size_t cnt, hipEvent_t arrived) = 0;
+  virtual int all_arrived(hipEvent_t ev_tail) = 0;
+  virtual ~PipeExtra() {}
 };
 static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -488,6 +506,8 @@ static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ri
     // share what is left -- two torch streams first used after a host-pointer call landed on ONE hardware queue and their
     // launches ran one after the other (tools/queue_map_probe.py, profiles/r05_host_pipeline.txt)
     HIPCK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
+    HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    c->pipe_env_schedule = getenv("BJJ_PIPE_CHUNK") || getenv("BJJ_PIPE_FIRST_CHUNK");
     c->pipe_chunk = env_items("BJJ_PIPE_CHUNK", BJJ_PIPE_CHUNK);
     c->pipe_first = env_items("BJJ_PIPE_FIRST_CHUNK", BJJ_PIPE_FIRST_CHUNK);
     if (c->pipe_first > c->pipe_chunk) c->pipe_first = c->pipe_chunk;
@@ -543,13 +563,15 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
   // ---- chunk schedule: first, 2 first, 4 first ... capped at pipe_chunk; a remainder below half a chunk joins the last chunk
   std::vector<size_t> lo_of;     // lo_of[ch] .. lo_of[ch + 1]
   {
-    size_t lo = 0, sz = c->pipe_first;
+    const size_t sz_max = (sp.max_chunk && !c->pipe_env_schedule) ? sp.max_chunk : c->pipe_chunk;
+    size_t lo = 0, sz = (sp.first_chunk && !c->pipe_env_schedule) ? sp.first_chunk : c->pipe_first;
+    if (sz > sz_max) sz = sz_max;
     while (lo < n) {
       size_t take = sz < n - lo ? sz : n - lo;
       if (n - lo - take < sz / 2) take = n - lo;          // what would be left is small: take it along
       lo_of.push_back(lo);
       lo += take;
-      if (sz < c->pipe_chunk) sz = sz * 2 < c->pipe_chunk ? sz * 2 : c->pipe_chunk;
+      if (sz < sz_max) sz = sz * 2 < sz_max ? sz * 2 : sz_max;
     }
     lo_of.push_back(n);
   }
@@ -561,8 +583,16 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
   for (int i = 0; i < sp.n_in; i++) { d_in_off[i] = dev_tot; dev_tot += up256(n * sp.in_stride[i]); }
   for (int i = 0; i < sp.n_out; i++) { d_out_off[i] = dev_tot; dev_tot += up256(n * sp.out_stride[i]); }
   for (int i = 0; i < sp.n_in; i++) if (!in_direct[i]) { r_in_off[i] = in_ring; in_ring += up16(max_chunk * sp.in_stride[i]); }
-  for (int i = 0; i < sp.n_out; i++) if (!out_direct[i]) { r_out_off[i] = out_ring; out_ring += up16(max_chunk * sp.out_stride[i]); }
+  // outputs that leave at the end go through ONE ring slot that holds the whole array
+  for (int i = 0; i < sp.n_out; i++) if (!out_direct[i]) { r_out_off[i] = out_ring; out_ring += up16((sp.out_at_end ? n : max_chunk) * sp.out_stride[i]); }
   { int rc = ensure_pipe(c, nchunks, dev_tot, in_ring, out_ring); if (rc) return rc; }
+  const bool chunk_out_ring = out_ring && !sp.out_at_end;   // pageable outputs travel chunk by chunk through the ring
+  if (sp.extra) {
+    void* bi[4]; void* bo[4];
+    for (int i = 0; i < sp.n_in; i++) bi[i] = c->dstage + d_in_off[i];
+    for (int i = 0; i < sp.n_out; i++) bo[i] = c->dstage + d_out_off[i];
+    int rc = sp.extra->begin(n, bi, bo); if (rc) return rc;
+  }
   *chunks_out += (u32)nchunks;
   CopyPool* pool = c->pool;
   std::vector<CopyGroup> g_in(nchunks), g_out(nchunks);
@@ -620,6 +650,10 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
                            cnt * sp.in_stride[i], hipMemcpyHostToDevice, c->s_in));
     HIPCK(hipEventRecord(c->ev_in[ch], c->s_in));
     tmark(1 + 3 * ch, c->s_in);                                // H2D done
+    if (sp.extra) {
+      int r = sp.extra->chunk_arrived(lo, cnt, c->ev_in[ch]); if (r) return r;
+      if (ch + 1 == nchunks) { r = sp.extra->all_arrived(c->ev_tail); if (r) return r; }
+    }
     hipStream_t lane = (ch & 1) ? c->stream2 : c->stream;
     HIPCK(hipStreamWaitEvent(lane, c->ev_in[ch], 0));
     void* d_in[4]; void* d_out[4];
@@ -636,11 +670,12 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
   auto enqueue_out = [&](size_t ch) -> int {
     const int b = (int)(ch % BJJ_PIPE_BUFS);
     const size_t lo = lo_of[ch], cnt = cnt_of(ch);
-    if (out_ring && ch >= BJJ_PIPE_BUFS) { int r = finish_out(ch - BJJ_PIPE_BUFS); if (r) return r; }   // frees pin_out[b]
+    if (sp.out_at_end) { tr("kernels seen complete", ch); return BJJ_OK; }   // nothing leaves chunk by chunk
+    if (chunk_out_ring && ch >= BJJ_PIPE_BUFS) { int r = finish_out(ch - BJJ_PIPE_BUFS); if (r) return r; }   // frees pin_out[b]
     for (int i = 0; i < sp.n_out; i++)
       HIPCK(hipMemcpyAsync(out_direct[i] ? sp.out[i] + lo * sp.out_stride[i] : c->pin_out[b] + r_out_off[i], c->dstage + d_out_off[i] + lo * sp.out_stride[i],
                            cnt * sp.out_stride[i], hipMemcpyDeviceToHost, c->s_out));
-    if (out_ring) HIPCK(hipEventRecord(c->ev_out[ch], c->s_out));   // only the staged path needs to know when ONE chunk has arrived
+    if (chunk_out_ring) HIPCK(hipEventRecord(c->ev_out[ch], c->s_out));   // only the staged path needs to know when ONE chunk has arrived
     tmark(3 + 3 * ch, c->s_out);                               // D2H done
     tr("D2H enqueued", ch);
     return BJJ_OK;
@@ -656,7 +691,7 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
       }
       { int r = enqueue_out(outs); if (r) return r; }
       outs++;
-      while (out_ring && harvested < outs) {   // results that have already arrived: start their copy-out, do not wait
+      while (chunk_out_ring && harvested < outs) {   // results that have already arrived: start their copy-out, do not wait
         const int r = harvest(harvested, false);
         if (r == 1) break;
         if (r) return r;
@@ -676,8 +711,18 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
       { int r = drain_kernels(false, fronts); if (r) return r; }   // only chunks that are enqueued can be drained
     }
     { int r = drain_kernels(true, nchunks); if (r) return r; }
-    if (out_ring) for (size_t ch = harvested; ch < nchunks; ch++) { int r = finish_out(ch); if (r) return r; }
-    if (out_ring) for (size_t ch = 0; ch < nchunks; ch++) pool->wait(&g_out[ch]);
+    if (chunk_out_ring) for (size_t ch = harvested; ch < nchunks; ch++) { int r = finish_out(ch); if (r) return r; }
+    if (chunk_out_ring) for (size_t ch = 0; ch < nchunks; ch++) pool->wait(&g_out[ch]);
+    if (sp.extra) { HIPCK(hipEventSynchronize(c->ev_tail)); tr("extra stages complete", nchunks); }
+    if (sp.out_at_end) {   // the whole output arrays, once: pinned -> directly, pageable -> ring slot 0 -> workers
+      for (int i = 0; i < sp.n_out; i++)
+        HIPCK(hipMemcpyAsync(out_direct[i] ? sp.out[i] : c->pin_out[0] + r_out_off[i], c->dstage + d_out_off[i], n * sp.out_stride[i], hipMemcpyDeviceToHost, c->s_out));
+      if (out_ring) {
+        HIPCK(hipStreamSynchronize(c->s_out));
+        for (int i = 0; i < sp.n_out; i++) if (!out_direct[i]) pool->submit(sp.out[i], c->pin_out[0] + r_out_off[i], n * sp.out_stride[i], &g_out[0]);
+        pool->wait(&g_out[0]);
+      }
+    }
     HIPCK(hipStreamSynchronize(c->s_out));
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipStreamSynchronize(c->stream2));
@@ -695,6 +740,7 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
   for (hipEvent_t e : tev) if (e) hipEventDestroy(e);
   if (rc) {   // error path: nothing may still be writing into the caller's memory or reading the rings when we return
     hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->s_out);
+    if (sp.extra) hipDeviceSynchronize();   // whatever the extra stages had enqueued on their own streams
     (void)hipGetLastError();
     if (pool) for (size_t ch = 0; ch < nchunks; ch++) { pool->wait(&g_in[ch]); pool->wait(&g_out[ch]); }
   }
@@ -778,6 +824,8 @@ static void ctx_destroy(bjj_ctx* c) {
   if (c->dstage) { hipMemset(c->dstage, 0, c->pipe_bytes); hipFree(c->dstage); }
   for (hipEvent_t e : c->ev_in) hipEventDestroy(e);
   for (hipEvent_t e : c->ev_out) hipEventDestroy(e);
+  if (c->ev_tail) hipEventDestroy(c->ev_tail);
+  if (c->pipe_wl) hipFree(c->pipe_wl);
   for (hipEvent_t e : c->ev_k) hipEventDestroy(e);
   if (c->err_words) hipHostFree(c->err_words);
   if (c->slot_block) hipFree(c->slot_block);
@@ -1110,9 +1158,7 @@ int bjj_poseidon5_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out, void*
   LAUNCHCK(bjjk::poseidon5(st, grid_for(c, n, c->occ_poseidon), (const uint8_t*)d_in, n, (uint8_t*)d_out), "bjj_poseidon5_dev");
   DEV_LEAVE(c);
 }
-// scan (priority stream) -> main kernel (the caller's stream), both ordered behind what `st` has queued so far
-static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s,
-                          const uint8_t* msg, size_t n, uint8_t* ok) {
+static int ensure_scan_stream(ScratchSet* S) {
   if (!S->scan_stream) {
     int least = 0, greatest = 0;
     HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -1120,6 +1166,12 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
     HIPCK(hipEventCreateWithFlags(&S->ev_scan_in, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&S->ev_scan_out, hipEventDisableTiming));
   }
+  return BJJ_OK;
+}
+// scan (priority stream) -> main kernel (the caller's stream), both ordered behind what `st` has queued so far
+static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s,
+                          const uint8_t* msg, size_t n, uint8_t* ok) {
+  { int rc_ = ensure_scan_stream(S); if (rc_) return rc_; }
   const int scan_grid = grid_for(c, n, c->occ_scan, 64) * 64 / bjjk::verify_scan_block();   // occ_scan counts waves
   bool busy = expect_overlap(c, S);
   if (busy && c->verify_mode < 0 && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; busy = false; }
@@ -1159,6 +1211,84 @@ static int verify_launch(bjj_ctx* c, bool schnorr, const void* d_pk, const void*
 int bjj_eddsa_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
                          void* d_ok, void* stream) {
   return verify_launch(c, false, d_pk, d_r, d_s, d_msg, n, d_ok, stream, "bjj_eddsa_verify_dev");
+}
+// ---- verify through the host-pointer pipeline -----------------------------------------------------------------------
+// Items whose pk or R is off the curve take the reference's exact formula sequence, ~3x as long as a bulk item and strictly
+// serial per lane (k_verify.hip).  A device-pointer launch starts them first and they are long done when the bulk is; a
+// CHUNK of the pipeline that carries its own exact items lasts at least as long as they do -- 6.6 ms for the first 2^15 items
+// instead of 2.3 -- and the next chunk of its lane waits behind it: 2^20 verifications of BASELINE configs[3] (1 in 64
+// corrupted, half of those off the curve) took 25 ms on pinned host memory against 18.7 ms on device pointers
+// (profiles/r05_host_verify_exact_split.txt).  Here the two kinds of work are separate launches:
+//   per chunk, behind its H2D:  the on-curve scan of its items on the priority stream, appending batch-wide indices to ONE list
+//                               the bulk launch of its items on its lane (no scan needed: a bulk workgroup recognises and skips
+//                               an off-curve item by itself)
+//   behind the last scan:       ONE exact launch over the list, on the priority stream (its few workgroups take the next slots
+//                               that free up); it shares the first scratch set's slot queue with that set's bulk launches -- the
+//                               queue holds a slot for every workgroup that can be resident, whatever launch it belongs to
+// The verdicts leave once, after both (PipeSpec::out_at_end: 1 byte per item).
+static int verify_bulk_launch(bjj_ctx* c, bool schnorr, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
+                              void* d_ok, void* stream) {
+  SET_ENTER(c, stream, n, false);
+  c->rings_used = true;
+  c->last_verify_mode = 1;
+  LAUNCHCK(bjjk::verify_main(st, 1, 0, schnorr, c->table, c->W, c->nwin, (const uint8_t*)d_pk, (const uint8_t*)d_r, (const uint8_t*)d_s,
+                             (const uint8_t*)d_msg, n, (uint8_t*)d_ok, S->vb_tables, S->slow, S->slotq, S->slot_cap | ((u32)c->xccs << 16),
+                             bjjk::VERIFY_BULK), "verify (bulk)");
+  SET_LEAVE(c);
+}
+struct VerifyPipe : PipeExtra {
+  bjj_ctx* c;
+  bool schnorr;
+  const uint8_t *pk = nullptr, *r = nullptr, *s = nullptr, *msg = nullptr;
+  uint8_t* ok = nullptr;
+  size_t n = 0;
+  VerifyPipe(bjj_ctx* c_, bool schnorr_) : c(c_), schnorr(schnorr_) {}
+  int begin(size_t n_, void** d_in, void** d_out) override {
+    n = n_;
+    pk = (const uint8_t*)d_in[0]; r = (const uint8_t*)d_in[1]; s = (const uint8_t*)d_in[2]; msg = (const uint8_t*)d_in[3];
+    ok = (uint8_t*)d_out[0];
+    ScratchSet* S = &c->set[0];
+    { int rc_ = ensure_scratch(c, S, 1); if (rc_) return rc_; }      // the set's tables and slot queues exist
+    { int rc_ = ensure_scan_stream(S); if (rc_) return rc_; }
+    if (n > c->pipe_wl_items) {
+      if (c->pipe_wl) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->pipe_wl)); c->pipe_wl = nullptr; c->pipe_wl_items = 0; }
+      HIPCK(hipMalloc((void**)&c->pipe_wl, (n + 16) * sizeof(u32)));
+      c->pipe_wl_items = n;
+    }
+    LAUNCHCK(bjjk::verify_list_reset(S->scan_stream, c->pipe_wl), "verify list");
+    return BJJ_OK;
+  }
+  int chunk_arrived(size_t lo, size_t cnt, hipEvent_t arrived) override {
+    ScratchSet* S = &c->set[0];
+    HIPCK(hipStreamWaitEvent(S->scan_stream, arrived, 0));
+    const int grid = grid_for(c, cnt, c->occ_scan, 64) * 64 / bjjk::verify_scan_block();
+    LAUNCHCK(bjjk::verify_scan_range(S->scan_stream, grid, pk, r, msg, lo, lo + cnt, c->pipe_wl), "verify scan");
+    return BJJ_OK;
+  }
+  int all_arrived(hipEvent_t ev_tail) override {
+    ScratchSet* S = &c->set[0];
+    c->rings_used = true;
+    LAUNCHCK(bjjk::verify_main(S->scan_stream, 1, 0, schnorr, c->table, c->W, c->nwin, pk, r, s, msg, n, ok, S->vb_tables, c->pipe_wl, S->slotq,
+                               S->slot_cap | ((u32)c->xccs << 16), bjjk::VERIFY_EXACT), "verify (exact)");
+    HIPCK(hipEventRecord(ev_tail, S->scan_stream));
+    return BJJ_OK;
+  }
+};
+static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok) {
+  PipeSpec sp = {4, 1, {pk, r, s, msg}, {64, 64, 32, 32}, {ok}, {1}, false};
+  static const bool per_chunk = [] { const char* e = getenv("BJJ_PIPE_VERIFY_SPLIT"); return e && e[0] == '0'; }();   // developer: the round-5 form
+  if (c->verify_mode == 0 || per_chunk)   // the persistent form is forced: it is one launch per chunk, exact items included
+    return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) {
+      return schnorr ? bjj_schnorr_verify_dev(c, i[0], i[1], i[2], i[3], cnt, o[0], st) : bjj_eddsa_verify_dev(c, i[0], i[1], i[2], i[3], cnt, o[0], st); });
+  VerifyPipe vp(c, schnorr);
+  sp.extra = &vp;
+  sp.out_at_end = true;
+  // 18 ms of kernels against 3.9 ms of H2D for 2^20 items: the copy-out never bounds this call, what costs is the ramp (the
+  // chip is part empty until the first chunks have arrived) and every launch's partly empty last round -- fewer, larger chunks
+  // than the copy-bound default (2^16 / 2^19: 19.17 ms, 2^15 / 2^18: 19.36 ms; profiles/r05_host_verify_exact_split.txt)
+  sp.first_chunk = (size_t)1 << 16;
+  sp.max_chunk = (size_t)1 << 19;
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return verify_bulk_launch(c, schnorr, i[0], i[1], i[2], i[3], cnt, o[0], st); });
 }
 int bjj_schnorr_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
                            void* d_ok, void* stream) {
@@ -1369,14 +1499,12 @@ int bjj_poseidon5(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out) {
 int bjj_eddsa_verify(bjj_ctx* c, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n,
                      uint8_t* ok) {
   HOST_PROLOGUE("bjj_eddsa_verify", !pk || !r || !s || !msg || !ok);
-  PipeSpec sp = {4, 1, {pk, r, s, msg}, {64, 64, 32, 32}, {ok}, {1}, false};
-  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_eddsa_verify_dev(c, i[0], i[1], i[2], i[3], cnt, o[0], st); });
+  return verify_host(c, false, pk, r, s, msg, n, ok);
 }
 int bjj_schnorr_verify(bjj_ctx* c, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n,
                        uint8_t* ok) {
   HOST_PROLOGUE("bjj_schnorr_verify", !pk || !r || !s || !msg || !ok);
-  PipeSpec sp = {4, 1, {pk, r, s, msg}, {64, 64, 32, 32}, {ok}, {1}, false};
-  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_schnorr_verify_dev(c, i[0], i[1], i[2], i[3], cnt, o[0], st); });
+  return verify_host(c, true, pk, r, s, msg, n, ok);
 }
 int bjj_point_add(bjj_ctx* c, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out) {
   HOST_PROLOGUE("bjj_point_add", !p || !q || !out);

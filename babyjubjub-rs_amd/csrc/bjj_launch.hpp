@@ -63,9 +63,13 @@ hipError_t merge_codec_flags(hipStream_t st, int grid, uint8_t* ok, const uint8_
 hipError_t scalar_keys(hipStream_t st, int grid, const uint8_t* keys, size_t n, uint8_t* out);
 // k_verify.hip
 hipError_t verify_scan(hipStream_t st, int grid_scan, const uint8_t* pk, const uint8_t* rb8, const uint8_t* msg, size_t n, uint32_t* wl);
+hipError_t verify_list_reset(hipStream_t st, uint32_t* wl);
+hipError_t verify_scan_range(hipStream_t st, int grid_scan, const uint8_t* pk, const uint8_t* rb8, const uint8_t* msg, size_t first, size_t end,
+                             uint32_t* wl);
+enum { VERIFY_BOTH = 0, VERIFY_BULK = 1, VERIFY_EXACT = 2 };   // which workgroups of the one-group-per-workgroup form a launch holds
 hipError_t verify_main(hipStream_t st, int mode, int grid, bool schnorr, const uint32_t* table, int W, int nwin, const uint8_t* pk,
                        const uint8_t* rb8, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok, uint32_t* vb_tables,
-                       uint32_t* wl, uint32_t* slotq, uint32_t slot_cap);
+                       uint32_t* wl, uint32_t* slotq, uint32_t slot_cap, int part = VERIFY_BOTH);
 // k_sign.hip
 hipError_t sign(hipStream_t st, int grid, const uint32_t* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n,
                 uint8_t* out_r, uint8_t* out_s, uint8_t* ok);

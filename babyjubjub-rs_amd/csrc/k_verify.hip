@@ -43,11 +43,13 @@
 #endif
 __global__ void __launch_bounds__(BJJ_SCAN_BLOCK) bjj_k_eddsa_verify_scan(const uint8_t* __restrict__ pk,
                                                                      const uint8_t* __restrict__ rb8,
-                                                                     const uint8_t* __restrict__ msg, size_t n,
+                                                                     const uint8_t* __restrict__ msg, size_t first, size_t n,
                                                                      u32* __restrict__ wl) {
+  // items first .. n-1 of the arrays (first > 0: the host-pointer pipeline scans a batch chunk by chunk, as the chunks arrive,
+  // into ONE list of batch-wide indices)
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
 #pragma unroll 1
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+  for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
     VerifyIn in = {pk + i * 64, rb8 + i * 64, nullptr, msg + i * 32};
     if (verify_needs_exact(in, c_K)) wl[WL_HDR + atomicAdd(&wl[0], 1u)] = (u32)i;
   }
@@ -198,22 +200,34 @@ int verify_scan_block() { return BJJ_SCAN_BLOCK; }
 hipError_t verify_scan(hipStream_t st, int grid_scan, const uint8_t* pk, const uint8_t* rb8, const uint8_t* msg, size_t n, u32* wl) {
   hipError_t e = hipMemsetAsync(wl, 0, WL_HDR * sizeof(u32), st);
   if (e != hipSuccess) return e;
-  BJJ_LAUNCH(bjj_k_eddsa_verify_scan, dim3(grid_scan), dim3(BJJ_SCAN_BLOCK), 0, st, pk, rb8, msg, n, wl);
+  BJJ_LAUNCH(bjj_k_eddsa_verify_scan, dim3(grid_scan), dim3(BJJ_SCAN_BLOCK), 0, st, pk, rb8, msg, (size_t)0, n, wl);
+  return hipGetLastError();
+}
+// The scan of items first .. end-1 appended to a list that somebody else has reset (verify_list_reset): the host-pointer
+// pipeline, one range per chunk.
+hipError_t verify_list_reset(hipStream_t st, u32* wl) { return hipMemsetAsync(wl, 0, WL_HDR * sizeof(u32), st); }
+hipError_t verify_scan_range(hipStream_t st, int grid_scan, const uint8_t* pk, const uint8_t* rb8, const uint8_t* msg, size_t first, size_t end, u32* wl) {
+  BJJ_LAUNCH(bjj_k_eddsa_verify_scan, dim3(grid_scan), dim3(BJJ_SCAN_BLOCK), 0, st, pk, rb8, msg, first, end, wl);
   return hipGetLastError();
 }
 hipError_t verify_main(hipStream_t st, int mode, int grid, bool schnorr, const u32* table, int W, int nwin, const uint8_t* pk,
                        const uint8_t* rb8, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok, u32* vb_tables, u32* wl,
-                       u32* slotq, u32 slot_cap) {
+                       u32* slotq, u32 slot_cap, int part) {
   if (mode == 1) {
+  // part (VERIFY_BOTH / VERIFY_BULK / VERIFY_EXACT, bjj_launch.hpp): the two kinds of workgroup of this form are independent --
+  // a bulk workgroup skips the items of the list, an exact workgroup touches nothing else -- so they can be two launches.  The
+  // host-pointer pipeline uses that: a chunk's bulk launch lasts as long as its items take, not as long as the ~3x longer exact
+  // items among them, and ONE exact launch serves the whole batch (bjj_hip.hip: VerifyPipe).
   const size_t nchunks = (n + 63) / 64;
-  const unsigned exact_wgs = (unsigned)(nchunks < 4096 ? nchunks : 4096);      // most of them find nothing on the list and exit at once
-  const unsigned bulk_wgs = (unsigned)(nchunks < 32768 ? nchunks : 32768);    // one 64-item chunk each up to 2^21 items, strided beyond
+  const unsigned exact_wgs = part == VERIFY_BULK ? 0u : (unsigned)(nchunks < 4096 ? nchunks : 4096);      // most of them find nothing on the list and exit at once
+  const unsigned bulk_wgs = part == VERIFY_EXACT ? 0u : (unsigned)(nchunks < 32768 ? nchunks : 32768);    // one 64-item chunk each up to 2^21 items, strided beyond
   const unsigned groups = exact_wgs + bulk_wgs;
   if (schnorr)
     BJJ_LAUNCH(bjj_k_schnorr_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap, exact_wgs);
   else
     BJJ_LAUNCH(bjj_k_eddsa_verify_groups, dim3(groups), dim3(64), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl, slotq, slot_cap, exact_wgs);
   } else {
+  if (part != VERIFY_BOTH) return hipErrorInvalidValue;   // the persistent form is one launch
   if (schnorr)
     BJJ_LAUNCH(bjj_k_schnorr_verify, dim3(grid), dim3(BJJ_VERIFY_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok, vb_tables, wl);
   else

@@ -797,8 +797,19 @@ def host_api_block(ctx, n, orc):
     best of a few calls each; byte-compared with the oracle on a sample.  NEVER `value`."""
     from babyjubjub_rs_amd import workload as w
     sc = np.ascontiguousarray(w.scalars_254(n)).reshape(-1)
-    m = np.ascontiguousarray(w.random_u256(w.SEED_MSGS, n, 0, top_bits_cleared=3)).reshape(-1)
     idx = np.unique(np.linspace(0, n - 1, 64).astype(np.int64))
+    # verify: the workload of `--workload verify` (BASELINE configs[3]: valid signatures from the device signer, 1 in 64 corrupted, half
+    # of those with pk or R off the curve = the ~3x longer exact items) -- not random points, which hold no exact item at all
+    dev = torch.device("cuda", torch.cuda.current_device())
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)  # noqa: E731
+    d_keys, d_m = up(w.random_u256(w.SEED_KEYS, n, 0)), up(w.random_u256(w.SEED_MSGS, n, 0, top_bits_cleared=3))
+    d_pk, d_r, d_s, d_f = (torch.empty(k, dtype=torch.uint8, device=dev) for k in (n * 64, n * 64, n * 32, n))
+    ctx.public_keys_dev(d_keys.data_ptr(), n, d_pk.data_ptr(), 0)
+    ctx.sign_dev(d_keys.data_ptr(), d_m.data_ptr(), n, d_r.data_ptr(), d_s.data_ptr(), d_f.data_ptr(), 0)
+    ctx.sync()
+    bad = w.corrupt(d_pk.view(n, 64), d_r.view(n, 64), d_s.view(n, 32), d_m.view(n, 32), n, 0)
+    v_host = [t.cpu().numpy() for t in (d_pk, d_r, d_s, d_m)]
+    d_ok = torch.empty(n, dtype=torch.uint8, device=dev)
 
     def best(f, reps, warm_s=0.5):
         # calls back to back for warm_s first: the section before this one leaves the GPU idle for a few hundred milliseconds
@@ -820,44 +831,74 @@ def host_api_block(ctx, n, orc):
             alloc = ctx.host_empty
         else:
             alloc = lambda nb: np.zeros(nb, np.uint8)  # noqa: E731
-        h_sc, h_m, out, ok = alloc(n * 32), alloc(n * 32), alloc(n * 64), alloc(n)
+        h_sc, out, ok = alloc(n * 32), alloc(n * 64), alloc(n)
         h_sc[:] = sc
-        h_m[:] = m
         out[:] = 0
         ok[:] = 0
         t_fb, t_fb_med = best(lambda: ctx._ck(ctx.lib.bjj_mul_fixed_base(ctx.handle, h_sc.ctypes.data, n, out.ctypes.data), "bjj_mul_fixed_base"), 7)
         i_fb = ctx.info()
         good = bool((np.asarray(out).reshape(n, 64)[idx] == orc.mul_fixed_base(sc.reshape(n, 32)[idx])).all())
-        A = alloc(n * 64)                                # n points of the group: used as pk and as R (verdicts are beside the point)
-        A[:] = out
-        t_v, t_v_med = best(lambda: ctx._ck(ctx.lib.bjj_eddsa_verify(ctx.handle, A.ctypes.data, A.ctypes.data, h_sc.ctypes.data, h_m.ctypes.data, n,
+        # variable base (Point::mul_scalar on a caller's own points, src/lib.rs:149-164): the points just computed, the same scalars
+        h_pts, out_vb = alloc(n * 64), alloc(n * 64)
+        h_pts[:] = out
+        out_vb[:] = 0
+        t_vb, t_vb_med = best(lambda: ctx._ck(ctx.lib.bjj_mul_var_base(ctx.handle, h_pts.ctypes.data, h_sc.ctypes.data, n, out_vb.ctypes.data), "bjj_mul_var_base"), 3)
+        i_vb = ctx.info()
+        good = good and bool((np.asarray(out_vb).reshape(n, 64)[idx] == orc.mul_var_base(np.asarray(h_pts).reshape(n, 64)[idx], sc.reshape(n, 32)[idx])).all())
+        hv = [alloc(a.size) for a in v_host]
+        for b, a in zip(hv, v_host):
+            b[:] = a
+        t_v, t_v_med = best(lambda: ctx._ck(ctx.lib.bjj_eddsa_verify(ctx.handle, hv[0].ctypes.data, hv[1].ctypes.data, hv[2].ctypes.data, hv[3].ctypes.data, n,
                                                                       ok.ctypes.data), "bjj_eddsa_verify"), 3)
         i_v = ctx.info()
-        An = np.asarray(A).reshape(n, 64)
-        good = good and bool((np.asarray(ok)[idx] == orc.verify(An[idx], An[idx], sc.reshape(n, 32)[idx], m.reshape(n, 32)[idx])).all())
+        vi = np.unique(np.concatenate([idx, np.nonzero(bad)[0][:64]]))                      # incl. corrupted items
+        good = good and bool((np.asarray(ok) == (~bad).astype(np.uint8)).all())             # every verdict against the corruption mask
+        good = good and bool((np.asarray(ok)[vi] == orc.verify(v_host[0].reshape(n, 64)[vi], v_host[1].reshape(n, 64)[vi], v_host[2].reshape(n, 32)[vi],
+                                                               v_host[3].reshape(n, 32)[vi])).all())
         res = {"fixed_base": {"value": n / t_fb, "unit": UNITS["fixed_base"], "ms_per_call": t_fb * 1e3, "ms_per_call_median": t_fb_med * 1e3,
                               "items": n, "bytes_moved": n * 96, "entry_point": "bjj_mul_fixed_base",
                               "arrays_direct": i_fb.last_host_direct_arrays, "arrays_staged": i_fb.last_host_staged_arrays,
                               "chunks": i_fb.last_host_chunks},
+               "var_base": {"value": n / t_vb, "unit": UNITS["var_base"], "ms_per_call": t_vb * 1e3, "ms_per_call_median": t_vb_med * 1e3,
+                            "items": n, "bytes_moved": n * 160, "entry_point": "bjj_mul_var_base",
+                            "arrays_direct": i_vb.last_host_direct_arrays, "arrays_staged": i_vb.last_host_staged_arrays,
+                            "chunks": i_vb.last_host_chunks, "device_one_launch_ms": t_dev_vb * 1e3, "vs_device_one_launch": t_vb / t_dev_vb},
                "verify": {"value": n / t_v, "unit": UNITS["verify"], "ms_per_call": t_v * 1e3, "ms_per_call_median": t_v_med * 1e3,
                           "items": n, "bytes_moved": n * 193, "entry_point": "bjj_eddsa_verify",
                           "arrays_direct": i_v.last_host_direct_arrays, "arrays_staged": i_v.last_host_staged_arrays,
-                          "chunks": i_v.last_host_chunks},
+                          "chunks": i_v.last_host_chunks, "device_one_launch_ms": t_dev * 1e3, "vs_device_one_launch": t_v / t_dev},
                "parity_sample_ok": good}
         if kind_mem == "pinned":
-            for a in (h_sc, h_m, out, ok, A):
+            for a in [h_sc, out, ok, h_pts, out_vb] + hv:
                 ctx.host_free(a)
         return res
 
+    # the same inputs through the device-pointer entry point, ONE launch at a time: what a synchronous call can be held against
+    # (the two-stream rate of `also.verify` lives on the overlap of consecutive launches, which a synchronous call cannot have)
+    def one_launch():
+        ctx.eddsa_verify_dev(d_pk.data_ptr(), d_r.data_ptr(), d_s.data_ptr(), d_m.data_ptr(), n, d_ok.data_ptr(), 0)
+        ctx.sync()
+    t_dev, _ = best(one_launch, 3)
+    d_sc = up(sc)
+    d_pts, d_vb = torch.empty(n * 64, dtype=torch.uint8, device=dev), torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    ctx.mul_fixed_base_dev(d_sc.data_ptr(), n, d_pts.data_ptr(), 0)
+
+    def one_launch_vb():
+        ctx.mul_var_base_dev(d_pts.data_ptr(), d_sc.data_ptr(), n, d_vb.data_ptr(), 0)
+        ctx.sync()
+    t_dev_vb, _ = best(one_launch_vb, 3)
     pinned = run("pinned")
     pageable = run("pageable")
     return {"note": "PCIe-inclusive: host pointers in, host pointers out, synchronous call.  fixed_base / verify = caller arrays in "
-                    "pinned memory (bjj_host_alloc): copied directly, chunked pipeline (2^15 items first, doubling to 2^18), chunk "
-                    "kernels alternating over the context's two compute streams; `pageable` = the same calls on ordinary memory, "
+                    "pinned memory (bjj_host_alloc): copied directly, chunked pipeline (2^15 items first, doubling to 2^18; "
+                    "verify 2^16 to 2^19, its off-curve items as one launch beside the chunks'), chunk kernels alternating over the context's two "
+                    "compute streams; verify inputs = the cfg-4 workload of `also.verify` (1 in 64 corrupted), `vs_device_one_launch` = the call "
+                    "against one device-pointer launch on the same inputs; `pageable` = the same calls on ordinary memory, "
                     "staged through pinned buffers by %d copy workers.  Calls back to back for 0.5 s before the timed ones (sustained "
                     "clocks), then best of 7 (fixed_base) / 3 (verify) and the median.  Reported beside the line, never as `value`."
                     % ctx.info().host_copy_threads,
-            "fixed_base": pinned["fixed_base"], "verify": pinned["verify"], "pageable": {"fixed_base": pageable["fixed_base"], "verify": pageable["verify"]},
+            "fixed_base": pinned["fixed_base"], "var_base": pinned["var_base"], "verify": pinned["verify"],
+            "pageable": {"fixed_base": pageable["fixed_base"], "var_base": pageable["var_base"], "verify": pageable["verify"]},
             "copy_threads": ctx.info().host_copy_threads,
             "parity_sample_ok": pinned["parity_sample_ok"] and pageable["parity_sample_ok"]}
 

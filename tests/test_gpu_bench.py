@@ -108,6 +108,11 @@ def test_bench_one_gpu_line_has_every_block():
     assert (h["fixed_base"]["arrays_direct"], h["fixed_base"]["arrays_staged"]) == (2, 0) and (h["verify"]["arrays_direct"], h["verify"]["arrays_staged"]) == (5, 0)
     hp = h["pageable"]
     assert (hp["fixed_base"]["arrays_direct"], hp["fixed_base"]["arrays_staged"]) == (0, 2) and hp["verify"]["arrays_staged"] == 5 and h["copy_threads"] >= 1
+    # ... the verify row on the cfg-4 workload (off-curve items included), held against one device-pointer launch on the same inputs;
+    # the variable-base row (Point::mul_scalar on the caller's own points)
+    assert h["verify"]["device_one_launch_ms"] > 0 and 0.5 < h["verify"]["vs_device_one_launch"] < 5.0 and "cfg-4" in h["note"]
+    assert (h["var_base"]["arrays_direct"], h["var_base"]["arrays_staged"]) == (3, 0) and hp["var_base"]["arrays_staged"] == 3
+    assert h["var_base"]["value"] > 0 and h["var_base"]["vs_device_one_launch"] > 0.5
     w23 = j["also"]["fixed_base_window_bits_23"]
     assert w23["kernel"] == "bjj_k_mul_fixed_base" and w23["streams"] == 1 and "clock_mhz" in w23 and w23["init_ms"] > 0
     if j["clock"].get("available"):

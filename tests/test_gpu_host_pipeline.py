@@ -188,6 +188,9 @@ def test_every_host_entry_point_on_pinned_memory_equals_the_staged_path(ctx16, o
     proj = np.concatenate([pts, rng.integers(0, 256, (n, 32), dtype=np.uint8)], axis=1)
     proj[::101, 64:] = 0                                         # z == 0
     r, s, okf = ctx16.sign(keys, msgs)
+    pk_v, r_v = pk.copy(), r.copy()
+    pk_v[::53, 7] ^= 4                                           # off-curve pk / R: the exact items of the verify pipeline,
+    r_v[5::211, 40] ^= 1                                         # which run as ONE launch beside the chunks' bulk launches
     comp = ctx16.compress_points(pk)
     comp[::71, 3] ^= 1                                           # some that do not decompress
     sig = np.concatenate([ctx16.compress_points(r), s], axis=1)
@@ -197,8 +200,8 @@ def test_every_host_entry_point_on_pinned_memory_equals_the_staged_path(ctx16, o
         ("bjj_mul_var_base", [(pts, 64), (sc, 32)], [], [64]),
         ("bjj_mul_var_base_wide", [(pts, 64), (wide, 64)], [64], [64]),
         ("bjj_poseidon5", [(h5, 160)], [], [32]),
-        ("bjj_eddsa_verify", [(pk, 64), (r, 64), (s, 32), (msgs, 32)], [], [1]),
-        ("bjj_schnorr_verify", [(pk, 64), (r, 64), (s, 32), (msgs, 32)], [], [1]),
+        ("bjj_eddsa_verify", [(pk_v, 64), (r_v, 64), (s, 32), (msgs, 32)], [], [1]),
+        ("bjj_schnorr_verify", [(pk_v, 64), (r_v, 64), (s, 32), (msgs, 32)], [], [1]),
         ("bjj_point_add", [(pts, 64), (pk, 64)], [], [64]),
         ("bjj_proj_add", [(proj, 96), (proj[::-1].copy(), 96)], [], [96]),
         ("bjj_proj_affine", [(proj, 96)], [], [64]),
@@ -231,7 +234,9 @@ def test_every_host_entry_point_on_pinned_memory_equals_the_staged_path(ctx16, o
             assert rc == 0, (name, mem, lib.bjj_last_error())
             i = ctx16.info()
             want = (len(ins) + len(outs), 0) if mem == "pinned" else (0, len(ins) + len(outs))
-            assert (i.last_host_direct_arrays, i.last_host_staged_arrays) == want and i.last_host_chunks == 3, (name, mem)
+            # the verifiers bring their own schedule (first chunk 2^16: 18 ms of kernels hide 4 ms of copies, bjj_hip.hip verify_host)
+            chunks = len(_schedule(n, 1 << 16, 1 << 19)) if name in ("bjj_eddsa_verify", "bjj_schnorr_verify") else 3
+            assert (i.last_host_direct_arrays, i.last_host_staged_arrays) == want and i.last_host_chunks == chunks, (name, mem, i.last_host_chunks)
             got[mem] = [np.asarray(b).copy() for b in a_out]
             if mem == "pinned":
                 for b in a_in + a_out:
@@ -243,13 +248,30 @@ def test_every_host_entry_point_on_pinned_memory_equals_the_staged_path(ctx16, o
     assert (results["bjj_mul_fixed_base"][0].reshape(n, 64)[idx] == oracle.mul_fixed_base(sc[idx])).all()
     assert (results["bjj_mul_var_base"][0].reshape(n, 64)[idx] == oracle.mul_var_base(pts[idx], sc[idx])).all()
     assert (results["bjj_poseidon5"][0].reshape(n, 32)[idx] == oracle.poseidon5(h5[idx])).all()
-    assert (results["bjj_eddsa_verify"][0][idx] == oracle.verify(pk[idx], r[idx], s[idx], msgs[idx])).all()
+    vidx = np.unique(np.concatenate([idx, np.arange(0, n, 53)[::7], np.arange(5, n, 211)[::5]]))   # incl. off-curve items
+    assert (results["bjj_eddsa_verify"][0][vidx] == oracle.verify(pk_v[vidx], r_v[vidx], s[vidx], msgs[vidx])).all()
+    # every verdict of both verifiers against the one-launch device-pointer call (exact groups inside the launch)
+    assert (results["bjj_eddsa_verify"][0] == _verify_one_launch(ctx16, False, pk_v, r_v, s, msgs)).all()
+    assert (results["bjj_schnorr_verify"][0] == _verify_one_launch(ctx16, True, pk_v, r_v, s, msgs)).all()
     assert (results["bjj_public_keys"][0].reshape(n, 64)[idx] == oracle.public_keys(keys[idx])).all()
     ro, so, oko = oracle.sign(keys[idx], msgs[idx])
     rs = results["bjj_sign"]
     assert (rs[0].reshape(n, 64)[idx] == ro).all() and (rs[1].reshape(n, 32)[idx] == so).all() and (rs[2][idx] == oko).all()
     dp, dok = oracle.decompress(comp[idx])
     assert (results["bjj_decompress_points"][0].reshape(n, 64)[idx] == dp).all() and (results["bjj_decompress_points"][1][idx] == dok).all()
+
+
+def _verify_one_launch(ctx, schnorr, pk, r, s, msg):
+    """the device-pointer entry point on the whole batch: one scan + one launch that holds the exact groups and the bulk"""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = pk.shape[0]
+    d = [torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev) for a in (pk, r, s, msg)]
+    d_ok = torch.full((n,), 0xAB, dtype=torch.uint8, device=dev)
+    f = ctx.schnorr_verify_dev if schnorr else ctx.eddsa_verify_dev
+    f(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), n, d_ok.data_ptr(), 0)
+    ctx.sync()
+    return d_ok.cpu().numpy()
 
 
 def _schedule(n, first, cap_chunk):
@@ -295,6 +317,23 @@ i = c.info()
 print("INFO", i.last_host_direct_arrays, i.last_host_staged_arrays, i.last_host_chunks)
 assert (np.asarray(p_out) == out2).all()
 np.save(sys.argv[1], out2)
+# verify across super-batches (193 B per item: 4 096 items each): the list of off-curve items is reset per super-batch and its
+# batch-wide indices start at the super-batch; cfg-4 signatures, 1 in 64 corrupted, half of those off the curve
+nv = 15000
+A, R, S, msg = w.make_signatures(c.mul_fixed_base, c.poseidon5, nv)
+bad = w.corrupt(A, R, S, msg, nv)
+flat = [np.ascontiguousarray(a).reshape(-1) for a in (A, R, S, msg)]
+ok_pg = np.full(nv, 9, np.uint8)
+c._ck(c.lib.bjj_eddsa_verify(c.handle, flat[0].ctypes.data, flat[1].ctypes.data, flat[2].ctypes.data, flat[3].ctypes.data, nv, ok_pg.ctypes.data), "v")
+print("VINFO", c.info().last_host_chunks, c.info().last_verify_dispatch)
+pin = []
+for a in flat:
+    b = c.host_empty(a.size); b[:] = a; pin.append(b)
+ok_pin = c.host_empty(nv); ok_pin[:] = 9
+c._ck(c.lib.bjj_schnorr_verify(c.handle, pin[0].ctypes.data, pin[1].ctypes.data, pin[2].ctypes.data, pin[3].ctypes.data, nv, ok_pin.ctypes.data), "vs")
+c._ck(c.lib.bjj_eddsa_verify(c.handle, pin[0].ctypes.data, pin[1].ctypes.data, pin[2].ctypes.data, pin[3].ctypes.data, nv, ok_pin.ctypes.data), "v")
+assert (ok_pg == (~bad).astype(np.uint8)).all() and (np.asarray(ok_pin) == ok_pg).all(), (int((ok_pg != (~bad)).sum()), int((np.asarray(ok_pin) != ok_pg).sum()))
+print("VOK", int(bad.sum()))
 c.close()
 ''' % (ROOT, n)
     with tempfile.TemporaryDirectory() as td:
@@ -307,6 +346,13 @@ c.close()
         infos = [[int(x) for x in l.split()[1:]] for l in r.stdout.splitlines() if l.startswith("INFO")]
         assert infos == [[2, 0, want], [0, 2, want]] and want > 20, (infos, want)
         got = np.load(outp).reshape(n, 64)
+        vcap = max((1 << 20) // 193 // 2048 * 2048, 2048)          # 4 096 verifications per super-batch
+        vwant = sum(len(_schedule(min(vcap, 15000 - lo), 1024, 2048)) for lo in range(0, 15000, vcap))
+        assert ("VINFO %d 1" % vwant) in r.stdout and "VOK" in r.stdout, r.stdout
+        # ... and the per-chunk form of round 5 (exact items inside every chunk's launch) gives the same verdicts
+        r2 = subprocess.run([sys.executable, "-c", code, outp], env=dict(env, BJJ_PIPE_VERIFY_SPLIT="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                            text=True, timeout=600)
+        assert r2.returncode == 0 and "VOK" in r2.stdout, r2.stdout
     assert (got == oracle.mul_fixed_base(w.scalars_254(n, offset=11))).all()
 
 
