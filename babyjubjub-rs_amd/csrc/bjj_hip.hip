@@ -1482,6 +1482,7 @@ int bjj_mul_fixed_base(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* ou
 int bjj_mul_var_base(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out) {
   HOST_PROLOGUE("bjj_mul_var_base", !pts || !scalars || !out);
   PipeSpec sp = {2, 1, {pts, scalars}, {64, 32}, {out}, {64}, false};
+  sp.first_chunk = (size_t)1 << 16;   // 14 ms of kernels over 3 ms of copies: a 2^15-item launch holds its lane for a whole round with a quarter of the chip
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_var_base_dev(c, i[0], i[1], cnt, o[0], st); });
 }
 int bjj_mul_var_base_wide(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t scalar_bytes, size_t n, uint8_t* out) {
@@ -1489,6 +1490,7 @@ int bjj_mul_var_base_wide(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars
   if (scalar_bytes == 0 || (scalar_bytes & 31) || scalar_bytes > BJJ_MAX_SCALAR_BYTES)
     return set_err(BJJ_E_INVALID, "bjj_mul_var_base_wide: scalar_bytes must be a multiple of 32 in 32..BJJ_MAX_SCALAR_BYTES");
   PipeSpec sp = {2, 1, {pts, scalars}, {64, scalar_bytes}, {out}, {64}, false};
+  sp.first_chunk = (size_t)1 << 16;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_var_base_wide_dev(c, i[0], i[1], scalar_bytes, cnt, o[0], st); });
 }
 int bjj_poseidon5(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out) {
