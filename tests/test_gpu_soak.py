@@ -76,3 +76,70 @@ def test_soak_all_entry_points(gpu_ctx, oracle, seed):
     # hash
     h = rng.integers(0, 256, (n, 160), dtype=np.uint8)
     assert (gpu_ctx.poseidon5(h) == oracle.poseidon5(h)).all()
+
+
+def _more_seeds(default):
+    """BJJ_SOAK_HOST_VERIFY_SEEDS=first:count in the environment (developer): a longer run of the test below"""
+    import os
+    e = os.environ.get("BJJ_SOAK_HOST_VERIFY_SEEDS")
+    if not e:
+        return default
+    a, b = e.split(":")
+    return list(range(int(a), int(a) + int(b)))
+
+
+@pytest.mark.parametrize("seed", _more_seeds([11, 12, 13, 14]))
+def test_soak_host_verify_across_chunks(gpu_ctx, oracle, seed):
+    """The verifiers on host pointers at sizes of several chunks: a call's off-curve items run as ONE launch beside the chunks'
+    bulk launches, its scans append to one batch-wide list, and that launch shares a slot queue with one lane's bulk launches
+    (bjj_hip.hip: VerifyPipe).  Random size, random density of off-curve pk / R (none ... 1 in 3), each array pinned or pageable
+    at random; every verdict against ONE device-pointer launch of the same inputs (exact groups inside the launch), a sample
+    that contains off-curve items against the oracle."""
+    import torch
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(100000, 400000))                        # two to three chunks of the verifiers' schedule (2^16, 2^17, 2^18 ...)
+    dev = torch.device("cuda", 0)
+    keys = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msgs[:, 31] &= 0x1f
+    msgs[rng.random(n) < 0.01, 31] = 0xff                        # a few msg > Q (Schnorr: Err)
+    pk = gpu_ctx.public_keys(keys)
+    r, s, okf = gpu_ctx.sign(keys, msgs)
+    dens = [0.0, 1 / 128, 1 / 16, 1 / 3][seed % 4]
+    A, R, S = pk.copy(), r.copy(), s.copy()
+    off_a, off_r = rng.random(n) < dens, rng.random(n) < dens / 2
+    A[off_a, int(rng.integers(0, 31))] ^= np.uint8(1 << int(rng.integers(0, 8)))     # pk.x
+    R[off_r, 32 + int(rng.integers(0, 31))] ^= np.uint8(1 << int(rng.integers(0, 8)))  # R.y
+    S[rng.random(n) < 0.02, 3] ^= 1                               # plain wrong signatures (bulk path)
+    arrays = [np.ascontiguousarray(a).reshape(-1) for a in (A, R, S, msgs)]
+    d = [torch.from_numpy(a).to(dev) for a in arrays]
+    d_ok = torch.empty(n, dtype=torch.uint8, device=dev)
+    for schnorr in (False, True):
+        d_ok.fill_(0xAB)
+        (gpu_ctx.schnorr_verify_dev if schnorr else gpu_ctx.eddsa_verify_dev)(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), n, d_ok.data_ptr(), 0)
+        gpu_ctx.sync()
+        want = d_ok.cpu().numpy()
+        held, ptrs = [], []
+        for a in arrays:                                          # pinned or pageable, per array
+            if rng.random() < 0.5:
+                b = gpu_ctx.host_empty(a.size)
+                b[:] = a
+                held.append(b)
+                ptrs.append(b.ctypes.data)
+            else:
+                ptrs.append(a.ctypes.data)
+        ok = gpu_ctx.host_empty(n) if rng.random() < 0.5 else np.empty(n, np.uint8)
+        ok[:] = 0xCD
+        f = gpu_ctx.lib.bjj_schnorr_verify if schnorr else gpu_ctx.lib.bjj_eddsa_verify
+        gpu_ctx._ck(f(gpu_ctx.handle, ptrs[0], ptrs[1], ptrs[2], ptrs[3], n, ok.ctypes.data), "verify")
+        i = gpu_ctx.info()
+        assert i.last_host_chunks >= 2 and i.last_host_direct_arrays + i.last_host_staged_arrays == 5
+        got = np.asarray(ok).copy()
+        assert (got == want).all(), (schnorr, n, int((got != want).sum()))
+        idx = np.unique(np.concatenate([np.arange(0, n, max(1, n // 40)), np.nonzero(off_a | off_r)[0][:40]]))
+        ref = (oracle.verify_schnorr if schnorr else oracle.verify)(A[idx], R[idx], S[idx], msgs[idx])
+        assert (got[idx] == ref).all()
+        for b in held:
+            gpu_ctx.host_free(b)
+        if gpu_ctx.host_is_pinned(ok):
+            gpu_ctx.host_free(ok)
