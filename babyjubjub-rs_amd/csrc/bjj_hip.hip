@@ -1250,6 +1250,11 @@ struct VerifyPipe : PipeExtra {
     ScratchSet* S = &c->set[0];
     { int rc_ = ensure_scratch(c, S, 1); if (rc_) return rc_; }      // the set's tables and slot queues exist
     { int rc_ = ensure_scan_stream(S); if (rc_) return rc_; }
+    // the exact launch works in this set's tables without being one of its calls (set_enter / set_leave): whatever used the set
+    // last on another stream -- a variable-base launch a caller has enqueued and not waited for lays ITS tables over the same
+    // memory -- must be done first.  Afterwards only this call's own bulk launches touch the set (slot queue), and the call
+    // does not return before the exact launch has completed (ev_tail).
+    { int rc_ = set_enter(c, S, S->scan_stream); if (rc_) return rc_; }
     if (n > c->pipe_wl_items) {
       if (c->pipe_wl) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->pipe_wl)); c->pipe_wl = nullptr; c->pipe_wl_items = 0; }
       HIPCK(hipMalloc((void**)&c->pipe_wl, (n + 16) * sizeof(u32)));
@@ -1277,7 +1282,14 @@ struct VerifyPipe : PipeExtra {
 static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok) {
   PipeSpec sp = {4, 1, {pk, r, s, msg}, {64, 64, 32, 32}, {ok}, {1}, false};
   static const bool per_chunk = [] { const char* e = getenv("BJJ_PIPE_VERIFY_SPLIT"); return e && e[0] == '0'; }();   // developer: the round-5 form
-  if (c->verify_mode == 0 || per_chunk)   // the persistent form is forced: it is one launch per chunk, exact items included
+  // a call of ONE chunk is a device-pointer launch with copies around it: its exact groups start first inside the launch, nothing
+  // waits behind them, and three launches instead of two would only add latency (a single `verify`, src/lib.rs:395, is such a call)
+  { ENTER_DEVICE(c->device); int rc_ = ensure_pipe(c, 0, 0, 0, 0); if (rc_) return rc_; }
+  const size_t first = c->pipe_env_schedule ? c->pipe_first : (size_t)1 << 16;
+  const bool one_chunk = n < first + first / 2;
+  sp.first_chunk = first;
+  sp.max_chunk = (size_t)1 << 19;
+  if (c->verify_mode == 0 || per_chunk || one_chunk)   // (the persistent form, when forced, is one launch per chunk, exact items included)
     return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) {
       return schnorr ? bjj_schnorr_verify_dev(c, i[0], i[1], i[2], i[3], cnt, o[0], st) : bjj_eddsa_verify_dev(c, i[0], i[1], i[2], i[3], cnt, o[0], st); });
   VerifyPipe vp(c, schnorr);
@@ -1286,8 +1298,6 @@ static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_
   // 18 ms of kernels against 3.9 ms of H2D for 2^20 items: the copy-out never bounds this call, what costs is the ramp (the
   // chip is part empty until the first chunks have arrived) and every launch's partly empty last round -- fewer, larger chunks
   // than the copy-bound default (2^16 / 2^19: 19.17 ms, 2^15 / 2^18: 19.36 ms; profiles/r05_host_verify_exact_split.txt)
-  sp.first_chunk = (size_t)1 << 16;
-  sp.max_chunk = (size_t)1 << 19;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return verify_bulk_launch(c, schnorr, i[0], i[1], i[2], i[3], cnt, o[0], st); });
 }
 int bjj_schnorr_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,

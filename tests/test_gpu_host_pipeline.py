@@ -429,3 +429,76 @@ def test_kernel_form_follows_pattern_and_state(oracle):
         assert forms[1:] == [0] * 5, forms
     finally:
         ctx.close()
+
+
+def test_host_verify_behind_an_unfinished_launch_that_owns_the_first_scratch_set(oracle):
+    """The exact launch of a host-pointer verification of several chunks works in the first scratch set's per-lane tables without being one
+    of the set's calls.  Variable-base launches the caller has enqueued on streams of their own and NOT waited for lay their tile tables
+    over the same memory: the verification queues its exact launch behind the set's last foreign launch (VerifyPipe::begin).  The scenario
+    -- both scratch sets owned by launches in flight -- is run and all three results are compared with runs that had the GPU to
+    themselves.  (Whether a missing wait shows depends on how the hardware interleaves the launches: a build without it passed this test on
+    the boxes of round 5, its exact launch running beside both others for 22 ms.  The wait is required by the set protocol all the same.)"""
+    import torch
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    import os
+    dev = torch.device("cuda", 0)
+    # the tile form of K2 for every launch: its workgroups retire tile by tile, so the verification's exact workgroups DO get onto the
+    # chip beside them (the grid-strided form holds every slot of the chip until it is done and would hide a missing wait)
+    old_env = os.environ.get("BJJ_K2_VARIANT")
+    os.environ["BJJ_K2_VARIANT"] = "1"
+    try:
+        ctx = bjj.Context(0, 16)
+    finally:
+        if old_env is None:
+            del os.environ["BJJ_K2_VARIANT"]
+        else:
+            os.environ["BJJ_K2_VARIANT"] = old_env
+    try:
+        n = 1 << 20
+        rng = np.random.default_rng(0x5e7)
+        sc = w.scalars_254(n, offset=123)
+        d_sc = torch.from_numpy(np.ascontiguousarray(sc).reshape(-1)).to(dev)
+        d_pts, d_out, d_ref = (torch.empty(n * 64, dtype=torch.uint8, device=dev) for _ in range(3))
+        X = torch.cuda.Stream(device=dev)
+        ctx.mul_fixed_base_dev(d_sc.data_ptr(), n, d_pts.data_ptr(), X.cuda_stream)          # first scratch use of the context: set 0 is X's
+        ctx.mul_var_base_dev(d_pts.data_ptr(), d_sc.data_ptr(), n, d_ref.data_ptr(), X.cuda_stream)
+        ctx.sync()
+        assert ctx.info().last_var_base_form == 1                                             # tiles: tables from the set's slot queue
+        # signatures with many off-curve R: a long exact launch that writes tables in many slots
+        m = 150000
+        keys = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+        msgs = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+        msgs[:, 31] &= 0x1f
+        pk = ctx.public_keys(keys)
+        r, s, _ = ctx.sign(keys, msgs)
+        r[::4, 40] ^= 2                  # R off the curve, pk on it: the exact item builds a window table of pk in its slot (verify_exact_t)
+        pk[3::64, 5] ^= 2                # ... and a few of the other kind (bit-serial, no table)
+        want = _verify_one_launch(ctx, False, pk, r, s, msgs)
+        ctx.sync()
+        hp = [_pinned_copy(ctx, a) for a in (pk, r, s, msgs)]
+        ok = ctx.host_empty(m)
+        ok[:] = 0xEE
+        # once with the GPU to itself: the staging of the pipeline is sized now (growing it later would free device memory, which waits
+        # for the whole device -- and with it for the launch this test wants to have in flight)
+        ctx._ck(ctx.lib.bjj_eddsa_verify(ctx.handle, hp[0].ctypes.data, hp[1].ctypes.data, hp[2].ctypes.data, hp[3].ctypes.data, m, ok.ctypes.data), "bjj_eddsa_verify")
+        assert (np.asarray(ok) == want).all()
+        ok[:] = 0xEE
+        # two launches on two streams of the caller take BOTH scratch sets (whichever is the least recently used first) and are left
+        # running; the verification through host pointers follows at once
+        Y = torch.cuda.Stream(device=dev)
+        d_out2 = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+        d_out.zero_()
+        torch.cuda.synchronize()
+        ctx.mul_var_base_dev(d_pts.data_ptr(), d_sc.data_ptr(), n, d_out.data_ptr(), X.cuda_stream)
+        ctx.mul_var_base_dev(d_pts.data_ptr(), d_sc.data_ptr(), n, d_out2.data_ptr(), Y.cuda_stream)
+        ctx._ck(ctx.lib.bjj_eddsa_verify(ctx.handle, hp[0].ctypes.data, hp[1].ctypes.data, hp[2].ctypes.data, hp[3].ctypes.data, m, ok.ctypes.data), "bjj_eddsa_verify")
+        got = np.asarray(ok).copy()
+        assert ctx.info().last_var_base_form == 1
+        ctx.sync()
+        assert (got == want).all(), int((got != want).sum())
+        assert bool((d_out == d_ref).all()) and bool((d_out2 == d_ref).all())
+        idx = np.arange(0, n, 40009)
+        assert (d_out.cpu().numpy().reshape(n, 64)[idx] == oracle.mul_var_base(d_pts.cpu().numpy().reshape(n, 64)[idx], sc[idx])).all()
+    finally:
+        ctx.close()
