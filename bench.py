@@ -13,7 +13,12 @@ library's own default is 23 bits).
 N > 1: one process per GPU over RCCL.  `python bench.py --gpus N` launches its N ranks itself (child processes through
 torch.distributed.run, before this process touches a GPU); under an external launcher (WORLD_SIZE set) it is a rank.
 Every rank owns its own 2^20-item block of the global batch -- the path shards with no data-path collective (weak
-scaling) -- and `value` is the whole-job rate: N * batch * K / max-over-ranks time.  The same line carries
+scaling) -- and `value` is the whole-job rate: N * batch * K / max-over-ranks time.
+
+OUTPUT.  stdout gets exactly ONE line, printed last: the compact record of babyjubjub-rs_amd/benchline.py (<= 4 KB: the
+contract's keys, `roofline`, `cpu_baseline`, every other workload as {value, unit, ms_per_step, roofline_frac, valu_frac,
+kernel}).  Everything measured -- per-launch event statistics, clock blocks, notes -- goes to bench_detail.json
+(`--detail-out`) and to stderr as one `bench_detail: {...}` line.  The detail record carries
   also    : the EdDSA-verify and variable-base halves of BASELINE's metric (1 M per GPU), with their own roofline /
             cpu_baseline blocks (1-GPU run) -- same steps / warm-up protocol
   strong  : fixed total work split over the N ranks: 2^20 fixed-base mults, and BASELINE configs[4] = 2^24 verifies,
@@ -221,7 +226,32 @@ def parse():
                          "(1 piece) is timed next to it")
     ap.add_argument("--devices", default=None,
                     help="--native-multi: comma-separated device list (default 0..gpus-1; a device may repeat with --transport peer)")
+    ap.add_argument("--detail-out", default=os.environ.get("BJJ_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")),
+                    help="file that receives EVERYTHING measured (the stdout line is the compact record of babyjubjub-rs_amd/benchline.py: "
+                         "<= 4 KB, numbers only); '' = no file.  The same record goes to stderr as one 'bench_detail: {...}' line")
     return ap.parse_args()
+
+
+DETAIL_OUT = os.path.join(ROOT, "bench_detail.json")   # set from --detail-out in main()
+
+
+def publish(full):
+    """rank 0's output: the full record to DETAIL_OUT and to stderr, then -- as the LAST thing written to stdout -- the one compact
+    line a driver parses (benchline.compact: <= 4 KB by construction)"""
+    from babyjubjub_rs_amd import benchline
+    shown = None
+    if DETAIL_OUT:
+        try:
+            with open(DETAIL_OUT, "w") as fh:
+                json.dump(full, fh, indent=1)
+                fh.write("\n")
+            shown = os.path.relpath(DETAIL_OUT, ROOT) if os.path.abspath(DETAIL_OUT).startswith(ROOT + os.sep) else DETAIL_OUT
+        except OSError as e:      # a read-only checkout must not cost the line
+            sys.stderr.write("bench.py: cannot write %s: %s\n" % (DETAIL_OUT, e))
+    sys.stderr.write("bench_detail: " + json.dumps(full) + "\n")
+    sys.stderr.flush()
+    sys.stdout.write(benchline.dumps(benchline.compact(full, shown)) + "\n")
+    sys.stdout.flush()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -584,6 +614,8 @@ def cpu_baseline(kind, wl, orc, budget_cpu_s=12.0):
                       "thread-count probe; host: %d logical CPUs, %s usable by this process, cgroup CPU quota %s"
                       % (sample, kind, best_t, hc["logical_cpus"], hc.get("affinity_cpus", "?"),
                          "none" if quota is None else quota),
+            "sample_short": "first %d items of the same batch; oracle/bjj_ref.c (C restatement of the reference algorithm), %d pthreads, "
+                            "cgroup CPU quota %s" % (sample, best_t, "none" if quota is None else quota),
             "single_thread_value": rate1, "host": hc}
 
 
@@ -983,7 +1015,7 @@ def run_native_multi(args):
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4] shape", "window_bits": ctx0.info().window_bits},
            "results": out, "parity_sample_ok": ok_all}
-    print(json.dumps(res))
+    publish(res)
     m.close()
     return 0 if ok_all else 3
 
@@ -1024,8 +1056,7 @@ class Headline:
                     r["optional_sections"] = note
                 if not self.parity:
                     r["value"] = None      # a miscomputing build publishes no number
-                sys.stdout.write(json.dumps(r) + "\n")
-                sys.stdout.flush()
+                publish(r)
 
     def abandon(self, note):
         """print what is complete and leave at once (called from the watchdog, or after an exception in an optional section)"""
@@ -1045,6 +1076,8 @@ class Headline:
 
 def main():
     args = parse()
+    global DETAIL_OUT
+    DETAIL_OUT = args.detail_out
     if args.steps is None:
         args.steps = 200 if args.workload == "fixed_base" else 20
     if args.warmup is None:

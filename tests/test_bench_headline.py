@@ -12,6 +12,7 @@ _SCRIPT = r"""
 import sys, time
 sys.path.insert(0, %(root)r)
 import bench
+bench.DETAIL_OUT = ""          # no bench_detail.json from a unit test
 mode = sys.argv[1]
 hl = bench.Headline(int(sys.argv[2]), {"metric": "m", "value": 1.0} if sys.argv[2] == "0" else None, 0.5)
 hl.parity = True
@@ -52,6 +53,7 @@ def test_hang_in_an_optional_section_still_prints_the_headline():
     j = js[0]
     assert j["value"] == 1.0 and j["parity_sample_ok"] is True and j["also"]["verify"]["value"] == 2.0
     assert "abandoned" in j["optional_sections"] and "abandoned" in r.stderr
+    assert "bench_detail: {" in r.stderr                  # the full record goes to stderr, the compact one to stdout
 
 
 def test_other_ranks_leave_silently():

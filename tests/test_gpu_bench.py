@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -14,12 +15,29 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(extra, env_extra=None, timeout=1200):
+    """runs bench.py; returns (process, DETAIL record or None).  The detail record (--detail-out) is what the assertions below read;
+    the stdout contract is checked HERE for every run: exactly one JSON line, printed last, under benchline.HARD_LIMIT bytes, and
+    equal to benchline.compact(detail) -- the round-5 line was 24 KB and the driver could not parse it.  `r.compact` keeps it."""
+    from babyjubjub_rs_amd import benchline
     env = dict(os.environ)
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=timeout)
+    with tempfile.TemporaryDirectory() as td:
+        det = os.path.join(td, "detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + ["--detail-out", det], cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        detail = json.load(open(det)) if os.path.exists(det) else None
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    return r, (json.loads(lines[-1]) if lines else None)
+    r.compact = None
+    if detail is None:
+        assert lines == []
+        return r, None
+    assert len(lines) == 1 and r.stdout.rstrip("\n").splitlines()[-1] == lines[0], r.stdout[-2000:]
+    assert len(lines[0]) < benchline.HARD_LIMIT, len(lines[0])
+    r.compact = json.loads(lines[0])
+    assert r.compact == json.loads(benchline.dumps(benchline.compact(detail, det)))
+    assert "shed_blocks" not in r.compact                      # the budget holds without dropping anything
+    assert ("bench_detail: {" in r.stderr)
+    return r, detail
 
 
 def test_bench_gpus_2_self_launch_shared_gpu():
@@ -74,6 +92,19 @@ def test_bench_one_gpu_line_has_every_block():
                  "--strong-total", str(1 << 18)])
     assert r.returncode == 0, r.stderr[-3000:]
     assert j["n_gpus"] == 1 and j["parity_sample_ok"] and j["roofline"]["frac"] > 0 and j["cpu_baseline"]["value"] > 0
+    # the compact stdout line: the contract's keys with numbers, every other workload as one small row
+    c = r.compact
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity_sample_ok"):
+        assert k in c, k
+    assert c["dtype"] == "u32" and "configs[1]" in c["config"]["workload"] and c["config"]["kernel"] == "bjj_k_mul_fixed_base_2x256"
+    assert set(c["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg"}
+    assert set(c["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and len(c["cpu_baseline"]["sample"]) <= 150
+    assert abs(c["value"] / j["value"] - 1) < 1e-5 and abs(c["ms_per_step"] / j["ms_per_step"] - 1) < 1e-5
+    for k in ("verify", "var_base"):
+        assert set(c["also"][k]) >= {"value", "unit", "ms_per_step", "roofline_frac", "valu_frac", "kernel"} or j["also"][k].get("valu") is None
+    assert c["also"]["fixed_base_window_bits_23"]["value"] > 0 and c["also"]["host_api"]["fixed_base"]["value"] > 0
+    assert c["strong"]["fixed_base_1M_total"]["value"] > 0 and len(json.dumps(c)) < 4096
     assert j["rotating_batches"] == 4 and j["single_batch_kernel_ms"] > 0
     # headline: two-stream protocol, the one-stream control (per-launch HIP events, median) next to it; roofline describes ONE launch
     assert j["streams"] == 2 and j["device_ms_per_launch"] > 0

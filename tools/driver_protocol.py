@@ -56,7 +56,8 @@ def main():
                 e[k] = os.path.join(ROOT, v) if k == "BJJ_LIB_PATH" and not os.path.isabs(v) else v
             t0 = time.time()
             p = subprocess.run(cmd, env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            # the full record is on stderr (`bench_detail: {...}`); stdout carries the compact line the driver parses
+            line = [ln[len("bench_detail: "):] for ln in p.stderr.splitlines() if ln.startswith("bench_detail: {")]
             if p.returncode != 0 or not line:
                 print("round %d %-10s FAILED rc=%d %s" % (r + 1, name, p.returncode, p.stderr[-300:]))
                 continue

@@ -25,6 +25,15 @@ def short(name):
 
 
 def line_of(path):
+    """the bench record of a log: the full `bench_detail: {...}` record bench.py writes to stderr (in the log itself when it holds
+    both streams, else in the .err file next to it), or -- logs of rounds 1-5 -- the last JSON line of stdout"""
+    for p_ in (path, os.path.splitext(path)[0] + ".err"):
+        try:
+            ls = [l[len("bench_detail: "):] for l in open(p_).read().splitlines() if l.startswith("bench_detail: {")]
+            if ls:
+                return json.loads(ls[-1])
+        except Exception:
+            pass
     try:
         ls = [l for l in open(path).read().splitlines() if l.startswith("{")]
         return json.loads(ls[-1]) if ls else None
