@@ -39,6 +39,8 @@ EXPORTED_SYMBOLS = (
     "bjj_mul_fixed_base_multi_dev", "bjj_mul_var_base_multi_dev", "bjj_eddsa_verify_multi_dev",
     "bjj_multi_last_timing", "bjj_multi_set_transport", "bjj_multi_set_chunks", "bjj_multi_last_overlap",
     "bjj_host_alloc", "bjj_host_free", "bjj_host_register", "bjj_host_unregister", "bjj_host_is_pinned",
+    "bjj_mul_fixed_base_compressed", "bjj_public_keys_compressed", "bjj_sign_compressed",
+    "bjj_mul_fixed_base_compressed_dev", "bjj_public_keys_compressed_dev", "bjj_sign_compressed_dev",
 )
 
 
@@ -66,6 +68,7 @@ class BjjInfo(ctypes.Structure):
         ("host_copy_threads", ctypes.c_int),
         ("kernel_fixed_base_overlap", ctypes.c_char_p),
         ("kernel_var_base_overlap", ctypes.c_char_p),
+        ("last_var_base_split", ctypes.c_int),
     ]
 
 
@@ -159,6 +162,12 @@ def load():
     lib.bjj_proj_add_dev.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.bjj_proj_affine.argtypes = [vp, vp, sz, vp]
     lib.bjj_proj_affine_dev.argtypes = [vp, vp, sz, vp, vp]
+    lib.bjj_mul_fixed_base_compressed.argtypes = [vp, vp, sz, vp]
+    lib.bjj_public_keys_compressed.argtypes = [vp, vp, sz, vp]
+    lib.bjj_sign_compressed.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.bjj_mul_fixed_base_compressed_dev.argtypes = [vp, vp, sz, vp, vp]
+    lib.bjj_public_keys_compressed_dev.argtypes = [vp, vp, sz, vp, vp]
+    lib.bjj_sign_compressed_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     # multi-GPU
     pd = ctypes.POINTER(ctypes.c_double)
     lib.bjj_multi_init.argtypes = [ctypes.POINTER(ci), ci, ci, ctypes.POINTER(vp)]

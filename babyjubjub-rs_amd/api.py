@@ -165,6 +165,14 @@ class Context:
         self._ck(self.lib.bjj_mul_fixed_base(self.handle, s.ctypes.data, n, out.ctypes.data), "bjj_mul_fixed_base")
         return out.reshape(n, 64)
 
+    def mul_fixed_base_compressed(self, scalars):
+        """B8.mul_scalar(n).compress() in one pass (lib.rs:149-164 + 166-178) -> (n, 32)"""
+        s = _as_u8(scalars, 32, "scalars")
+        n = s.size // 32
+        out = np.empty(n * 32, dtype=np.uint8)
+        self._ck(self.lib.bjj_mul_fixed_base_compressed(self.handle, s.ctypes.data, n, out.ctypes.data), "bjj_mul_fixed_base_compressed")
+        return out.reshape(n, 32)
+
     def mul_var_base(self, points, scalars):
         p = _as_u8(points, 64, "points")
         s = _as_u8(scalars, 32, "scalars")
@@ -269,6 +277,26 @@ class Context:
         out = np.empty(n * 64, dtype=np.uint8)
         self._ck(self.lib.bjj_public_keys(self.handle, a.ctypes.data, n, out.ctypes.data), "bjj_public_keys")
         return out.reshape(n, 64)
+
+    def public_keys_compressed(self, keys):
+        """sk.public().compress() in one pass (lib.rs:304-306 + 166-178) -> (n, 32)"""
+        a = _as_u8(keys, 32, "keys")
+        n = a.size // 32
+        out = np.empty(n * 32, dtype=np.uint8)
+        self._ck(self.lib.bjj_public_keys_compressed(self.handle, a.ctypes.data, n, out.ctypes.data), "bjj_public_keys_compressed")
+        return out.reshape(n, 32)
+
+    def sign_compressed(self, keys, msgs):
+        """sk.sign(msg)?.compress() in one pass (lib.rs:308-342 + 245-258) -> (sig (n, 64), ok (n,)); ok == 0 (sig all-zero) for Err"""
+        a = _as_u8(keys, 32, "keys")
+        m = _as_u8(msgs, 32, "msgs")
+        n = a.size // 32
+        if m.size != a.size:
+            raise BjjError("sign_compressed: array lengths disagree")
+        sig = np.empty(n * 64, dtype=np.uint8)
+        ok = np.empty(n, dtype=np.uint8)
+        self._ck(self.lib.bjj_sign_compressed(self.handle, a.ctypes.data, m.ctypes.data, n, sig.ctypes.data, ok.ctypes.data), "bjj_sign_compressed")
+        return sig.reshape(n, 64), ok
 
     def sign(self, keys, msgs):
         """-> (r_b8 (n, 64), s (n, 32), ok (n,)); ok == 0 where the reference returns Err (msg > Q)"""
@@ -377,6 +405,15 @@ class Context:
 
     def public_keys_dev(self, d_keys, n, d_out, stream=0):
         self._ck(self.lib.bjj_public_keys_dev(self.handle, d_keys, n, d_out, stream), "bjj_public_keys_dev")
+
+    def mul_fixed_base_compressed_dev(self, d_scalars, n, d_out32, stream=0):
+        self._ck(self.lib.bjj_mul_fixed_base_compressed_dev(self.handle, d_scalars, n, d_out32, stream), "bjj_mul_fixed_base_compressed_dev")
+
+    def public_keys_compressed_dev(self, d_keys, n, d_out32, stream=0):
+        self._ck(self.lib.bjj_public_keys_compressed_dev(self.handle, d_keys, n, d_out32, stream), "bjj_public_keys_compressed_dev")
+
+    def sign_compressed_dev(self, d_keys, d_msgs, n, d_sig64, d_ok, stream=0):
+        self._ck(self.lib.bjj_sign_compressed_dev(self.handle, d_keys, d_msgs, n, d_sig64, d_ok, stream), "bjj_sign_compressed_dev")
 
     def scalar_keys_dev(self, d_keys, n, d_out, stream=0):
         self._ck(self.lib.bjj_scalar_keys_dev(self.handle, d_keys, n, d_out, stream), "bjj_scalar_keys_dev")
@@ -574,6 +611,10 @@ class Signature:
     def __init__(self, r_b8, s):
         self.r_b8 = r_b8
         self.s = int(s)
+
+    def compress(self, ctx=None):  # lib.rs:245-258 -> 64 bytes: compressed R, then the first 32 little-endian bytes of s
+        s_le = self.s.to_bytes(max(32, (self.s.bit_length() + 7) // 8), "little")[:32]
+        return self.r_b8.compress(ctx) + s_le
 
 
 class PrivateKey:

@@ -40,7 +40,7 @@
 
 using namespace bjj;
 
-#define BJJ_VERSION_STRING "bjj-hip 0.5.0 gfx950"
+#define BJJ_VERSION_STRING "bjj-hip 0.6.0 gfx950"
 // Fixed-base window width.  window_bits = 0 (default) is a modest 23 bits = 11 signed digits, 5.9 GB: a library that
 // is linked into a process with other tenants of the GPU must not take half of the HBM unasked.  The wide tables are
 // opt-in: an explicit width (28 bits = 9 digits, 9 x (2^27 + 1) entries = 154.6 GB of the 288 GB; 26 = 10 digits,
@@ -101,6 +101,8 @@ struct ScratchSet {
   u32 slot_cap = 0;            // slots per XCD
   uint8_t* codec = nullptr;    // verify_compressed: n * (64 pk + 64 R + 32 s + 2 flags) bytes; public_keys: the scalar keys
   size_t codec_items = 0;
+  uint8_t* xy = nullptr;       // K1 with compressed output: n * 64 B, the phase-1 stash of X, Y (the 32-byte output slot cannot hold it)
+  size_t xy_items = 0;
   // Ordering of the set: every call that uses it records `ev_last` on its stream after enqueueing, and a call on a
   // DIFFERENT stream first makes its stream wait for it.  Calls return before the work runs, so "serialised by the
   // caller" alone would not order execution.
@@ -130,6 +132,16 @@ struct bjj_ctx {
   int k2_variant = -1;           // -1 = per call (tiles for a launch that runs alone, grid-strided while another is in flight), 0 / 1 = forced (BJJ_K2_VARIANT)
   int k1_variant = -1;           // -1 = per call (two-workgroup shape while another launch of the context is in flight), 0 / 1 = forced (BJJ_K1_VARIANT)
   int occ_poseidon = 1, occ_verify = 1, occ_scan = 1, occ_add = 1;
+  // Variable base, off-curve points (k_var.hip): K6 runs BEHIND K2 on the caller's stream (nothing extra for a clean batch) or,
+  // with the list made by a scan, BESIDE it on the set's priority stream.  -1 = per call by what the previous calls met
+  // (vb_seen: one device-visible pinned word per scratch set, written by K6 with the number of items it had), 0 / 1 = forced
+  // (BJJ_VB_SPLIT)
+  int vb_split = -1;
+  int occ_vb_scan = 1;
+  u32* vb_seen = nullptr;                  // [BJJ_SCRATCH_SETS] per set (device-pointer calls) + [1] the host-pointer pipeline
+  int last_vb_split = -1;
+  uint8_t* patch_host = nullptr;           // host-pointer pipeline: K6's results on their way into the caller's array (pinned)
+  size_t patch_host_bytes = 0;
   int xccs = 1;                // XCDs of the device (probed at init; sizes the verify kernels' slot queues)
   int occ_decomp = 1, occ_sign = 1, occ_sign_schnorr = 1;
   // signer hardening (bjj_set_signer_constant_time): a second, small fixed-base table (4-bit windows: 63 x 9 entries) that
@@ -171,6 +183,7 @@ struct bjj_ctx {
   CopyPool* pool = nullptr;
   size_t pipe_chunk = 0, pipe_first = 0;   // chunk schedule (items): first chunk, doubling up to pipe_chunk
   bool pipe_env_schedule = false;          // ... given in the environment: it overrides the entry points' own schedules too
+  bool pipe_ready = false;                 // ensure_pipe's first-use block ran to its end
   bool in_pipeline = false;                // a host-pointer call is enqueueing (enqueue_verify: where the scans run)
   bool pipe_scan_inline = true;            // BJJ_PIPE_SCAN=prio (developer): scans of the pipeline's chunks on the priority streams
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
@@ -429,16 +442,21 @@ struct PipeSpec {
   struct PipeExtra* extra = nullptr;   // stages beside the chunk launches (below)
   bool out_at_end = false;             // outputs leave the device once, after everything (they are not final chunk by chunk)
   size_t first_chunk = 0, max_chunk = 0;   // chunk schedule of this entry point (items; 0 = the context's, which the environment overrides)
+  size_t extra_dev_per_item = 0;           // bytes of device staging per item for `extra` (PipeExtra::d_extra), beside the arrays
 };
 // Work of a pipelined call that does not belong to ONE chunk.  All three run on the calling thread while it enqueues:
 //   begin          once per super-batch, before the first copy; d_in / d_out = the staging arrays of the whole super-batch
 //   chunk_arrived  behind the H2D of items lo .. lo+cnt-1 (ev_in of the chunk has been recorded: make a stream wait for it)
 //   all_arrived    behind the last chunk; whatever it enqueues is covered by ev_tail, which the call waits for before it copies
 //                  `out_at_end` outputs and returns
+//   finish         last: every copy of the super-batch has landed in the caller's arrays (host_out = where its outputs begin), every
+//                  stream of the pipeline and ev_tail are done -- host-side work on the results
 struct PipeExtra {
+  void* d_extra = nullptr;     // n * PipeSpec::extra_dev_per_item bytes of the super-batch's device staging (set before begin)
   virtual int begin(size_t n, void** d_in, void** d_out) = 0;
   virtual int chunk_arrived(size_t lo, size_t cnt, hipEvent_t arrived) = 0;
   virtual int all_arrived(hipEvent_t ev_tail) = 0;
+  virtual int finish(uint8_t* const* host_out, size_t n) { (void)host_out; (void)n; return BJJ_OK; }
   virtual ~PipeExtra() {}
 };
 static size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -491,22 +509,9 @@ static size_t env_items(const char* name, size_t dflt) {
 // part -- the pinned rings (in_ring / out_ring bytes per slot) and the copy workers
 static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ring, size_t out_ring) {
   ENTER_DEVICE(c->device);
-  if (!c->s_in) {
-    int least = 0, greatest = 0;
-    HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    int prio_in = greatest, prio_out = greatest;
-    if (const char* e = getenv("BJJ_PIPE_COPY_PRIORITY")) {   // developer: "nn" / "hn" / "nh" / "hh" = normal / high for s_in, s_out
-      if (e[0] == 'n') prio_in = 0;
-      if (e[0] && e[1] == 'n') prio_out = 0;
-    }
-    HIPCK(hipStreamCreateWithPriority(&c->s_in, hipStreamNonBlocking, prio_in));
-    HIPCK(hipStreamCreateWithPriority(&c->s_out, hipStreamNonBlocking, prio_out));
-    // the second lane is a high-priority stream as well: HIP gives the streams of one priority FOUR hardware queues, and a
-    // library that parks two normal-priority streams in them (the context's own stream is one) leaves the caller's streams to
-    // share what is left -- two torch streams first used after a host-pointer call landed on ONE hardware queue and their
-    // launches ran one after the other (tools/queue_map_probe.py, profiles/r05_host_pipeline.txt)
-    HIPCK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
-    HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+  // first use: the knobs first (they cannot fail), then whatever of streams / event is still missing; `pipe_ready` only when all of it
+  // exists -- a call after a failed first use comes through here again instead of running with a zero chunk size
+  if (!c->pipe_ready) {
     c->pipe_env_schedule = getenv("BJJ_PIPE_CHUNK") || getenv("BJJ_PIPE_FIRST_CHUNK");
     c->pipe_chunk = env_items("BJJ_PIPE_CHUNK", BJJ_PIPE_CHUNK);
     c->pipe_first = env_items("BJJ_PIPE_FIRST_CHUNK", BJJ_PIPE_FIRST_CHUNK);
@@ -515,6 +520,22 @@ static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ri
     if (const char* e = getenv("BJJ_PIPE_STAGING_MB")) { const long v = atol(e); if (v >= 1 && v <= 65536) c->pipe_budget = (size_t)v << 20; }
     if (const char* e = getenv("BJJ_HOST_FORCE_STAGED")) c->force_staged = e[0] == '1';
     if (const char* e = getenv("BJJ_PIPE_SCAN")) c->pipe_scan_inline = e[0] != 'p';
+    int least = 0, greatest = 0;
+    HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int prio_in = greatest, prio_out = greatest;
+    if (const char* e = getenv("BJJ_PIPE_COPY_PRIORITY")) {   // developer: "nn" / "hn" / "nh" / "hh" = normal / high for s_in, s_out
+      if (e[0] == 'n') prio_in = 0;
+      if (e[0] && e[1] == 'n') prio_out = 0;
+    }
+    if (!c->s_in) HIPCK(hipStreamCreateWithPriority(&c->s_in, hipStreamNonBlocking, prio_in));
+    if (!c->s_out) HIPCK(hipStreamCreateWithPriority(&c->s_out, hipStreamNonBlocking, prio_out));
+    // the second lane is a high-priority stream as well: HIP gives the streams of one priority FOUR hardware queues, and a
+    // library that parks two normal-priority streams in them (the context's own stream is one) leaves the caller's streams to
+    // share what is left -- two torch streams first used after a host-pointer call landed on ONE hardware queue and their
+    // launches ran one after the other (tools/queue_map_probe.py, profiles/r05_host_pipeline.txt)
+    if (!c->stream2) HIPCK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
+    if (!c->ev_tail) HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    c->pipe_ready = true;
   }
   try {
     while (c->ev_in.size() < chunks) {
@@ -558,8 +579,26 @@ static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ri
 // One super-batch of at most `cap` items (everything fits in the device staging).  launch(d_in[], d_out[], count, stream)
 // enqueues the kernels of one chunk on `stream`.
 template <typename Launch>
+static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool* in_direct, const bool* out_direct, u32 n_staged, Launch& launch,
+                                u32* chunks_out);
+// The body allocates (chunk schedule, copy groups, the workers' queue): a std::bad_alloc must not cross the extern "C" boundary,
+// and nothing may still be copying into the caller's memory or out of the rings when the call returns.
+template <typename Launch>
 static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool* in_direct, const bool* out_direct, u32 n_staged, Launch& launch,
                            u32* chunks_out) {
+  try {
+    return run_super_batch_body(c, n, sp, in_direct, out_direct, n_staged, launch, chunks_out);
+  } catch (...) {
+    // only the allocations at the head of the body can throw (the chunk schedule, the copy groups, the timing marks): no worker
+    // holds a task yet (CopyPool::submit does not throw), the device has at most a list reset queued
+    hipDeviceSynchronize();
+    (void)hipGetLastError();
+    return set_err(BJJ_E_NOMEM, "host-pointer pipeline: out of host memory");
+  }
+}
+template <typename Launch>
+static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool* in_direct, const bool* out_direct, u32 n_staged, Launch& launch,
+                                u32* chunks_out) {
   // ---- chunk schedule: first, 2 first, 4 first ... capped at pipe_chunk; a remainder below half a chunk joins the last chunk
   std::vector<size_t> lo_of;     // lo_of[ch] .. lo_of[ch + 1]
   {
@@ -582,6 +621,8 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
   size_t d_in_off[4], d_out_off[4], r_in_off[4], r_out_off[4], dev_tot = 0, in_ring = 0, out_ring = 0;
   for (int i = 0; i < sp.n_in; i++) { d_in_off[i] = dev_tot; dev_tot += up256(n * sp.in_stride[i]); }
   for (int i = 0; i < sp.n_out; i++) { d_out_off[i] = dev_tot; dev_tot += up256(n * sp.out_stride[i]); }
+  const size_t d_extra_off = dev_tot;
+  dev_tot += up256(n * sp.extra_dev_per_item);
   for (int i = 0; i < sp.n_in; i++) if (!in_direct[i]) { r_in_off[i] = in_ring; in_ring += up16(max_chunk * sp.in_stride[i]); }
   // outputs that leave at the end go through ONE ring slot that holds the whole array
   for (int i = 0; i < sp.n_out; i++) if (!out_direct[i]) { r_out_off[i] = out_ring; out_ring += up16((sp.out_at_end ? n : max_chunk) * sp.out_stride[i]); }
@@ -591,6 +632,7 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
     void* bi[4]; void* bo[4];
     for (int i = 0; i < sp.n_in; i++) bi[i] = c->dstage + d_in_off[i];
     for (int i = 0; i < sp.n_out; i++) bo[i] = c->dstage + d_out_off[i];
+    sp.extra->d_extra = sp.extra_dev_per_item ? c->dstage + d_extra_off : nullptr;
     int rc = sp.extra->begin(n, bi, bo); if (rc) return rc;
   }
   *chunks_out += (u32)nchunks;
@@ -730,6 +772,7 @@ static int run_super_batch(bjj_ctx* c, size_t n, const PipeSpec& sp, const bool*
   };
   int rc = body();
   tr("all chunks finished", nchunks);
+  if (!rc && sp.extra) { rc = sp.extra->finish(sp.out, n); tr("extra stages finished on the host", nchunks); }
   if (trace && !rc) {
     for (size_t ch = 0; ch < nchunks; ch++) {
       float t[3] = {0, 0, 0};
@@ -766,9 +809,11 @@ static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch
   size_t per_item = 0;
   for (int i = 0; i < sp.n_in; i++) { in_direct[i] = !c->force_staged && host_range_pinned(sp.in[i], n * sp.in_stride[i]); (in_direct[i] ? n_direct : n_staged)++; per_item += sp.in_stride[i]; }
   for (int i = 0; i < sp.n_out; i++) { out_direct[i] = !c->force_staged && host_range_pinned(sp.out[i], n * sp.out_stride[i]); (out_direct[i] ? n_direct : n_staged)++; per_item += sp.out_stride[i]; }
+  per_item += sp.extra_dev_per_item;
   // ---- super-batches: what fits into the device staging budget at once (2^20 verifications are 202 MB)
   size_t cap = c->pipe_budget / per_item;
   cap = cap > c->pipe_chunk ? cap / c->pipe_chunk * c->pipe_chunk : c->pipe_chunk;
+  if (!cap) return set_err(BJJ_E_HIP, "host-pointer pipeline: not initialised (chunk size 0)");   // the loop below would never advance
   u32 chunks = 0;
   int rc = BJJ_OK;
   c->in_pipeline = true;
@@ -782,8 +827,17 @@ static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch
   c->in_pipeline = false;
   c->last_host_direct = n_direct; c->last_host_staged = n_staged; c->last_host_chunks = chunks;
   // the call has synchronised for the caller: a verify / variable-base workgroup that gave up waiting for a table slot makes
-  // it an error here, not at some later bjj_sync
-  if (!rc) rc = ctx_check_slot_queues(c, "host-pointer call");
+  // it an error here, not at some later bjj_sync.  Only the pipeline's OWN streams have been waited for: while a
+  // device-pointer launch of the caller is still in flight on one of the sets, its workgroups are popping and pushing the rings --
+  // reading them now could miss an error that comes later (and clear rings_used, so that bjj_sync would skip the check), and
+  // rebuilding one would hand a slot out twice.  The check then stays pending for the next synchronising call.
+  if (!rc) {
+    bool busy = false;
+    for (const ScratchSet& S : c->set)
+      if (S.have_last && hipEventQuery(S.ev_last) == hipErrorNotReady) busy = true;
+    (void)hipGetLastError();
+    if (!busy) rc = ctx_check_slot_queues(c, "host-pointer call");
+  }
   return rc;
 }
 static int ensure_codec(bjj_ctx* c, ScratchSet* S, size_t n) {  // 162 bytes per item of intermediate records
@@ -791,6 +845,14 @@ static int ensure_codec(bjj_ctx* c, ScratchSet* S, size_t n) {  // 162 bytes per
     if (S->codec) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->codec)); S->codec = nullptr; S->codec_items = 0; }
     HIPCK(hipMalloc((void**)&S->codec, n * 162 + 64));
     S->codec_items = n;
+  }
+  return BJJ_OK;
+}
+static int ensure_xy(bjj_ctx* c, ScratchSet* S, size_t n) {     // 64 bytes per item: X, Y of phase 1 when the output slot is 32 bytes
+  if (n > S->xy_items) {
+    if (S->xy) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(S->xy)); S->xy = nullptr; S->xy_items = 0; }
+    HIPCK(hipMalloc((void**)&S->xy, n * 64));
+    S->xy_items = n;
   }
   return BJJ_OK;
 }
@@ -805,6 +867,7 @@ static void ctx_destroy(bjj_ctx* c) {
     if (S.scratch) hipFree(S.scratch);
     if (S.vb_tables) hipFree(S.vb_tables);
     if (S.slow) hipFree(S.slow);
+    if (S.xy) hipFree(S.xy);
     if (S.ev_scan_in) hipEventDestroy(S.ev_scan_in);
     if (S.ev_scan_out) hipEventDestroy(S.ev_scan_out);
     if (S.scan_stream) hipStreamDestroy(S.scan_stream);
@@ -828,6 +891,8 @@ static void ctx_destroy(bjj_ctx* c) {
   if (c->pipe_wl) hipFree(c->pipe_wl);
   for (hipEvent_t e : c->ev_k) hipEventDestroy(e);
   if (c->err_words) hipHostFree(c->err_words);
+  if (c->vb_seen) hipHostFree(c->vb_seen);
+  if (c->patch_host) hipHostFree(c->patch_host);
   if (c->slot_block) hipFree(c->slot_block);
   if (c->s_in) hipStreamDestroy(c->s_in);
   if (c->s_out) hipStreamDestroy(c->s_out);
@@ -884,6 +949,10 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   if (const char* e = getenv("BJJ_K1_VARIANT")) {   // tests / A-B: force one shape of the fixed-base kernel
     if (e[0] == '0' || e[0] == '1') c->k1_variant = e[0] - '0';
   }
+  if (const char* e = getenv("BJJ_VB_SPLIT")) {     // tests / A-B: K6 always behind K2 (0) or always beside it, behind a scan (1)
+    if (e[0] == '0' || e[0] == '1') c->vb_split = e[0] - '0';
+  }
+  c->occ_vb_scan = bjjk::occ_var_base_scan();
   c->lanes_var = bjjk::var_base_lanes_per_cu();
   c->occ_poseidon = bjjk::occ_poseidon5();
   c->occ_verify = bjjk::occ_verify();
@@ -893,7 +962,9 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   c->occ_sign = bjjk::occ_sign();
   c->occ_sign_schnorr = bjjk::occ_sign_schnorr();
   hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (se != hipSuccess) { ctx_destroy(c); return set_err(BJJ_E_HIP, std::string("bjj_init: stream/event: ") + hipGetErrorString(se)); }
+  if (se == hipSuccess) se = hipHostMalloc((void**)&c->vb_seen, (BJJ_SCRATCH_SETS + 1) * sizeof(u32), hipHostMallocDefault);
+  if (se != hipSuccess) { (void)hipGetLastError(); ctx_destroy(c); return set_err(BJJ_E_HIP, std::string("bjj_init: stream/event: ") + hipGetErrorString(se)); }
+  memset(c->vb_seen, 0, (BJJ_SCRATCH_SETS + 1) * sizeof(u32));
   {  // XCDs of this device (the verify kernels keep one queue of table slots per XCD)
     u32* d_word = nullptr;
     if (hipMalloc((void**)&d_word, sizeof(u32)) == hipSuccess) {
@@ -1044,7 +1115,7 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   info->scratch_bytes = (uint64_t)c->pipe_bytes;
   for (const ScratchSet& S : c->set)
     info->scratch_bytes += S.scratch_items * 64 + S.vb_threads * VB_TABLE_WORDS_MAX * sizeof(u32) + S.slow_items * 4 +
-                           (S.codec_items ? S.codec_items * 162 + 64 : 0);
+                           (S.codec_items ? S.codec_items * 162 + 64 : 0) + S.xy_items * 64;
   info->kernel_fixed_base = "bjj_k_mul_fixed_base";
   info->kernel_var_base = "bjj_k_mul_var_base_tiles";   // the form a launch that runs alone gets (k_var.hip)
   info->kernel_poseidon5 = "bjj_k_poseidon5";
@@ -1053,6 +1124,7 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   info->signer_constant_time = c->ct_signer ? 1 : 0;
   info->last_fixed_base_shape = c->last_k1;
   info->last_var_base_form = c->last_k2;
+  info->last_var_base_split = c->last_vb_split;
   info->last_verify_dispatch = c->last_verify_mode;
   info->last_host_direct_arrays = c->last_host_direct;
   info->last_host_staged_arrays = c->last_host_staged;
@@ -1103,44 +1175,195 @@ int bjj_check_table(bjj_ctx* c, uint64_t* n_bad) {
     if (with_codec) { rc_ = ensure_codec((c), S, (n)); if (rc_) return rc_; } \
     rc_ = set_enter((c), S, st); if (rc_) return rc_; }
 #define SET_LEAVE(c) return set_leave((c), S, st)
+#define LAUNCHCK_S(expr, who)                                                                       \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return set_err(BJJ_E_HIP, std::string(who) + ": " + hipGetErrorString(e_)); \
+  } while (0)
 #define LAUNCHCK(expr, name)                                                                        \
   do {                                                                                              \
     hipError_t e_ = (expr);                                                                         \
     if (e_ != hipSuccess) return set_err(BJJ_E_HIP, std::string(name ": ") + hipGetErrorString(e_)); \
   } while (0)
 
-int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_out, void* stream) {
-  CHECK_CTX(c, "bjj_mul_fixed_base_dev");
+static int ensure_scan_stream(ScratchSet* S) {
+  if (!S->scan_stream) {
+    int least = 0, greatest = 0;
+    HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCK(hipStreamCreateWithPriority(&S->scan_stream, hipStreamNonBlocking, greatest));
+    HIPCK(hipEventCreateWithFlags(&S->ev_scan_in, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&S->ev_scan_out, hipEventDisableTiming));
+  }
+  return BJJ_OK;
+}
+// compressed: d_out holds 32-byte Point::compress records (src/lib.rs:166-178), the compression fused into K1's epilogue
+static int fixed_base_launch(bjj_ctx* c, const void* d_scalars, size_t n, void* d_out, void* stream, bool compressed, const char* who) {
+  if (!c) return set_err(BJJ_E_INVALID, std::string(who) + ": ctx is NULL");
   if (n == 0) return BJJ_OK;
   CHECK_N(n);
-  CHECK_PTR(d_scalars, "bjj_mul_fixed_base_dev"); CHECK_PTR(d_out, "bjj_mul_fixed_base_dev");
+  if (!d_scalars || !d_out || !aligned16(d_scalars) || !aligned16(d_out))
+    return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   SET_ENTER(c, stream, n, false);
+  if (compressed) { int rc_ = ensure_xy(c, S, n); if (rc_) return rc_; }
   const int kv = fixed_base_variant(c, S);
   LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, kv ? c->lanes_fixed_2x256 : c->lanes_fixed, kv, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
-                                (uint8_t*)d_out, S->scratch), "bjj_mul_fixed_base_dev");
+                                (uint8_t*)d_out, S->scratch, compressed ? S->xy : nullptr), "bjj_mul_fixed_base_dev");
   SET_LEAVE(c);
 }
-static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t scalar_bytes, size_t n, void* d_out,
-                           void* stream, const char* who) {
+int bjj_mul_fixed_base_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_out, void* stream) {
+  return fixed_base_launch(c, d_scalars, n, d_out, stream, false, "bjj_mul_fixed_base_dev");
+}
+int bjj_mul_fixed_base_compressed_dev(bjj_ctx* c, const void* d_scalars, size_t n, void* d_out32, void* stream) {
+  return fixed_base_launch(c, d_scalars, n, d_out32, stream, true, "bjj_mul_fixed_base_compressed_dev");
+}
+// Off-curve points (k_var.hip): which form does this call take?  Forced by BJJ_VB_SPLIT, else by what K6 found in the calls that have
+// COMPLETED so far (K6 writes its item count into the set's pinned word; a call that is still in flight has not reported yet, so a
+// caller that enqueues many launches without synchronising gets one form for all of them).
+static bool vb_want_split(const bjj_ctx* c) {
+  if (c->vb_split >= 0) return c->vb_split == 1;
+  u32 any = 0;
+  for (int k = 0; k <= BJJ_SCRATCH_SETS; k++) any |= __atomic_load_n(&c->vb_seen[k], __ATOMIC_RELAXED);
+  return any != 0;
+}
+static int var_base_check(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t scalar_bytes, size_t n, void* d_out, const char* who) {
   if (!c) return set_err(BJJ_E_INVALID, std::string(who) + ": ctx is NULL");
   if (scalar_bytes == 0 || (scalar_bytes & 31) || scalar_bytes > BJJ_MAX_SCALAR_BYTES)
     return set_err(BJJ_E_INVALID, std::string(who) + ": scalar_bytes must be a multiple of 32 in 32..BJJ_MAX_SCALAR_BYTES");
-  if (n == 0) return BJJ_OK;
-  CHECK_N(n);
-  if (!d_pts || !d_scalars || !d_out || !aligned16(d_pts) || !aligned16(d_scalars) || !aligned16(d_out))
+  if (n >> 32) return set_err(BJJ_E_INVALID, "batches are limited to 2^32 - 1 items per call");
+  if (n && (!d_pts || !d_scalars || !d_out || !aligned16(d_pts) || !aligned16(d_scalars) || !aligned16(d_out)))
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
-  SET_ENTER(c, stream, n, false);
-  // k_var.hip: the two forms of K2 -- tiles for a launch that runs alone, grid-strided for overlapping launches
-  // (expect_overlap).  A large launch queues behind the other sets and runs alone (tiles).
+  return BJJ_OK;
+}
+// k_var.hip: the two forms of K2 -- tiles for a launch that runs alone, grid-strided for overlapping launches (expect_overlap).
+// A large launch queues behind the other sets and runs alone (tiles).
+static int var_base_form(bjj_ctx* c, ScratchSet* S, hipStream_t st, size_t n, int* kv_out) {
   bool overlap = c->k2_variant < 0 && expect_overlap(c, S);
   if (overlap && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; overlap = false; }
   const int kv = c->k2_variant >= 0 ? c->k2_variant : (overlap ? 0 : 1);
   c->last_k2 = kv;
   if (kv == 1) c->rings_used = true;      // the tiles take their table scratch from the slot queues
-  LAUNCHCK(bjjk::mul_var_base(st, c->cus, c->lanes_var, kv, c->cus * 4, (const uint8_t*)d_pts, (const uint8_t*)d_scalars,
-                              (int)(scalar_bytes / 4), n, (uint8_t*)d_out, S->scratch, S->vb_tables, S->slow, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)),
-           "bjj_mul_var_base_dev");
+  *kv_out = kv;
+  return BJJ_OK;
+}
+// One device-pointer call.  Clean batches (every point on the curve -- what the history says): K2 makes the list of the items it
+// skips, K6 follows on the caller's stream and finds it empty: nothing extra.  Once a completed call has met an off-curve point:
+//   caller's stream:   ------------------------- K2 (skips them, no list) ------------------------ wait --
+//   priority stream:   wait -- scan (the list) -- K6 (its ~4.5 ms serial chains, a few waves) ---- record
+// so that the malformed items cost their share of the chip instead of a launch-long tail: one off-curve point in 4 096 was +30 % on
+// a 2^20-item launch with K6 behind K2 (profiles/r05_var_base_offcurve.txt); beside it, see profiles/r06_var_base_offcurve.txt.
+static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t scalar_bytes, size_t n, void* d_out,
+                           void* stream, const char* who) {
+  { int rc_ = var_base_check(c, d_pts, d_scalars, scalar_bytes, n, d_out, who); if (rc_) return rc_; }
+  if (n == 0) return BJJ_OK;
+  SET_ENTER(c, stream, n, false);
+  int kv = 0;
+  { int rc_ = var_base_form(c, S, st, n, &kv); if (rc_) return rc_; }
+  const uint8_t* pts = (const uint8_t*)d_pts;
+  const uint8_t* sc = (const uint8_t*)d_scalars;
+  const int sc_words = (int)(scalar_bytes / 4);
+  u32* seen = &c->vb_seen[S - c->set];
+  const bool split = vb_want_split(c);
+  c->last_vb_split = split ? 1 : 0;
+  if (split) {
+    { int rc_ = ensure_scan_stream(S); if (rc_) return rc_; }
+    HIPCK(hipEventRecord(S->ev_scan_in, st));
+    HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));
+    LAUNCHCK(bjjk::var_base_list_reset(S->scan_stream, S->slow), "variable-base list");
+    LAUNCHCK(bjjk::var_base_scan(S->scan_stream, grid_for(c, n, c->occ_vb_scan, 64), pts, 0, n, S->slow), "variable-base scan");
+    LAUNCHCK(bjjk::mul_var_base_exact(S->scan_stream, c->cus * 4, pts, sc, sc_words, (uint8_t*)d_out, S->slow, nullptr, seen), "variable-base (exact)");
+    HIPCK(hipEventRecord(S->ev_scan_out, S->scan_stream));
+  }
+  LAUNCHCK_S(bjjk::mul_var_base_main(st, c->cus, c->lanes_var, kv, pts, sc, sc_words, n, (uint8_t*)d_out, S->scratch, S->vb_tables, split ? nullptr : S->slow,
+                                     S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)), who);
+  if (split) HIPCK(hipStreamWaitEvent(st, S->ev_scan_out, 0));
+  else LAUNCHCK(bjjk::mul_var_base_exact(st, c->cus * 4, pts, sc, sc_words, (uint8_t*)d_out, S->slow, nullptr, seen), "variable-base (exact)");
   SET_LEAVE(c);
+}
+// ---- variable base through the host-pointer pipeline: the cure verify got in round 5 (VerifyPipe below) -----------------------
+//   per chunk, behind its H2D:  the on-curve scan of its points on the priority stream, appending batch-wide indices to ONE list;
+//                               K2 over its items on its lane -- K2 skips an off-curve item by itself and never writes its slot
+//   behind the last scan:       ONE K6 launch over the list on the priority stream, results COMPACT beside the list (d_extra): a
+//                               chunk's outputs leave the device when its K2 is done, long before K6 is
+//   when everything has landed: the host lays the few exact results over their slots in the caller's array
+// Before: K6 behind K2 in EVERY chunk's lane -- one off-curve point in 4 096 cost 2^20 items on pinned memory +71 % (15.9 ->
+// 27.3 ms, profiles/r05_var_base_offcurve.txt).
+static int var_base_bulk_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t scalar_bytes, size_t n, void* d_out, void* stream) {
+  SET_ENTER(c, stream, n, false);
+  int kv = 0;
+  { int rc_ = var_base_form(c, S, st, n, &kv); if (rc_) return rc_; }
+  c->last_vb_split = 1;
+  LAUNCHCK(bjjk::mul_var_base_main(st, c->cus, c->lanes_var, kv, (const uint8_t*)d_pts, (const uint8_t*)d_scalars, (int)(scalar_bytes / 4), n, (uint8_t*)d_out,
+                                   S->scratch, S->vb_tables, nullptr, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)), "variable base (bulk)");
+  SET_LEAVE(c);
+}
+struct VarBasePipe : PipeExtra {
+  bjj_ctx* c;
+  int sc_words;
+  const uint8_t *pts = nullptr, *scalars = nullptr;
+  size_t n = 0;
+  VarBasePipe(bjj_ctx* c_, size_t scalar_bytes) : c(c_), sc_words((int)(scalar_bytes / 4)) {}
+  int begin(size_t n_, void** d_in, void** d_out) override {
+    (void)d_out;
+    n = n_;
+    pts = (const uint8_t*)d_in[0]; scalars = (const uint8_t*)d_in[1];
+    ScratchSet* S = &c->set[0];
+    { int rc_ = ensure_scan_stream(S); if (rc_) return rc_; }
+    if (n > c->pipe_wl_items) {
+      if (c->pipe_wl) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->pipe_wl)); c->pipe_wl = nullptr; c->pipe_wl_items = 0; }
+      HIPCK(hipMalloc((void**)&c->pipe_wl, (n + 16) * sizeof(u32)));
+      c->pipe_wl_items = n;
+    }
+    LAUNCHCK(bjjk::var_base_list_reset(S->scan_stream, c->pipe_wl), "variable-base list");
+    return BJJ_OK;
+  }
+  int chunk_arrived(size_t lo, size_t cnt, hipEvent_t arrived) override {
+    ScratchSet* S = &c->set[0];
+    HIPCK(hipStreamWaitEvent(S->scan_stream, arrived, 0));
+    LAUNCHCK(bjjk::var_base_scan(S->scan_stream, grid_for(c, cnt, c->occ_vb_scan, 64), pts, lo, lo + cnt, c->pipe_wl), "variable-base scan");
+    return BJJ_OK;
+  }
+  int all_arrived(hipEvent_t ev_tail) override {
+    ScratchSet* S = &c->set[0];
+    LAUNCHCK(bjjk::mul_var_base_exact(S->scan_stream, c->cus * 4, pts, scalars, sc_words, nullptr, c->pipe_wl, (uint8_t*)d_extra,
+                                      &c->vb_seen[BJJ_SCRATCH_SETS]), "variable-base (exact)");
+    HIPCK(hipEventRecord(ev_tail, S->scan_stream));
+    return BJJ_OK;
+  }
+  int finish(uint8_t* const* host_out, size_t) override {
+    const size_t cnt = __atomic_load_n(&c->vb_seen[BJJ_SCRATCH_SETS], __ATOMIC_ACQUIRE);   // K6 is done (ev_tail): its count is in
+    if (!cnt) return BJJ_OK;
+    if (cnt > n) return set_err(BJJ_E_HIP, "variable base: the exact list is longer than the batch");
+    const size_t need = cnt * 68;
+    if (need > c->patch_host_bytes) {
+      if (c->patch_host) { HIPCK(hipHostFree(c->patch_host)); c->patch_host = nullptr; c->patch_host_bytes = 0; }
+      const size_t want = need < ((size_t)1 << 16) ? (size_t)1 << 16 : need + need / 2;
+      HIPCK(hipHostMalloc((void**)&c->patch_host, want, hipHostMallocDefault));
+      c->patch_host_bytes = want;
+    }
+    HIPCK(hipMemcpyAsync(c->patch_host, d_extra, cnt * 64, hipMemcpyDeviceToHost, c->s_out));
+    HIPCK(hipMemcpyAsync(c->patch_host + cnt * 64, c->pipe_wl + 8, cnt * 4, hipMemcpyDeviceToHost, c->s_out));
+    HIPCK(hipStreamSynchronize(c->s_out));
+    const u32* idx = (const u32*)(c->patch_host + cnt * 64);
+    for (size_t j = 0; j < cnt; j++) {
+      if (idx[j] >= n) return set_err(BJJ_E_HIP, "variable base: index out of range on the exact list");
+      memcpy(host_out[0] + (size_t)idx[j] * 64, c->patch_host + j * 64, 64);
+    }
+    return BJJ_OK;
+  }
+};
+static int var_base_host(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t scalar_bytes, size_t n, uint8_t* out) {
+  PipeSpec sp = {2, 1, {pts, scalars}, {64, scalar_bytes}, {out}, {64}, false};
+  sp.first_chunk = (size_t)1 << 16;   // 14 ms of kernels over 3 ms of copies: a 2^15-item launch holds its lane for a whole round with a quarter of the chip
+  static const bool per_chunk = [] { const char* e = getenv("BJJ_PIPE_VAR_BASE_SPLIT"); return e && e[0] == '0'; }();   // developer: the round-5 form
+  { ENTER_DEVICE(c->device); int rc_ = ensure_pipe(c, 0, 0, 0, 0); if (rc_) return rc_; }
+  const size_t first = c->pipe_env_schedule ? c->pipe_first : sp.first_chunk;
+  // a call of ONE chunk is a device-pointer launch with copies around it (a single Point::mul_scalar, src/lib.rs:149, is such a call)
+  if (per_chunk || c->vb_split == 0 || n < first + first / 2)
+    return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return var_base_launch(c, i[0], i[1], scalar_bytes, cnt, o[0], st, "bjj_mul_var_base"); });
+  VarBasePipe vp(c, scalar_bytes);
+  sp.extra = &vp;
+  sp.extra_dev_per_item = 64;         // K6's compact results: as many as there are items, at worst
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return var_base_bulk_launch(c, i[0], i[1], scalar_bytes, cnt, o[0], st); });
 }
 int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* stream) {
   return var_base_launch(c, d_pts, d_scalars, 32, n, d_out, stream, "bjj_mul_var_base_dev");
@@ -1157,16 +1380,6 @@ int bjj_poseidon5_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out, void*
   DEV_ENTER(c, stream);
   LAUNCHCK(bjjk::poseidon5(st, grid_for(c, n, c->occ_poseidon), (const uint8_t*)d_in, n, (uint8_t*)d_out), "bjj_poseidon5_dev");
   DEV_LEAVE(c);
-}
-static int ensure_scan_stream(ScratchSet* S) {
-  if (!S->scan_stream) {
-    int least = 0, greatest = 0;
-    HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIPCK(hipStreamCreateWithPriority(&S->scan_stream, hipStreamNonBlocking, greatest));
-    HIPCK(hipEventCreateWithFlags(&S->ev_scan_in, hipEventDisableTiming));
-    HIPCK(hipEventCreateWithFlags(&S->ev_scan_out, hipEventDisableTiming));
-  }
-  return BJJ_OK;
 }
 // scan (priority stream) -> main kernel (the caller's stream), both ordered behind what `st` has queued so far
 static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s,
@@ -1420,25 +1633,46 @@ int bjj_scalar_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out, v
   LAUNCHCK(bjjk::scalar_keys(st, grid_for(c, n, 4), (const uint8_t*)d_keys, n, (uint8_t*)d_out), "bjj_scalar_keys_dev");
   DEV_LEAVE(c);
 }
-int bjj_public_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy, void* stream) {
-  CHECK_CTX(c, "bjj_public_keys_dev");
+// compressed: d_out holds the 32-byte records of sk.public().compress() (src/lib.rs:304-306, 166-178)
+static int public_keys_launch(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy, void* stream, bool compressed, const char* who) {
+  if (!c) return set_err(BJJ_E_INVALID, std::string(who) + ": ctx is NULL");
   if (n == 0) return BJJ_OK;
   CHECK_N(n);
-  CHECK_PTR(d_keys, "bjj_public_keys_dev"); CHECK_PTR(d_out_xy, "bjj_public_keys_dev");
+  if (!d_keys || !d_out_xy || !aligned16(d_keys) || !aligned16(d_out_xy))
+    return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
   SET_ENTER(c, stream, n, true);
+  if (compressed) { int rc_ = ensure_xy(c, S, n); if (rc_) return rc_; }
+  uint8_t* xy = compressed ? S->xy : nullptr;
   // B8.mul_scalar(&self.scalar_key()), src/lib.rs:304-306; the scalar keys live in the codec scratch only for the
   // duration of the multiplication and are wiped on the same stream right behind it
   LAUNCHCK(bjjk::scalar_keys(st, grid_for(c, n, 4), (const uint8_t*)d_keys, n, S->codec), "scalar_keys");
   if (c->ct_signer) {
-    LAUNCHCK(bjjk::mul_fixed_base_scan(st, c->cus, c->ct_table, BJJ_CT_W, fixed_nwin(BJJ_CT_W), S->codec, n, (uint8_t*)d_out_xy, S->scratch),
+    LAUNCHCK(bjjk::mul_fixed_base_scan(st, c->cus, c->ct_table, BJJ_CT_W, fixed_nwin(BJJ_CT_W), S->codec, n, (uint8_t*)d_out_xy, S->scratch, xy),
              "mul_fixed_base_scan");
   } else {
     const int kv = fixed_base_variant(c, S);
     LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, kv ? c->lanes_fixed_2x256 : c->lanes_fixed, kv, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy,
-                                  S->scratch), "mul_fixed_base");
+                                  S->scratch, xy), "mul_fixed_base");
   }
   HIPCK(hipMemsetAsync(S->codec, 0, n * 32, st));
   SET_LEAVE(c);
+}
+int bjj_public_keys_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out_xy, void* stream) {
+  return public_keys_launch(c, d_keys, n, d_out_xy, stream, false, "bjj_public_keys_dev");
+}
+int bjj_public_keys_compressed_dev(bjj_ctx* c, const void* d_keys, size_t n, void* d_out32, void* stream) {
+  return public_keys_launch(c, d_keys, n, d_out32, stream, true, "bjj_public_keys_compressed_dev");
+}
+// d_out_s == NULL: the compressed form -- d_out_r holds 64-byte Signature::compress records (src/lib.rs:245-258)
+static int sign_launch(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, void* d_out_r, void* d_out_s, void* d_ok, void* stream) {
+  DEV_ENTER(c, stream);
+  if (c->ct_signer)
+    LAUNCHCK(bjjk::sign_ct(st, grid_for(c, n, c->occ_sign_ct), c->ct_table, BJJ_CT_W, fixed_nwin(BJJ_CT_W), (const uint8_t*)d_keys,
+                           (const uint8_t*)d_msgs, n, (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok), "bjj_sign_dev (constant-time)");
+  else
+  LAUNCHCK(bjjk::sign(st, grid_for(c, n, c->occ_sign), c->table, c->W, c->nwin, (const uint8_t*)d_keys, (const uint8_t*)d_msgs, n,
+                      (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok), "bjj_sign_dev");
+  DEV_LEAVE(c);
 }
 int bjj_sign_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, void* d_out_r, void* d_out_s, void* d_ok,
                  void* stream) {
@@ -1448,14 +1682,15 @@ int bjj_sign_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, v
   CHECK_PTR(d_keys, "bjj_sign_dev"); CHECK_PTR(d_msgs, "bjj_sign_dev"); CHECK_PTR(d_out_r, "bjj_sign_dev");
   CHECK_PTR(d_out_s, "bjj_sign_dev");
   if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_sign_dev: d_ok is NULL");
-  DEV_ENTER(c, stream);
-  if (c->ct_signer)
-    LAUNCHCK(bjjk::sign_ct(st, grid_for(c, n, c->occ_sign_ct), c->ct_table, BJJ_CT_W, fixed_nwin(BJJ_CT_W), (const uint8_t*)d_keys,
-                           (const uint8_t*)d_msgs, n, (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok), "bjj_sign_dev (constant-time)");
-  else
-  LAUNCHCK(bjjk::sign(st, grid_for(c, n, c->occ_sign), c->table, c->W, c->nwin, (const uint8_t*)d_keys, (const uint8_t*)d_msgs, n,
-                      (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok), "bjj_sign_dev");
-  DEV_LEAVE(c);
+  return sign_launch(c, d_keys, d_msgs, n, d_out_r, d_out_s, d_ok, stream);
+}
+int bjj_sign_compressed_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, void* d_out_sig64, void* d_ok, void* stream) {
+  CHECK_CTX(c, "bjj_sign_compressed_dev");
+  if (n == 0) return BJJ_OK;
+  CHECK_N(n);
+  CHECK_PTR(d_keys, "bjj_sign_compressed_dev"); CHECK_PTR(d_msgs, "bjj_sign_compressed_dev"); CHECK_PTR(d_out_sig64, "bjj_sign_compressed_dev");
+  if (!d_ok) return set_err(BJJ_E_INVALID, "bjj_sign_compressed_dev: d_ok is NULL");
+  return sign_launch(c, d_keys, d_msgs, n, d_out_sig64, nullptr, d_ok, stream);
 }
 
 int bjj_sign_schnorr_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, const void* d_nonces, size_t n, void* d_out_r,
@@ -1489,19 +1724,21 @@ int bjj_mul_fixed_base(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* ou
   PipeSpec sp = {1, 1, {scalars}, {32}, {out}, {64}, false};
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_fixed_base_dev(c, i[0], cnt, o[0], st); });
 }
+// 32 bytes per result across PCIe instead of 64: the copy-out is what bounds the affine form (1.19 ms of 1.58 per 2^20 items)
+int bjj_mul_fixed_base_compressed(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* out32) {
+  HOST_PROLOGUE("bjj_mul_fixed_base_compressed", !scalars || !out32);
+  PipeSpec sp = {1, 1, {scalars}, {32}, {out32}, {32}, false};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_fixed_base_compressed_dev(c, i[0], cnt, o[0], st); });
+}
 int bjj_mul_var_base(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out) {
   HOST_PROLOGUE("bjj_mul_var_base", !pts || !scalars || !out);
-  PipeSpec sp = {2, 1, {pts, scalars}, {64, 32}, {out}, {64}, false};
-  sp.first_chunk = (size_t)1 << 16;   // 14 ms of kernels over 3 ms of copies: a 2^15-item launch holds its lane for a whole round with a quarter of the chip
-  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_var_base_dev(c, i[0], i[1], cnt, o[0], st); });
+  return var_base_host(c, pts, scalars, 32, n, out);
 }
 int bjj_mul_var_base_wide(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t scalar_bytes, size_t n, uint8_t* out) {
   HOST_PROLOGUE("bjj_mul_var_base_wide", !pts || !scalars || !out);
   if (scalar_bytes == 0 || (scalar_bytes & 31) || scalar_bytes > BJJ_MAX_SCALAR_BYTES)
     return set_err(BJJ_E_INVALID, "bjj_mul_var_base_wide: scalar_bytes must be a multiple of 32 in 32..BJJ_MAX_SCALAR_BYTES");
-  PipeSpec sp = {2, 1, {pts, scalars}, {64, scalar_bytes}, {out}, {64}, false};
-  sp.first_chunk = (size_t)1 << 16;
-  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_var_base_wide_dev(c, i[0], i[1], scalar_bytes, cnt, o[0], st); });
+  return var_base_host(c, pts, scalars, scalar_bytes, n, out);
 }
 int bjj_poseidon5(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out) {
   HOST_PROLOGUE("bjj_poseidon5", !in || !out);
@@ -1559,6 +1796,16 @@ int bjj_public_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out_xy) 
   HOST_PROLOGUE("bjj_public_keys", !keys || !out_xy);
   PipeSpec sp = {1, 1, {keys}, {32}, {out_xy}, {64}, true};
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_public_keys_dev(c, i[0], cnt, o[0], st); });
+}
+int bjj_public_keys_compressed(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out32) {
+  HOST_PROLOGUE("bjj_public_keys_compressed", !keys || !out32);
+  PipeSpec sp = {1, 1, {keys}, {32}, {out32}, {32}, true};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_public_keys_compressed_dev(c, i[0], cnt, o[0], st); });
+}
+int bjj_sign_compressed(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_sig64, uint8_t* ok) {
+  HOST_PROLOGUE("bjj_sign_compressed", !keys || !msgs || !out_sig64 || !ok);
+  PipeSpec sp = {2, 2, {keys, msgs}, {32, 32}, {out_sig64, ok}, {64, 1}, true};
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_sign_compressed_dev(c, i[0], i[1], cnt, o[0], o[1], st); });
 }
 int bjj_sign(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
   HOST_PROLOGUE("bjj_sign", !keys || !msgs || !out_r || !out_s || !ok);

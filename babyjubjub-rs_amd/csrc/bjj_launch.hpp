@@ -44,13 +44,21 @@ int occ_sign_schnorr();
 hipError_t build_fixed_table(hipStream_t st, uint32_t* table, uint32_t* bases, int W, int nwin);
 hipError_t check_fixed_table(hipStream_t st, int grid, const uint32_t* table, const uint32_t* bases, int W, int nwin,
                              unsigned long long* d_bad);
+// xy == nullptr: out = 64-byte affine points; xy != nullptr: out = 32-byte Point::compress records, xy = 64 B / item of stash
 hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant, const uint32_t* table, int W, int nwin,
-                          const uint8_t* scalars, size_t n, uint8_t* out, uint32_t* scratch);
+                          const uint8_t* scalars, size_t n, uint8_t* out, uint32_t* scratch, uint8_t* xy = nullptr);
 hipError_t mul_fixed_base_scan(hipStream_t st, int cus, const uint32_t* table, int W, int nwin, const uint8_t* scalars, size_t n,
-                               uint8_t* out, uint32_t* scratch);   // constant-time form over the small 4-bit table
+                               uint8_t* out, uint32_t* scratch, uint8_t* xy = nullptr);   // constant-time form over the small 4-bit table
 // k_var.hip (sc_words: 32-bit words per scalar record, 8 for the 32-byte form)
-hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int variant, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
-                        uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow, uint32_t* slotq, uint32_t slot_cap);
+// K2 (slow != nullptr: appends the off-curve items it skips; nullptr: they are on somebody else's list), the on-curve scan that makes
+// such a list, and K6 over a list (patch: compact results beside the indices instead of the items' own slots; seen: host word <- count)
+hipError_t mul_var_base_main(hipStream_t st, int cus, int lanes_per_cu, int variant, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
+                             uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow, uint32_t* slotq, uint32_t slot_cap);
+hipError_t var_base_list_reset(hipStream_t st, uint32_t* list);
+hipError_t var_base_scan(hipStream_t st, int grid, const uint8_t* pts, size_t first, size_t end, uint32_t* list);
+hipError_t mul_var_base_exact(hipStream_t st, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, uint8_t* out,
+                              const uint32_t* slow, uint8_t* patch, uint32_t* seen);
+int occ_var_base_scan();
 hipError_t point_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);
 hipError_t proj_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);
 hipError_t proj_affine(hipStream_t st, int grid, const uint8_t* p, size_t n, uint8_t* out);

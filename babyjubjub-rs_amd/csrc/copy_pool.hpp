@@ -45,13 +45,20 @@ struct CopyPool {
       }
     }
   }
-  void submit(uint8_t* dst, const uint8_t* src, size_t bytes, CopyGroup* g) {
+  // Never throws: if the queue cannot grow (std::bad_alloc), what has been queued stays queued -- `pending` counts exactly the
+  // queued slices -- and the calling thread copies the rest itself (an exception must not cross the C boundary, and
+  // a group's count must never run ahead of its tasks).
+  void submit(uint8_t* dst, const uint8_t* src, size_t bytes, CopyGroup* g) noexcept {
     if (!bytes) return;
+    size_t o = 0;
     {
       std::lock_guard<std::mutex> lk(mu);
-      for (size_t o = 0; o < bytes; o += kSlice) { q.push_back({dst + o, src + o, bytes - o < kSlice ? bytes - o : kSlice, g}); g->pending++; }
+      try {
+        for (; o < bytes; o += kSlice) { q.push_back({dst + o, src + o, bytes - o < kSlice ? bytes - o : kSlice, g}); g->pending++; }
+      } catch (...) {}
     }
     cv_task.notify_all();
+    if (o < bytes) memcpy(dst + o, src + o, bytes - o);
   }
   void wait(CopyGroup* g) {
     std::unique_lock<std::mutex> lk(mu);

@@ -83,44 +83,70 @@ __device__ Fr block_invert(const Fr& x, u32* lds /* NL * 64 words */) {
   return fr_mul(fr_mul(ginv, epre), esuf);
 }
 
-// Phase-1 record for the affine epilogue: X, Y (as 2 x 32-byte integers) go to the
-// item's final output slot; Z and the lane's running prefix product go to scratch.
-__device__ __forceinline__ void epilogue_stash(const Ext& p, Fr& run, uint8_t* out_item, u32* scr_item) {
+// Phase-1 record for the affine epilogue: X, Y (as 2 x 32-byte integers) go to `xy_item` -- the item's final output slot when the
+// result is the 64-byte affine point, a slot of the scratch set's XY area when the result is the 32-byte compressed point
+// (EPI_COMPRESS) -- Z and the lane's running prefix product go to scratch.
+__device__ __forceinline__ void epilogue_stash(const Ext& p, Fr& run, uint8_t* xy_item, u32* scr_item) {
   u32 w[8];
-  fr_to_words(p.X, w); store_w8(out_item, w);
-  fr_to_words(p.Y, w); store_w8(out_item + 32, w);
+  fr_to_words(p.X, w); store_w8(xy_item, w);
+  fr_to_words(p.Y, w); store_w8(xy_item + 32, w);
   fr_to_words(p.Z, w); store_w8(scr_item, w);
   fr_to_words(run, w); store_w8(scr_item + 8, w);
   run = fr_mul(run, p.Z);
 }
+// An item this launch does NOT finish (EPI_SKIPPABLE kernels; K2: the point is off the curve, the exact kernel K6 owns the item's
+// output slot and may be writing it while this launch runs): Z = 0 marks it -- the Z of a computed point is never 0 -- and the
+// running product passes it by.  Nothing is written to the output slot, neither here nor in phase 2.
+__device__ __forceinline__ void epilogue_stash_skipped(u32* scr_item) {
+  const u32 z[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  store_w8(scr_item, z);
+}
+// Epilogue forms (template flags; the default -- affine output, no skipped items -- is what K1 and the signer use, and its code
+// does not change when the other forms are instantiated next to it)
+enum : unsigned { EPI_AFFINE = 0u, EPI_COMPRESS = 1u, EPI_SKIPPABLE = 2u };
 // Phase-2: given inv = 1 / (product of this lane's Z_0..Z_i) as a PLAIN (non-Montgomery) integer, finish item i
 // and step inv down to 1 / (Z_0..Z_{i-1}).  A Montgomery product of a plain and a Montgomery operand is the plain
-// product, so Y * (1/Z) lands directly on the canonical output integer.  Output: reference-curve (x, y).
-__device__ __forceinline__ void epilogue_finish(Fr& inv, uint8_t* out_item, const u32* scr_item) {
+// product, so Y * (1/Z) lands directly on the canonical output integer.  Output: reference-curve (x, y), or with EPI_COMPRESS
+// Point::compress of it (src/lib.rs:166-178: y as 32 little-endian bytes, bit 255 set when x > Q >> 1) -- x is canonical right
+// here, so the sign costs one comparison instead of a second pass over 64-byte points.
+template <unsigned FORM = EPI_AFFINE>
+__device__ __forceinline__ void epilogue_finish(Fr& inv, uint8_t* out_item, uint8_t* xy_item, const u32* scr_item) {
   constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
   u32 w[8];
-  load_w8(scr_item, w);     Fr Z = fr_from_words(w);
+  load_w8(scr_item, w);
+  if (FORM & EPI_SKIPPABLE) {
+    if ((w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) == 0u) return;
+  }
+  Fr Z = fr_from_words(w);
   load_w8(scr_item + 8, w); Fr P = fr_from_words(w);
-  load_w8(out_item, w);     Fr X = fr_from_words(w);
-  load_w8(out_item + 32, w); Fr Y = fr_from_words(w);
+  load_w8(xy_item, w);      Fr X = fr_from_words(w);
+  load_w8(xy_item + 32, w); Fr Y = fr_from_words(w);
   Fr zinv = fr_mul(inv, P);               // plain 1/Z
   inv = fr_mul(inv, Z);
   Fr c2 = fr_mul(zinv, c_K.FINV);         // plain 1/(Z F): maps x' back to the reference curve
   Fr x = fr_cond_sub_kr(fr_mul(X, c2), R1);
   Fr y = fr_cond_sub_kr(fr_mul(Y, zinv), R1);
-  fr_to_words(x, w); store_w8(out_item, w);
-  fr_to_words(y, w); store_w8(out_item + 32, w);
+  if (FORM & EPI_COMPRESS) {
+    fr_to_words(y, w);
+    if (plain_gt_halfq(x, c_K)) w[7] |= 0x80000000u;
+    store_w8(out_item, w);
+  } else {
+    fr_to_words(x, w); store_w8(out_item, w);
+    fr_to_words(y, w); store_w8(out_item + 32, w);
+  }
 }
-template <int BLOCK = BJJ_EPI_BLOCK>
+// out: 64 bytes per item (32 with EPI_COMPRESS); xy: where phase 1 stashed X, Y, 64 bytes per item (== out for the affine form)
+template <int BLOCK = BJJ_EPI_BLOCK, unsigned FORM = EPI_AFFINE>
 __device__ __forceinline__ void epilogue_run(Fr run, size_t n, size_t tid, size_t nthreads, uint8_t* out, u32* scratch,
-                                             u32* lds) {
+                                             u32* lds, uint8_t* xy = nullptr) {
   Fr inv = fr_mul(block_invert<BLOCK>(run, lds), fr_one_plain());  // out of Montgomery form once per lane
   if (tid >= n) return;
   size_t cnt = (n - tid + nthreads - 1) / nthreads;
 #pragma unroll 1
   for (size_t m = cnt; m-- > 0;) {
     size_t i = tid + m * nthreads;
-    epilogue_finish(inv, out + i * 64, scratch + i * 16);
+    if (FORM & EPI_COMPRESS) epilogue_finish<FORM>(inv, out + i * 32, xy + i * 64, scratch + i * 16);
+    else epilogue_finish<FORM>(inv, out + i * 64, out + i * 64, scratch + i * 16);
   }
 }
 

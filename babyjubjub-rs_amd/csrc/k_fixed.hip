@@ -48,9 +48,12 @@ __global__ void __launch_bounds__(BJJ_BLOCK) bjj_k_check_fixed_table(const u32* 
 }
 
 
-template <int BLOCK, int NBUF>
+// FORM = EPI_AFFINE: out holds 64-byte points and doubles as the phase-1 stash (xy == out); EPI_COMPRESS: out holds 32-byte
+// Point::compress records (src/lib.rs:166-178) and the stash is the scratch set's XY area.
+template <int BLOCK, int NBUF, unsigned FORM = EPI_AFFINE>
 __device__ __forceinline__ void mul_fixed_base_body(const u32* __restrict__ table, int W, int nwin, const uint8_t* __restrict__ scalars,
-                                                    size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch) {
+                                                    size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch,
+                                                    uint8_t* __restrict__ xy = nullptr) {
   __shared__ u32 lds[NL * 64];
   __shared__ __attribute__((aligned(16))) u32 stage[(BLOCK / 64) * NBUF * FB_STAGE_WORDS];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,9 +67,9 @@ __device__ __forceinline__ void mul_fixed_base_body(const u32* __restrict__ tabl
     u32 sc[8];
     load_w8(scalars + (valid ? i : n - 1) * 32, sc);
     Ext p = fixed_base_mul(fb, W, nwin, sc, c_K);
-    if (valid) epilogue_stash(p, run, out + i * 64, scratch + i * 16);
+    if (valid) epilogue_stash(p, run, ((FORM & EPI_COMPRESS) ? xy : out) + i * 64, scratch + i * 16);
   }
-  epilogue_run<BLOCK>(run, n, tid, nthreads, out, scratch, lds);
+  epilogue_run<BLOCK, FORM>(run, n, tid, nthreads, out, scratch, lds, xy);
 }
 // Two shapes of the same kernel:
 //  * bjj_k_mul_fixed_base: ONE workgroup of BJJ_K1_BLOCK = 512 lanes per CU (2 waves per SIMD, two staging areas per wave,
@@ -84,9 +87,9 @@ __global__ void __launch_bounds__(BJJ_K1_BLOCK, BJJ_K1_MIN_BLOCKS) bjj_k_mul_fix
 }
 // The signer's constant-time option (bjj_set_signer_constant_time; PrivateKey::public, src/lib.rs:304-306): the multiplication
 // through the scanning policy over the context's small 4-bit table -- no address depends on a digit of the scalar.
-__global__ void __launch_bounds__(BJJ_EPI_BLOCK, 1) bjj_k_mul_fixed_base_scan(const u32* __restrict__ table, int W, int nwin,
-                                                                        const uint8_t* __restrict__ scalars, size_t n,
-                                                                        uint8_t* __restrict__ out, u32* __restrict__ scratch) {
+template <unsigned FORM>
+__device__ __forceinline__ void mul_fixed_base_scan_body(const u32* __restrict__ table, int W, const uint8_t* __restrict__ scalars, size_t n,
+                                                         uint8_t* __restrict__ out, u32* __restrict__ scratch, uint8_t* __restrict__ xy, int nwin) {
   __shared__ u32 lds[NL * 64];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
@@ -97,20 +100,48 @@ __global__ void __launch_bounds__(BJJ_EPI_BLOCK, 1) bjj_k_mul_fixed_base_scan(co
     u32 sc[8];
     load_w8(scalars + i * 32, sc);
     Ext p = fixed_base_mul(fb, W, nwin, sc, c_K);
-    epilogue_stash(p, run, out + i * 64, scratch + i * 16);
+    epilogue_stash(p, run, ((FORM & EPI_COMPRESS) ? xy : out) + i * 64, scratch + i * 16);
   }
-  epilogue_run<BJJ_EPI_BLOCK>(run, n, tid, nthreads, out, scratch, lds);
+  epilogue_run<BJJ_EPI_BLOCK, FORM>(run, n, tid, nthreads, out, scratch, lds, xy);
+}
+__global__ void __launch_bounds__(BJJ_EPI_BLOCK, 1) bjj_k_mul_fixed_base_scan(const u32* __restrict__ table, int W, int nwin,
+                                                                        const uint8_t* __restrict__ scalars, size_t n,
+                                                                        uint8_t* __restrict__ out, u32* __restrict__ scratch) {
+  mul_fixed_base_scan_body<EPI_AFFINE>(table, W, scalars, n, out, scratch, nullptr, nwin);
 }
 __global__ void __launch_bounds__(256, 2) bjj_k_mul_fixed_base_2x256(const u32* __restrict__ table, int W, int nwin,
                                                                     const uint8_t* __restrict__ scalars, size_t n,
                                                                     uint8_t* __restrict__ out, u32* __restrict__ scratch) {
   mul_fixed_base_body<256, 2>(table, W, nwin, scalars, n, out, scratch);
 }
+// ---- the same three kernels with Point::compress fused into the epilogue (src/lib.rs:166-178): 32 bytes per result instead of 64.
+// `sk.public().compress()` is what a key server ships, and the host-pointer form of K1 is bound by the copy-out (64 MB of
+// affine points per 2^20 items = 1.2 ms of PCIe against 0.6 ms of kernel): half the bytes, and no second pass over the points.
+__global__ void __launch_bounds__(BJJ_K1_BLOCK, BJJ_K1_MIN_BLOCKS) bjj_k_mul_fixed_base_c32(const u32* __restrict__ table, int W, int nwin,
+                                                                      const uint8_t* __restrict__ scalars, size_t n,
+                                                                      uint8_t* __restrict__ out32, u32* __restrict__ scratch,
+                                                                      uint8_t* __restrict__ xy) {
+  mul_fixed_base_body<BJJ_K1_BLOCK, BJJ_K1_NBUF, EPI_COMPRESS>(table, W, nwin, scalars, n, out32, scratch, xy);
+}
+__global__ void __launch_bounds__(256, 2) bjj_k_mul_fixed_base_2x256_c32(const u32* __restrict__ table, int W, int nwin,
+                                                                        const uint8_t* __restrict__ scalars, size_t n,
+                                                                        uint8_t* __restrict__ out32, u32* __restrict__ scratch,
+                                                                        uint8_t* __restrict__ xy) {
+  mul_fixed_base_body<256, 2, EPI_COMPRESS>(table, W, nwin, scalars, n, out32, scratch, xy);
+}
+__global__ void __launch_bounds__(BJJ_EPI_BLOCK, 1) bjj_k_mul_fixed_base_scan_c32(const u32* __restrict__ table, int W, int nwin,
+                                                                            const uint8_t* __restrict__ scalars, size_t n,
+                                                                            uint8_t* __restrict__ out32, u32* __restrict__ scratch,
+                                                                            uint8_t* __restrict__ xy) {
+  mul_fixed_base_scan_body<EPI_COMPRESS>(table, W, scalars, n, out32, scratch, xy, nwin);
+}
 
 // ---- launchers (declared in bjj_launch.hpp) ------------------------------------------------------------
 namespace bjjk {
-int fixed_base_lanes_per_cu(int variant) {
-  return variant ? occupancy_of(bjj_k_mul_fixed_base_2x256, 256) * 256 : occupancy_of(bjj_k_mul_fixed_base, BJJ_K1_BLOCK) * BJJ_K1_BLOCK;
+int fixed_base_lanes_per_cu(int variant) {   // one grid size serves the affine and the compressed form: the lesser of the two
+  const int a = variant ? occupancy_of(bjj_k_mul_fixed_base_2x256, 256) * 256 : occupancy_of(bjj_k_mul_fixed_base, BJJ_K1_BLOCK) * BJJ_K1_BLOCK;
+  const int b = variant ? occupancy_of(bjj_k_mul_fixed_base_2x256_c32, 256) * 256 : occupancy_of(bjj_k_mul_fixed_base_c32, BJJ_K1_BLOCK) * BJJ_K1_BLOCK;
+  return a < b ? a : b;
 }
 hipError_t build_fixed_table(hipStream_t st, u32* table, u32* bases, int W, int nwin) {
   const size_t entries = fixed_stride(W) * (size_t)nwin;
@@ -128,20 +159,29 @@ hipError_t check_fixed_table(hipStream_t st, int grid, const u32* table, const u
   BJJ_LAUNCH(bjj_k_check_fixed_table, dim3((unsigned)grid), dim3(BJJ_BLOCK), 0, st, table, bases, W, nwin, d_bad);
   return hipGetLastError();
 }
+// xy != nullptr: the compressed form (out = 32-byte records, xy = the 64-byte-per-item stash)
 hipError_t mul_fixed_base_scan(hipStream_t st, int cus, const u32* table, int W, int nwin, const uint8_t* scalars, size_t n,
-                               uint8_t* out, u32* scratch) {
+                               uint8_t* out, u32* scratch, uint8_t* xy) {
   const size_t want = (n + BJJ_EPI_BLOCK - 1) / BJJ_EPI_BLOCK;
-  const size_t cap = (size_t)cus * (size_t)occupancy_of(bjj_k_mul_fixed_base_scan, BJJ_EPI_BLOCK);
+  const size_t cap = (size_t)cus * (size_t)(xy ? occupancy_of(bjj_k_mul_fixed_base_scan_c32, BJJ_EPI_BLOCK) : occupancy_of(bjj_k_mul_fixed_base_scan, BJJ_EPI_BLOCK));
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  BJJ_LAUNCH(bjj_k_mul_fixed_base_scan, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
+  if (xy)
+    BJJ_LAUNCH(bjj_k_mul_fixed_base_scan_c32, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch, xy);
+  else
+    BJJ_LAUNCH(bjj_k_mul_fixed_base_scan, dim3(grid), dim3(BJJ_EPI_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);
   return hipGetLastError();
 }
 hipError_t mul_fixed_base(hipStream_t st, int cus, int lanes_per_cu, int variant, const u32* table, int W, int nwin, const uint8_t* scalars,
-                          size_t n, uint8_t* out, u32* scratch) {
+                          size_t n, uint8_t* out, u32* scratch, uint8_t* xy) {
   const int block = variant ? 256 : BJJ_K1_BLOCK;
   const size_t want = (n + block - 1) / block, cap = (size_t)cus * (size_t)(lanes_per_cu / block);
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  if (variant)
+  if (xy) {
+    if (variant)
+      BJJ_LAUNCH(bjj_k_mul_fixed_base_2x256_c32, dim3(grid), dim3(256), 0, st, table, W, nwin, scalars, n, out, scratch, xy);
+    else
+      BJJ_LAUNCH(bjj_k_mul_fixed_base_c32, dim3(grid), dim3(BJJ_K1_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch, xy);
+  } else if (variant)
     BJJ_LAUNCH(bjj_k_mul_fixed_base_2x256, dim3(grid), dim3(256), 0, st, table, W, nwin, scalars, n, out, scratch);
   else
     BJJ_LAUNCH(bjj_k_mul_fixed_base, dim3(grid), dim3(BJJ_K1_BLOCK), 0, st, table, W, nwin, scalars, n, out, scratch);

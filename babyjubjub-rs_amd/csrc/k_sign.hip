@@ -5,7 +5,9 @@
 // selects -- and costs ~8x more per fixed-base multiplication (62 additions instead of 8).
 #include "k_common.hpp"
 
-template <bool CT>
+// C64: the signature leaves as Signature::compress (src/lib.rs:245-258): 64 bytes at out_r + i * 64 = Point::compress(R) || s as
+// 32 little-endian bytes (s < l: the reference's min(len, 32) copy never truncates); out_s is not used.
+template <bool CT, bool C64 = false>
 __device__ __forceinline__ void sign_body(const u32* __restrict__ table, int W, int nwin, const uint8_t* __restrict__ keys,
                                           const uint8_t* __restrict__ msgs, size_t n, uint8_t* __restrict__ out_r,
                                           uint8_t* __restrict__ out_s, uint8_t* __restrict__ ok) {
@@ -27,7 +29,13 @@ __device__ __forceinline__ void sign_body(const u32* __restrict__ table, int W, 
     if (i < n) {
 #pragma unroll
       for (int j = 0; j < 8; j++) { rx[j] = good ? rx[j] : 0u; ry[j] = good ? ry[j] : 0u; s[j] = good ? s[j] : 0u; }
-      store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry); store_w8(out_s + i * 32, s);
+      if constexpr (C64) {
+        u32 c[8];
+        compress_item(rx, ry, c, c_K);
+        store_w8(out_r + i * 64, c); store_w8(out_r + i * 64 + 32, s);
+      } else {
+        store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry); store_w8(out_s + i * 32, s);
+      }
       ok[i] = good ? 1 : 0;
     }
   }
@@ -36,6 +44,8 @@ __device__ __forceinline__ void sign_body(const u32* __restrict__ table, int W, 
                   size_t n, uint8_t* __restrict__ out_r, uint8_t* __restrict__ out_s, uint8_t* __restrict__ ok
 __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign(SIGN_ARGS) { sign_body<false>(table, W, nwin, keys, msgs, n, out_r, out_s, ok); }
 __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign_ct(SIGN_ARGS) { sign_body<true>(table, W, nwin, keys, msgs, n, out_r, out_s, ok); }
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign_c64(SIGN_ARGS) { sign_body<false, true>(table, W, nwin, keys, msgs, n, out_r, out_s, ok); }
+__global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign_ct_c64(SIGN_ARGS) { sign_body<true, true>(table, W, nwin, keys, msgs, n, out_r, out_s, ok); }
 
 // PrivateKey::sign_schnorr (src/lib.rs:344-361) with caller-supplied 1024-bit nonces (128 B each); s is the
 // reference's unreduced integer k + scalar_key*h in a 160-byte little-endian record.
@@ -83,18 +93,21 @@ __global__ void __launch_bounds__(BJJ_BLOCK, 2) bjj_k_sign_schnorr_ct(SCHNORR_AR
 }
 
 namespace bjjk {
-int occ_sign() { return occupancy_of(bjj_k_sign, BJJ_BLOCK); }
+int occ_sign() { const int a = occupancy_of(bjj_k_sign, BJJ_BLOCK), b = occupancy_of(bjj_k_sign_c64, BJJ_BLOCK); return a < b ? a : b; }
 int occ_sign_schnorr() { return occupancy_of(bjj_k_sign_schnorr, BJJ_BLOCK); }
-int occ_sign_ct() { return occupancy_of(bjj_k_sign_ct, BJJ_BLOCK); }
+int occ_sign_ct() { const int a = occupancy_of(bjj_k_sign_ct, BJJ_BLOCK), b = occupancy_of(bjj_k_sign_ct_c64, BJJ_BLOCK); return a < b ? a : b; }
 int occ_sign_schnorr_ct() { return occupancy_of(bjj_k_sign_schnorr_ct, BJJ_BLOCK); }
+// out_s == nullptr: the compressed form (out_r = 64-byte Signature::compress records)
 hipError_t sign(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n,
                 uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
-  BJJ_LAUNCH(bjj_k_sign, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
+  if (out_s) BJJ_LAUNCH(bjj_k_sign, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
+  else BJJ_LAUNCH(bjj_k_sign_c64, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
   return hipGetLastError();
 }
 hipError_t sign_ct(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n,
                    uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
-  BJJ_LAUNCH(bjj_k_sign_ct, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
+  if (out_s) BJJ_LAUNCH(bjj_k_sign_ct, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
+  else BJJ_LAUNCH(bjj_k_sign_ct_c64, dim3(grid), dim3(BJJ_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
   return hipGetLastError();
 }
 hipError_t sign_schnorr(hipStream_t st, int grid, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs,

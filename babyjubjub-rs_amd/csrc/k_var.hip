@@ -47,8 +47,13 @@ __device__ void wide_scalar_mod_order(const u32* __restrict__ w, int nw, u32 out
 }
 
 // ---------------------------------------------------------------------------
-// K2: variable base.  Off-curve points are appended to `slow` (slow[0] = count, item indices from
-// slow[8]) and finished by K6 (bjj_k_mul_var_base_exact) right after this kernel.
+// K2: variable base.  An off-curve point (the reference's Point has pub fields and no check, src/lib.rs:134-138) is not this
+// kernel's item: K6 (bjj_k_mul_var_base_exact) replays the reference's loop for it and owns its output slot, which K2 never
+// touches (epilogue_stash_skipped) -- so K6 may run BESIDE K2.  Two ways the list of those items comes about:
+//   slow != nullptr   K2 appends them as it meets them (slow[0] = count, item indices from slow[8]); K6 follows on the same stream.
+//                     What a batch of on-curve points costs nothing extra for; one off-curve item then adds K6's ~4.5 ms
+//                     (a strictly serial 254-step chain on one lane) BEHIND the launch.
+//   slow == nullptr   somebody else has made the list (bjj_k_var_base_scan, on another stream) and K6 is already running.
 // WIDE: scalars are records of `sc_words` 32-bit words (a multiple of 8; `n: &BigInt` is unbounded, src/lib.rs:149,
 // 156-157); for an on-curve point n*P == (n mod 8l)*P exactly.
 // ---------------------------------------------------------------------------
@@ -63,8 +68,8 @@ __device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, c
     u32 w[8], sc[8];
     load_w8(pts + i * 64, w);      Fr x = fr_to_mont_words(w);
     load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
-    Ext p = ext_identity();
     if (ref_on_curve(x, y, c_K)) {
+      Ext p;
       if (WIDE) {
         wide_scalar_mod_order((const u32*)(scalars + i * (size_t)sc_words * 4), sc_words, sc);
         Ext P = ext_from_ref_affine(x, y, c_K);
@@ -74,12 +79,13 @@ __device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, c
         load_w8(scalars + i * 32, sc);
         p = var_base_fast(x, y, sc, tbl, c_K);
       }
+      epilogue_stash(p, run, out + i * 64, scratch + i * 16);
     } else {
-      slow[8 + atomicAdd(&slow[0], 1u)] = (u32)i;  // placeholder result; K6 overwrites the output
+      if (slow) slow[8 + atomicAdd(&slow[0], 1u)] = (u32)i;
+      epilogue_stash_skipped(scratch + i * 16);                 // K6's item: its output slot is not ours
     }
-    epilogue_stash(p, run, out + i * 64, scratch + i * 16);
   }
-  epilogue_run<BJJ_K2_BLOCK>(run, n, tid, nthreads, out, scratch, lds);
+  epilogue_run<BJJ_K2_BLOCK, EPI_SKIPPABLE>(run, n, tid, nthreads, out, scratch, lds);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
                                                                 const uint8_t* __restrict__ scalars, size_t n,
@@ -132,11 +138,30 @@ __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var
     u32* __restrict__ vb_tables, u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap) {
   var_base_tile<true>(pts, scalars, sc_words, n, out, scratch, vb_tables, slow, slotq, cap);
 }
+// The on-curve scan of items first .. end-1 (2 conversions + 5 multiplications per item against K2's ~3 000): the items K6 owns,
+// appended to `list` (same layout as `slow`; somebody else has reset it).  Runs on the priority stream while K2 fills the chip:
+// 64-lane workgroups of few registers take whatever slot frees up.
+__global__ void __launch_bounds__(64) bjj_k_var_base_scan(const uint8_t* __restrict__ pts, size_t first, size_t end, u32* __restrict__ list) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += nthreads) {
+    u32 w[8];
+    load_w8(pts + i * 64, w);      Fr x = fr_to_mont_words(w);
+    load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
+    if (!ref_on_curve(x, y, c_K)) list[8 + atomicAdd(&list[0], 1u)] = (u32)i;
+  }
+}
 // K6: exact replay of the reference's loop for the (rare) off-curve inputs, one per lane; sc_words words per scalar.
+//   patch == nullptr : result j goes to its item's slot out + i * 64
+//   patch != nullptr : result j goes to patch + j * 64, next to its index slow[8 + j] (the host-pointer pipeline: a chunk's results
+//                      may have left the device before K6 is done; the host lays the few patched results over them, bjj_hip.hip)
+//   seen  != nullptr : device-visible HOST word that receives the count -- what the next call's choice of form goes by
 __global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __restrict__ pts,
                                                                const uint8_t* __restrict__ scalars, int sc_words,
-                                                               uint8_t* __restrict__ out, const u32* __restrict__ slow) {
+                                                               uint8_t* __restrict__ out, const u32* __restrict__ slow,
+                                                               uint8_t* __restrict__ patch, u32* __restrict__ seen) {
   const u32 cnt = slow[0];
+  if (seen && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(seen, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
     const size_t i = slow[8 + j];
     u32 w[8];
@@ -144,8 +169,9 @@ __global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __
     load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
     Fr ox, oy;
     ref_mul_scalar(x, y, (const u32*)(scalars + i * (size_t)sc_words * 4), sc_words, ox, oy, c_K);
-    fr_from_mont_words(ox, w); store_w8(out + i * 64, w);
-    fr_from_mont_words(oy, w); store_w8(out + i * 64 + 32, w);
+    uint8_t* dst = patch ? patch + (size_t)j * 64 : out + i * 64;
+    fr_from_mont_words(ox, w); store_w8(dst, w);
+    fr_from_mont_words(oy, w); store_w8(dst + 32, w);
   }
 }
 
@@ -220,10 +246,14 @@ int occ_point_add() {
             c = occupancy_of(bjj_k_proj_affine, BJJ_BLOCK);
   return a < b ? (a < c ? a : c) : (b < c ? b : c);
 }
-hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int variant, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
-                        uint8_t* out, u32* scratch, u32* vb_tables, u32* slow, u32* slotq, u32 slot_cap) {
-  hipError_t e = hipMemsetAsync(slow, 0, 8 * sizeof(u32), st);
-  if (e != hipSuccess) return e;
+// K2 alone.  slow != nullptr: the list is reset here and filled by the kernel (K6 must follow on `st`: mul_var_base_exact);
+// slow == nullptr: the off-curve items are somebody else's (var_base_scan + mul_var_base_exact on another stream).
+hipError_t mul_var_base_main(hipStream_t st, int cus, int lanes_per_cu, int variant, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
+                             uint8_t* out, u32* scratch, u32* vb_tables, u32* slow, u32* slotq, u32 slot_cap) {
+  if (slow) {
+    hipError_t e = hipMemsetAsync(slow, 0, 8 * sizeof(u32), st);
+    if (e != hipSuccess) return e;
+  }
   const size_t want = (n + BJJ_K2_BLOCK - 1) / BJJ_K2_BLOCK, cap = (size_t)cus * (size_t)(lanes_per_cu / BJJ_K2_BLOCK);
   if (variant == 1) {
   if (sc_words == 8)
@@ -240,11 +270,19 @@ hipError_t mul_var_base(hipStream_t st, int cus, int lanes_per_cu, int variant, 
     BJJ_LAUNCH(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
                        vb_tables, slow);
   }
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  BJJ_LAUNCH(bjj_k_mul_var_base_exact, dim3(grid_exact), dim3(64), 0, st, pts, scalars, sc_words, out, slow);
   return hipGetLastError();
 }
+hipError_t var_base_list_reset(hipStream_t st, u32* list) { return hipMemsetAsync(list, 0, 8 * sizeof(u32), st); }
+hipError_t var_base_scan(hipStream_t st, int grid, const uint8_t* pts, size_t first, size_t end, u32* list) {
+  BJJ_LAUNCH(bjj_k_var_base_scan, dim3(grid), dim3(64), 0, st, pts, first, end, list);
+  return hipGetLastError();
+}
+hipError_t mul_var_base_exact(hipStream_t st, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, uint8_t* out, const u32* slow,
+                              uint8_t* patch, u32* seen) {
+  BJJ_LAUNCH(bjj_k_mul_var_base_exact, dim3(grid_exact), dim3(64), 0, st, pts, scalars, sc_words, out, slow, patch, seen);
+  return hipGetLastError();
+}
+int occ_var_base_scan() { return occupancy_of(bjj_k_var_base_scan, 64); }   // resident scan waves per CU
 hipError_t point_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out) {
   BJJ_LAUNCH(bjj_k_point_add, dim3(grid), dim3(BJJ_BLOCK), 0, st, p, q, n, out);
   return hipGetLastError();

@@ -30,6 +30,11 @@
  *   bjj_sign_schnorr     PrivateKey::sign_schnorr(m) src/lib.rs:344-361 (caller-supplied nonce)
  *   bjj_eddsa_verify_compressed  decompress_point(pk), decompress_signature(sig)
  *                        (src/lib.rs:260-268), then verify -- the wire-format ingest path
+ *   bjj_mul_fixed_base_compressed  B8.mul_scalar(n).compress()         src/lib.rs:149-164 + 166-178
+ *   bjj_public_keys_compressed     PrivateKey::public().compress()     src/lib.rs:304-306 + 166-178
+ *   bjj_sign_compressed            PrivateKey::sign(msg)?.compress()   src/lib.rs:308-342 + 245-258
+ *                        -- the wire-format OUTPUT path: the compression is fused into the producing kernel's
+ *                        epilogue, results are 32 (64) bytes instead of 64 (96) on their way across PCIe
  *
  * Data formats (all little-endian, caller-owned, tightly packed arrays):
  *   field element  32 bytes, the canonical integer < r  (== Fr::into_repr().0
@@ -71,7 +76,19 @@
  * set's last call.  The library keeps no pointer past return.
  * Environment knobs (read by bjj_init; for tests and A/B runs): BJJ_K1_VARIANT,
  * BJJ_K2_VARIANT, BJJ_VERIFY_DISPATCH = 0 | 1 force one form of the fixed-base /
- * variable-base / verify kernel instead of the per-call choice.
+ * variable-base / verify kernel instead of the per-call choice; BJJ_VB_SPLIT = 0 | 1
+ * forces where the exact kernel of the variable-base path runs (below).
+ *
+ * Malformed points on the variable-base path.  Point has pub fields and no check (src/lib.rs:134-138), so an
+ * (x, y) that is not on the curve is a legal input; its result is whatever the reference's formula sequence
+ * yields, and the library reproduces it bit for bit with a strictly serial replay of that loop (~4.5 ms for one
+ * item on one lane, whatever the batch size).  bjj_mul_var_base(_wide)_dev runs that exact kernel BEHIND the
+ * batch kernel while every completed call of the context has been clean (a clean batch pays nothing), and -- from
+ * the first call after one that met an off-curve point -- BESIDE it on a priority stream, behind a scan of the
+ * points (0.7 % of a launch): the malformed items then cost their share of the chip instead of a launch-long tail
+ * (2^20 items, 1 off-curve point in 4 096: see profiles/r06_var_base_offcurve.txt).  The host-pointer forms of more
+ * than one pipeline chunk always run the exact items as ONE launch beside the chunks' launches and lay their
+ * results over the caller's array at the end.  bjj_get_info: last_var_base_split.
  *
  * Key material: the signer-side entry points wipe every library-owned buffer the
  * keys / nonces passed through (staging buffers, derived scalar keys) before they
@@ -191,6 +208,9 @@ int bjj_proj_add(bjj_ctx* ctx, const uint8_t* p_xyz /* n*96 */, const uint8_t* q
 int bjj_proj_affine(bjj_ctx* ctx, const uint8_t* p_xyz /* n*96 */, size_t n, uint8_t* out_xy /* n*64 */);
 /* Wire format (src/lib.rs:166-178): 32 bytes = y little-endian, bit 255 = (x > (r-1)/2). */
 int bjj_compress_points(bjj_ctx* ctx, const uint8_t* pts_xy /* n*64 */, size_t n, uint8_t* out /* n*32 */);
+/* B8.mul_scalar(n).compress() in one pass: byte-identical to bjj_compress_points(bjj_mul_fixed_base(..)), half the bytes
+ * back across PCIe (the copy-out is what bounds the affine form on host pointers) and no second call. */
+int bjj_mul_fixed_base_compressed(bjj_ctx* ctx, const uint8_t* scalars /* n*32 */, size_t n, uint8_t* out /* n*32 */);
 /* ok[i] = 1 where decompress_point returns Ok, 0 where it returns Err (y >= r, x^2 a non-residue,
  * or x^2 == 0 -- the reference's modsqrt rejects 0); out_xy[i] is all-zero for Err. */
 int bjj_decompress_points(bjj_ctx* ctx, const uint8_t* in /* n*32 */, size_t n, uint8_t* out_xy /* n*64 */,
@@ -214,8 +234,14 @@ int bjj_scalar_keys(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, size_t n, uint
  * 8 per multiplication (bjj_sign about 2x slower).  The verifier entry points handle public data only and are unaffected. */
 int bjj_set_signer_constant_time(bjj_ctx* ctx, int on);
 int bjj_public_keys(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, size_t n, uint8_t* out_xy /* n*64 */);
+/* sk.public().compress() -- what a key server ships (src/lib.rs:304-306, 166-178) */
+int bjj_public_keys_compressed(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, size_t n, uint8_t* out /* n*32 */);
 int bjj_sign(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, const uint8_t* msgs /* n*32 */, size_t n,
              uint8_t* out_r_xy /* n*64 */, uint8_t* out_s /* n*32 */, uint8_t* ok /* n */);
+/* sk.sign(msg)?.compress(): 64 bytes per signature = Point::compress(R) then s as 32 little-endian bytes
+ * (Signature::compress, src/lib.rs:245-258); all-zero with ok[i] = 0 where the reference returns Err. */
+int bjj_sign_compressed(bjj_ctx* ctx, const uint8_t* keys /* n*32 */, const uint8_t* msgs /* n*32 */, size_t n,
+                        uint8_t* out_sig /* n*64 */, uint8_t* ok /* n */);
 /* PrivateKey::sign_schnorr(m) -> Result<(Point, BigInt), String> (src/lib.rs:344-361) with the nonce supplied by
  * the caller: the reference draws k = rng.gen_biguint(1024) (:347-348) -- randomness stays on the host, so the
  * call is deterministic.  nonces: 128-byte little-endian integers.  out_r = k*B8; out_s = k + scalar_key*h as
@@ -252,6 +278,10 @@ int bjj_compress_points_dev(bjj_ctx* ctx, const void* d_pts_xy, size_t n, void* 
 int bjj_decompress_points_dev(bjj_ctx* ctx, const void* d_in, size_t n, void* d_out_xy, void* d_ok, void* stream);
 int bjj_eddsa_verify_compressed_dev(bjj_ctx* ctx, const void* d_pk, const void* d_sig, const void* d_msg, size_t n,
                                     void* d_ok, void* stream);
+int bjj_mul_fixed_base_compressed_dev(bjj_ctx* ctx, const void* d_scalars, size_t n, void* d_out /* n*32 */, void* stream);
+int bjj_public_keys_compressed_dev(bjj_ctx* ctx, const void* d_keys, size_t n, void* d_out /* n*32 */, void* stream);
+int bjj_sign_compressed_dev(bjj_ctx* ctx, const void* d_keys, const void* d_msgs, size_t n, void* d_out_sig /* n*64 */,
+                            void* d_ok, void* stream);
 
 /* Makes sure the context's scratch can serve batches of up to n items, so that
  * later *_dev calls do not allocate (call once before timing). */
@@ -289,6 +319,8 @@ typedef struct {
   int host_copy_threads;       /* copy workers of the staged path (0 until a pageable array has been seen) */
   const char* kernel_fixed_base_overlap; /* kernel symbols of the forms overlapping launches get (two streams) */
   const char* kernel_var_base_overlap;
+  /* since 0.6.0 */
+  int last_var_base_split;     /* variable base, the exact kernel for off-curve points: 0 = behind the batch kernel, 1 = beside it (scan first) */
 } bjj_info;
 int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
 

@@ -147,6 +147,9 @@ impl Point {
         PointProjective { x: self.x, y: self.y, z: Fr::one() }
     }
 
+    /// COST OF THE n = 1 CALL: about 1.3 ms (a kernel launch plus two PCIe round trips) against 0.17 ms for the reference on one
+    /// CPU core -- item by item this drop-in is SLOWER than the crate it replaces; the GPU pays from 4-8 items per call on.
+    /// Use `mul_scalar_batch` / `mul_fixed_base_batch` (first table).
     pub fn mul_scalar(&self, n: &BigInt) -> Point {
         // lib.rs:149-164: abs(n) * P, n of any size, not reduced
         mul_scalar_batch(std::slice::from_ref(self), std::slice::from_ref(n)).pop().unwrap()
@@ -296,6 +299,8 @@ pub fn new_key() -> PrivateKey {
     PrivateKey::import(be[..32].to_vec()).unwrap()
 }
 
+/// COST OF THE n = 1 CALL: about 1.4 ms against 0.44 ms for the reference on one CPU core -- a caller that verifies signature by
+/// signature gets slower; break-even is 4-8 signatures per call.  Use `verify_batch` (first table).
 pub fn verify(pk: Point, sig: Signature, msg: BigInt) -> bool {
     // lib.rs:395-412
     if msg > *Q {
@@ -394,6 +399,48 @@ pub fn public_batch(keys: &[PrivateKey]) -> Vec<Point> {
         kb.extend_from_slice(&k.key);
     }
     with_gpu(|g| g.public_keys(&kb)).expect("public_batch").chunks(64).map(point_from_bytes).collect()
+}
+
+/// `keys[i].public().compress()` for all i: what a key server ships.  One pass on the GPU (the compression is fused into the
+/// multiplication's epilogue, `bjj_public_keys_compressed`): 32 bytes per key come back instead of 64.
+pub fn public_compressed_batch(keys: &[PrivateKey]) -> Vec<[u8; 32]> {
+    let mut kb = Vec::with_capacity(keys.len() * 32);
+    for k in keys {
+        kb.extend_from_slice(&k.key);
+    }
+    with_gpu(|g| g.public_keys_compressed(&kb))
+        .expect("public_compressed_batch")
+        .chunks(32)
+        .map(|c| {
+            let mut r = [0u8; 32];
+            r.copy_from_slice(c);
+            r
+        })
+        .collect()
+}
+
+/// `keys[i].sign(msgs[i]).map(|s| s.compress())` for all i (`bjj_sign_compressed`: 64 bytes per signature)
+pub fn sign_compressed_batch(keys: &[PrivateKey], msgs: &[BigInt]) -> Vec<Result<[u8; 64], String>> {
+    assert_eq!(keys.len(), msgs.len());
+    let qq = &*Q;
+    let bad: Vec<bool> = msgs.iter().map(|m| m > qq || m.sign() == Sign::Minus).collect();
+    let (mut kb, mut mb) = (Vec::with_capacity(keys.len() * 32), Vec::with_capacity(keys.len() * 32));
+    for (i, k) in keys.iter().enumerate() {
+        kb.extend_from_slice(&k.key);
+        mb.extend_from_slice(&bigint_to_le(if bad[i] { qq } else { &msgs[i] }, 32));
+    }
+    let (sig, ok) = with_gpu(|g| g.sign_compressed(&kb, &mb)).expect("sign_compressed_batch");
+    (0..keys.len())
+        .map(|i| {
+            if bad[i] || ok[i] == 0 {
+                Err("msg outside the Finite Field".to_string())
+            } else {
+                let mut r = [0u8; 64];
+                r.copy_from_slice(&sig[64 * i..64 * i + 64]);
+                Ok(r)
+            }
+        })
+        .collect()
 }
 
 /// `keys[i].sign(msgs[i])` for all i

@@ -39,6 +39,7 @@ pub struct BjjInfo {
     pub host_copy_threads: c_int,
     pub kernel_fixed_base_overlap: *const c_char,
     pub kernel_var_base_overlap: *const c_char,
+    pub last_var_base_split: c_int,
 }
 
 pub const BJJ_OK: c_int = 0;
@@ -76,12 +77,15 @@ extern "C" {
     pub fn bjj_proj_add(ctx: *mut BjjCtx, p_xyz: *const u8, q_xyz: *const u8, n: usize, out_xyz: *mut u8) -> c_int;
     pub fn bjj_proj_affine(ctx: *mut BjjCtx, p_xyz: *const u8, n: usize, out_xy: *mut u8) -> c_int;
     pub fn bjj_compress_points(ctx: *mut BjjCtx, pts_xy: *const u8, n: usize, out: *mut u8) -> c_int;
+    pub fn bjj_mul_fixed_base_compressed(ctx: *mut BjjCtx, scalars: *const u8, n: usize, out: *mut u8) -> c_int;
     pub fn bjj_decompress_points(ctx: *mut BjjCtx, input: *const u8, n: usize, out_xy: *mut u8, ok: *mut u8) -> c_int;
     pub fn bjj_eddsa_verify_compressed(ctx: *mut BjjCtx, pk: *const u8, sig: *const u8, msg: *const u8, n: usize, ok: *mut u8) -> c_int;
     pub fn bjj_scalar_keys(ctx: *mut BjjCtx, keys: *const u8, n: usize, out: *mut u8) -> c_int;
     pub fn bjj_set_signer_constant_time(ctx: *mut BjjCtx, on: c_int) -> c_int;
     pub fn bjj_public_keys(ctx: *mut BjjCtx, keys: *const u8, n: usize, out_xy: *mut u8) -> c_int;
+    pub fn bjj_public_keys_compressed(ctx: *mut BjjCtx, keys: *const u8, n: usize, out: *mut u8) -> c_int;
     pub fn bjj_sign(ctx: *mut BjjCtx, keys: *const u8, msgs: *const u8, n: usize, out_r_xy: *mut u8, out_s: *mut u8, ok: *mut u8) -> c_int;
+    pub fn bjj_sign_compressed(ctx: *mut BjjCtx, keys: *const u8, msgs: *const u8, n: usize, out_sig: *mut u8, ok: *mut u8) -> c_int;
     pub fn bjj_sign_schnorr(ctx: *mut BjjCtx, keys: *const u8, msgs: *const u8, nonces: *const u8, n: usize, out_r_xy: *mut u8, out_s: *mut u8, ok: *mut u8) -> c_int;
     pub fn bjj_mul_fixed_base_dev(ctx: *mut BjjCtx, d_scalars: *const c_void, n: usize, d_out_xy: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn bjj_mul_var_base_dev(ctx: *mut BjjCtx, d_pts_xy: *const c_void, d_scalars: *const c_void, n: usize, d_out_xy: *mut c_void, stream: *mut c_void) -> c_int;
@@ -99,6 +103,9 @@ extern "C" {
     pub fn bjj_compress_points_dev(ctx: *mut BjjCtx, d_pts_xy: *const c_void, n: usize, d_out: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn bjj_decompress_points_dev(ctx: *mut BjjCtx, d_in: *const c_void, n: usize, d_out_xy: *mut c_void, d_ok: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn bjj_eddsa_verify_compressed_dev(ctx: *mut BjjCtx, d_pk: *const c_void, d_sig: *const c_void, d_msg: *const c_void, n: usize, d_ok: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn bjj_mul_fixed_base_compressed_dev(ctx: *mut BjjCtx, d_scalars: *const c_void, n: usize, d_out: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn bjj_public_keys_compressed_dev(ctx: *mut BjjCtx, d_keys: *const c_void, n: usize, d_out: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn bjj_sign_compressed_dev(ctx: *mut BjjCtx, d_keys: *const c_void, d_msgs: *const c_void, n: usize, d_out_sig: *mut c_void, d_ok: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn bjj_reserve(ctx: *mut BjjCtx, n: usize) -> c_int;
     pub fn bjj_check_table(ctx: *mut BjjCtx, n_bad: *mut u64) -> c_int;
     pub fn bjj_get_info(ctx: *mut BjjCtx, info: *mut BjjInfo) -> c_int;

@@ -40,9 +40,43 @@ impl<'a> std::ops::DerefMut for PinnedBuf<'a> {
     }
 }
 
+/// The pool keeps at most this many released buffers / bytes; what does not fit is unpinned at once (a caller whose batch sizes
+/// vary must not accumulate one power-of-two buffer per size for the life of the context).
+const POOL_MAX_BUFFERS: usize = 16;
+const POOL_MAX_BYTES: usize = 1 << 30;
+
+impl<'a> PinnedBuf<'a> {
+    /// Zero the buffer now (key material, nonces): pooled buffers are handed out again with their old contents.
+    pub fn wipe(&mut self) {
+        for b in self.iter_mut() {
+            unsafe { std::ptr::write_volatile(b, 0) };
+        }
+    }
+}
+
 impl<'a> Drop for PinnedBuf<'a> {
     fn drop(&mut self) {
-        self.gpu.pool.borrow_mut().push((self.ptr, self.cap));
+        let mut pool = self.gpu.pool.borrow_mut();
+        let held: usize = pool.iter().map(|&(_, c)| c).sum();
+        if pool.len() < POOL_MAX_BUFFERS && held + self.cap <= POOL_MAX_BYTES {
+            pool.push((self.ptr, self.cap));
+        } else {
+            unsafe { ffi::bjj_host_free(self.gpu.ctx, self.ptr as *mut std::os::raw::c_void) };
+        }
+    }
+}
+
+/// A per-device context that belongs to a `multi::MultiGpu` handle: it cannot outlive the handle (its pool's buffers are
+/// released through the context, which `bjj_multi_free` destroys).
+pub struct BorrowedGpu<'m> {
+    gpu: Gpu,
+    _handle: std::marker::PhantomData<&'m ()>,
+}
+
+impl<'m> std::ops::Deref for BorrowedGpu<'m> {
+    type Target = Gpu;
+    fn deref(&self) -> &Gpu {
+        &self.gpu
     }
 }
 
@@ -66,9 +100,9 @@ impl Gpu {
         Ok(Gpu { ctx, owned: true, pool: RefCell::new(Vec::new()) })
     }
 
-    /// A context owned by a `multi::MultiGpu` handle.
-    pub(crate) fn borrowed(ctx: *mut ffi::BjjCtx) -> Gpu {
-        Gpu { ctx, owned: false, pool: RefCell::new(Vec::new()) }
+    /// A context owned by a `multi::MultiGpu` handle; `'m` is the borrow of that handle.
+    pub(crate) fn borrowed<'m>(ctx: *mut ffi::BjjCtx) -> BorrowedGpu<'m> {
+        BorrowedGpu { gpu: Gpu { ctx, owned: false, pool: RefCell::new(Vec::new()) }, _handle: std::marker::PhantomData }
     }
 
     /// `len` bytes of pinned memory (contents unspecified): the smallest released buffer that fits, else a new allocation.
@@ -250,6 +284,38 @@ impl Gpu {
         let mut out = vec![0u8; n * 64];
         check(unsafe { ffi::bjj_public_keys(self.ctx, keys.as_ptr(), n, out.as_mut_ptr()) }, "bjj_public_keys")?;
         Ok(out)
+    }
+
+    /// `sk.public().compress()` for every key in one pass (reference src/lib.rs:304-306 + 166-178): 32 bytes per key, the
+    /// compression fused into the multiplication's epilogue -- half the bytes back across PCIe and no second call.
+    pub fn public_keys_compressed(&self, keys: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(keys, 32, "keys")?;
+        let mut out = vec![0u8; n * 32];
+        check(unsafe { ffi::bjj_public_keys_compressed(self.ctx, keys.as_ptr(), n, out.as_mut_ptr()) }, "bjj_public_keys_compressed")?;
+        Ok(out)
+    }
+
+    /// `B8.mul_scalar(n).compress()` for every 32-byte scalar in one pass (reference src/lib.rs:149-164 + 166-178)
+    pub fn mul_fixed_base_compressed(&self, scalars: &[u8]) -> Result<Vec<u8>, String> {
+        let n = records(scalars, 32, "scalars")?;
+        let mut out = vec![0u8; n * 32];
+        check(unsafe { ffi::bjj_mul_fixed_base_compressed(self.ctx, scalars.as_ptr(), n, out.as_mut_ptr()) }, "bjj_mul_fixed_base_compressed")?;
+        Ok(out)
+    }
+
+    /// (sig, ok): `sk.sign(msg)?.compress()` (reference src/lib.rs:308-342 + 245-258), 64 bytes per signature; ok[i] == 0 (and an
+    /// all-zero record) where `PrivateKey::sign` returns `Err`
+    pub fn sign_compressed(&self, keys: &[u8], msgs: &[u8]) -> Result<(Vec<u8>, Vec<u8>), String> {
+        let n = records(keys, 32, "keys")?;
+        if msgs.len() != n * 32 {
+            return Err("sign_compressed: array lengths disagree".into());
+        }
+        let (mut sig, mut ok) = (vec![0u8; n * 64], vec![0u8; n]);
+        check(
+            unsafe { ffi::bjj_sign_compressed(self.ctx, keys.as_ptr(), msgs.as_ptr(), n, sig.as_mut_ptr(), ok.as_mut_ptr()) },
+            "bjj_sign_compressed",
+        )?;
+        Ok((sig, ok))
     }
 
     /// (R, s, ok): ok[i] == 0 where `PrivateKey::sign` returns `Err` (msg > Q, reference src/lib.rs:309-311)

@@ -2,7 +2,7 @@
 //! contiguous ceil(n/G) blocks; host slices go through one pipeline thread per device, device-resident arrays through a
 //! pipelined RCCL scatter / kernels / gather inside libbjj_hip.so (peer blocks travel in pieces; `set_chunks`).
 use crate::ffi;
-use crate::gpu::{check, Gpu};
+use crate::gpu::{check, BorrowedGpu, Gpu};
 use std::os::raw::{c_int, c_void};
 use std::ptr;
 
@@ -40,8 +40,8 @@ impl MultiGpu {
         unsafe { ffi::bjj_multi_device(self.m, rank as c_int) as i32 }
     }
 
-    /// the per-device context of a rank (owned by the handle)
-    pub fn gpu(&self, rank: usize) -> Gpu {
+    /// the per-device context of a rank (owned by the handle: the borrow ends with `&self`)
+    pub fn gpu(&self, rank: usize) -> BorrowedGpu<'_> {
         Gpu::borrowed(unsafe { ffi::bjj_multi_ctx(self.m, rank as c_int) })
     }
 
