@@ -443,6 +443,14 @@ struct PipeSpec {
   bool out_at_end = false;             // outputs leave the device once, after everything (they are not final chunk by chunk)
   size_t first_chunk = 0, max_chunk = 0;   // chunk schedule of this entry point (items; 0 = the context's, which the environment overrides)
   size_t extra_dev_per_item = 0;           // bytes of device staging per item for `extra` (PipeExtra::d_extra), beside the arrays
+  // Kernel-bound calls whose launches are work-conserving among themselves (one tile / group per workgroup):
+  //   tail_chunk            the LAST chunk has at most this many items (0 = no rule): its copy-out is the only one nothing hides
+  //   last_on_priority_lane the lanes are the context's stream (normal priority) and stream2 (highest): the hardware serves the
+  //                         priority lane's workgroups first, so ITS chain of launches ends first and the other lane's last launch
+  //                         runs its tail alone.  With the last chunk on the priority lane the other lane's launches fill every tail
+  //                         but the very last one -- as in ONE launch (profiles/r06_var_base_host_schedule.txt)
+  size_t tail_chunk = 0;
+  bool last_on_priority_lane = false;
 };
 // Work of a pipelined call that does not belong to ONE chunk.  All three run on the calling thread while it enqueues:
 //   begin          once per super-batch, before the first copy; d_in / d_out = the staging arrays of the whole super-batch
@@ -605,16 +613,22 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
     const size_t sz_max = (sp.max_chunk && !c->pipe_env_schedule) ? sp.max_chunk : c->pipe_chunk;
     size_t lo = 0, sz = (sp.first_chunk && !c->pipe_env_schedule) ? sp.first_chunk : c->pipe_first;
     if (sz > sz_max) sz = sz_max;
-    while (lo < n) {
-      size_t take = sz < n - lo ? sz : n - lo;
-      if (n - lo - take < sz / 2) take = n - lo;          // what would be left is small: take it along
+    // a separate small last chunk only when there is a schedule to speak of in front of it
+    const size_t tail = (sp.tail_chunk && !c->pipe_env_schedule && n >= 4 * sp.tail_chunk) ? sp.tail_chunk : 0;
+    const size_t body_n = n - tail;
+    while (lo < body_n) {
+      size_t take = sz < body_n - lo ? sz : body_n - lo;
+      if (body_n - lo - take < sz / 2) take = body_n - lo;          // what would be left is small: take it along
       lo_of.push_back(lo);
       lo += take;
       if (sz < sz_max) sz = sz * 2 < sz_max ? sz * 2 : sz_max;
     }
+    if (tail) lo_of.push_back(body_n);
     lo_of.push_back(n);
   }
   const size_t nchunks = lo_of.size() - 1;
+  static const int parity_env = [] { const char* e = getenv("BJJ_PIPE_LANE_PARITY"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();   // developer A/B
+  const size_t lane_flip = parity_env >= 0 ? (size_t)parity_env : (sp.last_on_priority_lane ? ((nchunks - 1) & 1) ^ 1 : 0);   // chunk ch runs on lane (ch + flip) & 1; lane 1 = stream2
   size_t max_chunk = 0;
   for (size_t ch = 0; ch < nchunks; ch++) if (lo_of[ch + 1] - lo_of[ch] > max_chunk) max_chunk = lo_of[ch + 1] - lo_of[ch];
   // device staging: array i of the whole super-batch at d_off[i]; pinned ring slots: the staged arrays of ONE chunk
@@ -696,7 +710,7 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
       int r = sp.extra->chunk_arrived(lo, cnt, c->ev_in[ch]); if (r) return r;
       if (ch + 1 == nchunks) { r = sp.extra->all_arrived(c->ev_tail); if (r) return r; }
     }
-    hipStream_t lane = (ch & 1) ? c->stream2 : c->stream;
+    hipStream_t lane = ((ch + lane_flip) & 1) ? c->stream2 : c->stream;
     HIPCK(hipStreamWaitEvent(lane, c->ev_in[ch], 0));
     void* d_in[4]; void* d_out[4];
     for (int i = 0; i < sp.n_in; i++) d_in[i] = c->dstage + d_in_off[i] + lo * sp.in_stride[i];
@@ -1243,6 +1257,8 @@ static int var_base_form(bjj_ctx* c, ScratchSet* S, hipStream_t st, size_t n, in
   c->last_k2 = kv;
   if (kv == 1) c->rings_used = true;      // the tiles take their table scratch from the slot queues
   *kv_out = kv;
+  static const bool trace = [] { const char* e = getenv("BJJ_PIPE_TRACE"); return e && e[0] == '1'; }();
+  if (trace) fprintf(stderr, "[k2] %zu items on set %d: %s\n", n, (int)(S - c->set), kv ? "tiles" : "grid-strided");
   return BJJ_OK;
 }
 // One device-pointer call.  Clean batches (every point on the curve -- what the history says): K2 makes the list of the items it
@@ -1289,8 +1305,13 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
 // 27.3 ms, profiles/r05_var_base_offcurve.txt).
 static int var_base_bulk_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t scalar_bytes, size_t n, void* d_out, void* stream) {
   SET_ENTER(c, stream, n, false);
-  int kv = 0;
-  { int rc_ = var_base_form(c, S, st, n, &kv); if (rc_) return rc_; }
+  // one tile per workgroup, whatever else is in flight: the chunks' launches are then work-conserving among themselves -- a
+  // workgroup retires after its tile and the slot goes to whichever launch has tiles pending -- where the grid-strided form's
+  // resident sets (the better form for two whole 2^20-item launches that overlap) made the call's length depend on how the chunks'
+  // partly filled rounds happened to interleave (15.6 ... 18.0 ms for the same 2^20 items, profiles/r06_var_base_host_schedule.txt)
+  const int kv = c->k2_variant >= 0 ? c->k2_variant : 1;
+  c->last_k2 = kv;
+  if (kv == 1) c->rings_used = true;
   c->last_vb_split = 1;
   LAUNCHCK(bjjk::mul_var_base_main(st, c->cus, c->lanes_var, kv, (const uint8_t*)d_pts, (const uint8_t*)d_scalars, (int)(scalar_bytes / 4), n, (uint8_t*)d_out,
                                    S->scratch, S->vb_tables, nullptr, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)), "variable base (bulk)");
@@ -1363,6 +1384,8 @@ static int var_base_host(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars,
   VarBasePipe vp(c, scalar_bytes);
   sp.extra = &vp;
   sp.extra_dev_per_item = 64;         // K6's compact results: as many as there are items, at worst
+  sp.tail_chunk = (size_t)1 << 16;
+  sp.last_on_priority_lane = true;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return var_base_bulk_launch(c, i[0], i[1], scalar_bytes, cnt, o[0], st); });
 }
 int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* stream) {

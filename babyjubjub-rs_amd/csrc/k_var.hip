@@ -160,6 +160,11 @@ __global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __
                                                                const uint8_t* __restrict__ scalars, int sc_words,
                                                                uint8_t* __restrict__ out, const u32* __restrict__ slow,
                                                                uint8_t* __restrict__ patch, u32* __restrict__ seen) {
+  // A K6 wave is one serial chain of ~6 000 dependent multiplications (4.5 ms alone).  Beside K2 it shares its SIMD with two or
+  // three K2 waves, and at equal priority the instruction arbiter gives it a quarter of the issue slots: the chain stretches to
+  // the length of the whole K2 launch and becomes the critical path.  Raised wave priority keeps it at its own latency; the few
+  // K6 waves cost K2 nothing measurable.
+  __builtin_amdgcn_s_setprio(3);
   const u32 cnt = slow[0];
   if (seen && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(seen, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {

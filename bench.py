@@ -638,9 +638,51 @@ def source_hash_now():
 
 
 def profile_is_current(stored_hash):
-    """the committed counters are quoted only for the build they were taken from"""
+    """the committed counters are quoted only for the build they were taken from (whole-tree fingerprint: entries of rounds 3-5)"""
     now = source_hash_now()
     return stored_hash is not None and now is not None and stored_hash == now
+
+
+_KERNEL_HASHES = None
+
+
+def kernel_hash_now(kernel):
+    """fingerprint of the MACHINE CODE of one kernel of the library in this tree (srchash.kernel_hashes); None if unknown"""
+    global _KERNEL_HASHES
+    if _KERNEL_HASHES is None:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "babyjubjub-rs_amd"))
+            import srchash
+            _KERNEL_HASHES = srchash.kernel_hashes()
+        except Exception:
+            _KERNEL_HASHES = {}
+    return _KERNEL_HASHES.get(kernel)
+
+
+def profile_entry_is_current(entry, kernel=None):
+    """Do these committed counters describe the kernel that ships?  An entry that carries `code_hash` (round 6: the fingerprint of
+    the profiled kernel's machine code, babyjubjub-rs_amd/srchash.py) is current exactly when the library in this tree holds the same
+    code for that kernel -- an edit of another translation unit, or a new kernel next to it, does not stale it.  Older entries go by
+    the whole-tree fingerprint."""
+    if not entry:
+        return False
+    k = kernel or entry.get("kernel")
+    if entry.get("code_hash") and k:
+        now = kernel_hash_now(k)
+        return now is not None and now == entry["code_hash"]
+    return profile_is_current(entry.get("source_hash") or entry.get("_source_hash"))
+
+
+def mix_is_current(mixj, kernel):
+    """profiles/isa_mix.json: the static instruction mix of `kernel` was taken from the code that ships"""
+    m = mixj.get(kernel) or {}
+    if m.get("code_hash"):
+        return kernel_hash_now(kernel) == m["code_hash"]
+    return profile_is_current(mixj.get("_source_hash"))
+
+
+def fingerprint_text(entry):
+    return ("kernel code fingerprint %s" % entry["code_hash"]) if entry.get("code_hash") else ("source fingerprint %s" % entry.get("source_hash"))
 
 
 def roofline_blocks(kind, kernel_ms, n, info, extra):
@@ -661,20 +703,21 @@ def roofline_block(kind, kernel_ms, n, info, kernel=None):
     ach = algo / (kernel_ms * 1e-3) / 1e9
     tr = load_profile_json("hbm_traffic.json").get(kind, {})
     same_cfg = n == (1 << 20) and tr.get("window_bits") in (None, info.window_bits)
-    stale = bool(tr) and not profile_is_current(tr.get("source_hash"))
+    stale = bool(tr) and not profile_entry_is_current(tr)
     quote = same_cfg and bool(tr) and not stale
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
            "traffic": tr.get("bytes_per_launch") if quote else None,
-           "traffic_source": ("static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command at source fingerprint "
-                              "%s, committed; not re-measured in this run)" % (tr.get("source"), tr.get("source_hash"))) if quote else None,
+           "traffic_source": ("static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command at %s, committed; "
+                              "not re-measured in this run)" % (tr.get("source"), fingerprint_text(tr))) if quote else None,
            "kernel": kernel or KERNEL[kind], "kernel_ms_avg": kernel_ms, "algorithmic_bytes_per_launch": algo,
            "note": "integer-ALU bound path (see DESIGN.md): HBM fraction is reported as measured"}
     if kernel and tr.get("kernel") and tr["kernel"] != kernel:   # the committed counters describe another kernel form
         out["traffic"], out["traffic_source"] = None, None
     if stale:
         out["stale_profile"] = True
-        out["stale_profile_note"] = ("profiles/hbm_traffic.json was taken at source fingerprint %s, this tree is %s: counters not "
-                                     "quoted (re-run tools/profile_r.sh + tools/summarize_profile.py)" % (tr.get("source_hash"), source_hash_now()))
+        out["stale_profile_note"] = ("profiles/hbm_traffic.json was taken at %s, this tree has %s: counters not quoted (re-run "
+                                     "tools/profile_r.sh + tools/summarize_profile.py)"
+                                     % (fingerprint_text(tr), kernel_hash_now(tr.get("kernel")) if tr.get("code_hash") else source_hash_now()))
     return out
 
 
@@ -697,7 +740,7 @@ def roofline_overlapped_block(kind, span_ms, detail, n, info, kernel):
     algo = ALGO_BYTES[kind] * n
     ach = algo / (span_ms * 1e-3) / 1e9
     tr = load_profile_json("hbm_traffic.json").get(kind + "_two_stream", {})
-    stale = bool(tr) and not profile_is_current(tr.get("source_hash"))
+    stale = bool(tr) and not profile_entry_is_current(tr)
     quote = bool(tr) and not stale and n == (1 << 20) and tr.get("window_bits") in (None, info.window_bits) and tr.get("kernel") == kernel
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
            "kernel": kernel, "streams": 2, "span_ms_per_launch": span_ms, "algorithmic_bytes_per_launch": algo,
@@ -713,7 +756,7 @@ def roofline_overlapped_block(kind, span_ms, detail, n, info, kernel):
     # dispatches) and its own static instruction mix -- the same two figures `valu` gives for the one-stream kernel
     mixj = load_profile_json("isa_mix.json")
     mix = mixj.get(kernel or "", {})
-    if quote and mix and tr.get("valu_insts_per_launch") and tr.get("sq_busy_cycles") and profile_is_current(mixj.get("_source_hash")):
+    if quote and mix and tr.get("valu_insts_per_launch") and tr.get("sq_busy_cycles") and mix_is_current(mixj, kernel):
         cyc = mix["avg_issue_cycles_per_valu_inst"]
         ipc = tr["valu_insts_per_launch"] / 1024.0 / (tr["sq_busy_cycles"] / 32.0)
         peak = 1024 * 2.4 / cyc
@@ -738,10 +781,11 @@ def valu_block(kind, kernel_ms, n, info, clock=None):
     vi = tr.get("valu_insts_per_launch")
     if not vi or not mix or n != (1 << 20) or tr.get("window_bits") not in (None, info.window_bits):
         return None
-    if not profile_is_current(tr.get("source_hash")) or not profile_is_current(load_profile_json("isa_mix.json").get("_source_hash")):
+    if not profile_entry_is_current(tr) or not mix_is_current(load_profile_json("isa_mix.json"), KERNEL[kind]):
         return {"stale_profile": True, "frac": None,
-                "note": "the committed instruction counters / ISA mix describe another build (source fingerprint %s / %s, tree %s)"
-                        % (tr.get("source_hash"), load_profile_json("isa_mix.json").get("_source_hash"), source_hash_now())}
+                "note": "the committed instruction counters / ISA mix describe another build (%s / mix %s; this tree: kernel %s, source %s)"
+                        % (fingerprint_text(tr), mix.get("code_hash") or load_profile_json("isa_mix.json").get("_source_hash"),
+                           kernel_hash_now(KERNEL[kind]), source_hash_now())}
     cyc = mix["avg_issue_cycles_per_valu_inst"]
     peak = 1024 * 2.4 / cyc
     va = vi / (kernel_ms * 1e-3) / 1e9

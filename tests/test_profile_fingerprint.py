@@ -99,10 +99,75 @@ def test_committed_profiles_carry_a_fingerprint_or_are_flagged():
     sys.path.insert(0, ROOT)
     import bench
     tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    kh = srchash.kernel_hashes()
     for kind in ("fixed_base", "verify", "var_base"):
         r = bench.roofline_block(kind, 1.0, 1 << 20, _Info())
-        current = tr.get(kind, {}).get("source_hash") == srchash.tree_hash()
+        e = tr.get(kind, {})
+        current = (kh.get(e.get("kernel")) == e["code_hash"]) if e.get("code_hash") else (e.get("source_hash") == srchash.tree_hash())
         assert (r["traffic"] is not None) == current and (r.get("stale_profile", False) is True) == (not current)
+
+
+def test_kernel_code_fingerprints_of_the_shipped_library():
+    """round 6: counters are tied to the MACHINE CODE of the kernel they describe (srchash.kernel_hashes): every kernel of the library
+    has one; it depends on the kernel's instructions, its descriptor (registers, LDS, scratch) and the functions it may call -- not on
+    where the linker put it, and not on the other kernels"""
+    import struct
+    kh = srchash.kernel_hashes()
+    for k in ("bjj_k_mul_fixed_base", "bjj_k_mul_fixed_base_2x256", "bjj_k_mul_fixed_base_c32", "bjj_k_mul_var_base", "bjj_k_mul_var_base_tiles",
+              "bjj_k_mul_var_base_exact", "bjj_k_var_base_scan", "bjj_k_eddsa_verify_groups", "bjj_k_poseidon5", "bjj_k_sign", "bjj_k_sign_c64"):
+        assert k in kh and len(kh[k]) == 16, k
+    assert len(set(kh.values())) == len(kh)                       # no two kernels share a fingerprint
+    assert srchash.kernel_hashes() == kh and srchash.kernel_hash("bjj_k_poseidon5") == kh["bjj_k_poseidon5"]
+    assert srchash.kernel_hashes("/nonexistent/libbjj_hip.so") == {} and srchash.kernel_hash("no_such_kernel") is None
+    # one flipped instruction byte of ONE kernel changes that kernel's fingerprint and no other's; a flipped code-entry offset changes none
+    data = bytearray(open(srchash.LIB, "rb").read())
+    target, found = "bjj_k_poseidon5", None
+    for off, size in srchash._code_objects(bytes(data)):
+        img = bytes(data[off:off + size])
+        funcs, objs = srchash._elf_functions(img)
+        for n, body in funcs.items():
+            if srchash._plain(n) == target and n + ".kd" in objs:
+                found = (off + img.index(body), off + img.index(objs[n + ".kd"]))
+    assert found
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "lib.so")
+        mod = bytearray(data)
+        mod[found[0] + 64] ^= 1
+        open(p, "wb").write(mod)
+        k2 = srchash.kernel_hashes(p)
+        assert k2[target] != kh[target] and all(k2[k] == kh[k] for k in kh if k != target)
+        mod = bytearray(data)
+        mod[found[1] + 16] ^= 0x40                                # KERNEL_CODE_ENTRY_BYTE_OFFSET of the descriptor
+        open(p, "wb").write(mod)
+        assert srchash.kernel_hashes(p) == kh
+        mod = bytearray(data)
+        mod[found[1] + 48] ^= 1                                   # compute_pgm_rsrc1 (register counts): a different kernel
+        open(p, "wb").write(mod)
+        assert srchash.kernel_hashes(p)[target] != kh[target]
+
+
+def test_bench_goes_by_the_kernel_code_fingerprint_when_an_entry_has_one(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    now = {"bjj_k_mul_fixed_base": "aaaaaaaaaaaaaaaa"}
+    prof = {"hbm_traffic.json": {"fixed_base": {"bytes_per_launch": 1.5e9, "source": "profiles/x.md", "batch": 1 << 20, "kernel": "bjj_k_mul_fixed_base",
+                                                "valu_insts_per_launch": 2.5e8, "window_bits": 28, "source_hash": "an-older-tree", "code_hash": "aaaaaaaaaaaaaaaa"}},
+            "isa_mix.json": {"_source_hash": "an-older-tree",
+                             "bjj_k_mul_fixed_base": {"avg_issue_cycles_per_valu_inst": 4.0, "quarter_rate_share": 0.76, "code_hash": "aaaaaaaaaaaaaaaa"}}}
+    monkeypatch.setattr(bench, "load_profile_json", lambda name: prof.get(name, {}))
+    monkeypatch.setattr(bench, "kernel_hash_now", lambda k: now.get(k))
+    monkeypatch.setattr(bench, "source_hash_now", lambda: "this-tree")
+    # the tree has moved on (another unit was edited), the kernel's code has not: its counters are still quoted
+    r = bench.roofline_block("fixed_base", 0.6, 1 << 20, _Info(), "bjj_k_mul_fixed_base")
+    assert r["traffic"] == 1.5e9 and "stale_profile" not in r and "kernel code fingerprint aaaaaaaaaaaaaaaa" in r["traffic_source"]
+    assert bench.valu_block("fixed_base", 0.6, 1 << 20, _Info())["frac"] > 0
+    # the kernel's code changed: stale, whatever the tree fingerprint says
+    now["bjj_k_mul_fixed_base"] = "bbbbbbbbbbbbbbbb"
+    monkeypatch.setattr(bench, "source_hash_now", lambda: "an-older-tree")
+    r = bench.roofline_block("fixed_base", 0.6, 1 << 20, _Info(), "bjj_k_mul_fixed_base")
+    assert r["traffic"] is None and r["stale_profile"] is True
+    assert bench.valu_block("fixed_base", 0.6, 1 << 20, _Info())["stale_profile"] is True
 
 
 def test_a_fast_math_build_does_not_compile(tmp_path):

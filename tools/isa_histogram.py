@@ -117,7 +117,11 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     sys.path.insert(0, os.path.join(ROOT, "babyjubjub-rs_amd"))
     import srchash
-    mix["_source_hash"] = srchash.tree_hash()   # bench.py quotes the mix only for the tree it was taken from
+    mix["_source_hash"] = srchash.tree_hash()
+    kh = srchash.kernel_hashes()                # bench.py quotes a kernel's mix only while the library holds the same machine code for it
+    for name, m in mix.items():
+        if isinstance(m, dict) and name in kh:
+            m["code_hash"] = kh[name]
     json.dump(mix, open(os.path.join(ROOT, "profiles", "isa_mix.json"), "w"), indent=1, sort_keys=True)
     open(os.path.join(ROOT, "profiles", "%s_isa_mix.txt" % tag), "w").write("\n".join(table) + "\n")
     print("\n".join(table))

@@ -12,6 +12,7 @@ OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
 python3 babyjubjub-rs_amd/srchash.py > $OUT/source_hash.txt
+python3 -c "import sys, json; sys.path.insert(0, 'babyjubjub-rs_amd'); import srchash; json.dump(srchash.kernel_hashes(), open('$OUT/code_hashes.json', 'w'), indent=1)"   # machine-code fingerprint of every kernel of the library that runs here
 if [ "$WL" = fixed_base ]; then
   ARGS="bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"; SHORT="--no-also --no-strong"
 else

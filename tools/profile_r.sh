@@ -5,7 +5,8 @@ TAG=${1:-r01}; WL=${2:-fixed_base}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
-python3 babyjubjub-rs_amd/srchash.py > $OUT/source_hash.txt   # the tree these counters describe (tools/summarize_profile.py, bench.py)
+python3 babyjubjub-rs_amd/srchash.py > $OUT/source_hash.txt
+python3 -c "import sys, json; sys.path.insert(0, 'babyjubjub-rs_amd'); import srchash; json.dump(srchash.kernel_hashes(), open('$OUT/code_hashes.json', 'w'), indent=1)"   # machine-code fingerprint of every kernel of the library that runs here   # the tree these counters describe (tools/summarize_profile.py, bench.py)
 python3 bench.py --workload $WL --no-also --no-strong > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; tail -c 3000 $OUT/bench_$WL.json
 export TMPDIR=/tmp
 ARGS="bench.py --workload $WL --streams 1 --no-cpu-baseline --no-also --no-strong"   # same steps / warm-up as the default bench line; ONE stream: the profiler serialises launches anyway, and per-launch counters / durations mean one thing

@@ -161,11 +161,12 @@ if before:
     open(os.path.join(ROOT, "profiles", "%s_%s_two_stream_unprofiled_line.json" % (tag, wl)), "w").write(json.dumps(before) + "\n")
 tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 d = json.load(open(tj)) if os.path.exists(tj) else {}
-hp = os.path.join(src, "source_hash.txt")
+hp, cp = os.path.join(src, "source_hash.txt"), os.path.join(src, "code_hashes.json")
 profiled = open(hp).read().strip() if os.path.exists(hp) else None
-if profiled and profiled != srchash.tree_hash():
-    raise SystemExit("csrc/ changed since %s was profiled (%s != %s): summary written, hbm_traffic.json NOT updated" % (tag, profiled, srchash.tree_hash()))
-ent = {"kernel": kernel, "source": "profiles/" + name, "source_hash": profiled or srchash.tree_hash(), "batch": 1 << 20,
+code = json.load(open(cp)).get(kernel) if os.path.exists(cp) else srchash.kernel_hash(kernel)
+if code != srchash.kernel_hash(kernel):
+    raise SystemExit("%s in this tree's library is not the code %s profiled (%s != %s): summary written, hbm_traffic.json NOT updated" % (kernel, tag, srchash.kernel_hash(kernel), code))
+ent = {"kernel": kernel, "source": "profiles/" + name, "source_hash": profiled or srchash.tree_hash(), "code_hash": code, "batch": 1 << 20,
        "trace_span_us_per_launch": span_us / K, "trace_kernel_us_avg": sum(dur) / len(dur),
        "unprofiled_ms_per_step": before["ms_per_step"] if before else None}
 if traffic:

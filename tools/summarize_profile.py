@@ -73,14 +73,15 @@ with open(os.path.join(ROOT, "profiles", "%s_%s_summary.md" % (tag, wl)), "w") a
 tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 d = json.load(open(tj)) if os.path.exists(tj) else {}
 if traffic:
-    # the tree must be the one that was profiled: run this tool before touching csrc/ again (gpurun_out/<tag>/source_hash.txt,
-    # written on the GPU box by tools/profile_r.sh, is checked against it)
-    hp = os.path.join(src, "source_hash.txt")
+    # the counters are stamped with the fingerprint of the profiled kernel's MACHINE CODE (gpurun_out/<tag>/code_hashes.json, written
+    # on the GPU box by tools/profile_r.sh from the library that ran): they must describe the library in this tree
+    hp, cp = os.path.join(src, "source_hash.txt"), os.path.join(src, "code_hashes.json")
     profiled = open(hp).read().strip() if os.path.exists(hp) else None
-    if profiled and profiled != srchash.tree_hash():
-        raise SystemExit("csrc/ changed since %s was profiled (%s != %s): re-profile" % (tag, profiled, srchash.tree_hash()))
+    code = json.load(open(cp)).get(KERNEL) if os.path.exists(cp) else srchash.kernel_hash(KERNEL)
+    if code != srchash.kernel_hash(KERNEL):
+        raise SystemExit("%s in this tree's library is not the code %s profiled (%s != %s): re-profile" % (KERNEL, tag, srchash.kernel_hash(KERNEL), code))
     d[wl] = {"bytes_per_launch": traffic, "source": "profiles/%s_%s_summary.md" % (tag, wl), "batch": int(meta.get("Grid_Size", 0)) and 1 << 20,
-             "source_hash": profiled or srchash.tree_hash()}
+             "source_hash": profiled or srchash.tree_hash(), "code_hash": code}
     d[wl]["kernel"] = KERNEL
     if "SQ_INSTS_VALU" in counters:
         d[wl]["valu_insts_per_launch"] = counters["SQ_INSTS_VALU"][0]

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer probe: what off-curve input points cost the variable-base path (they take the reference's bit-serial formula
-sequence in a launch of their own behind the main kernel, k_var.hip: bjj_k_mul_var_base_exact): one device-pointer launch of
-2^20 items with none / 1 in 4096 / 1 in 97 / 1 in 8 of the points off the curve, and the host-pointer call on pinned memory."""
+sequence in a launch of their own, k_var.hip: bjj_k_mul_var_base_exact -- behind the main kernel, or beside it behind a scan once the
+context has met an off-curve point): one device-pointer launch of 2^20 items with none / 1 in 4096 / 1 in 97 / 1 in 8 of the points off
+the curve, and the host-pointer call on pinned memory.  BJJ_VB_SPLIT=0 + BJJ_PIPE_VAR_BASE_SPLIT=0 in the environment = the round-5 forms."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -47,7 +48,10 @@ for every in (0, 4096, 97, 8):
         v[::every, 7] ^= 4
     h_pts[:] = d_pts.cpu().numpy()
     t_dev = best(dev_call)
+    s_dev = ctx.info().last_var_base_split
     t_host = best(lambda: ctx._ck(ctx.lib.bjj_mul_var_base(ctx.handle, h_pts.ctypes.data, h_sc.ctypes.data, n, h_out.ctypes.data), "vb"))
+    s_host = ctx.info().last_var_base_split
     same = bool((torch.from_numpy(np.asarray(h_out)).to(dev) == d_out).all())
-    print("off-curve points: %-12s one device launch %7.3f ms   host call (pinned) %7.3f ms   equal: %s"
-          % ("none" if not every else "1 in %d" % every, t_dev, t_host, same), flush=True)
+    form = {0: "behind", 1: "beside", -1: "?"}
+    print("off-curve points: %-12s one device launch %7.3f ms (exact kernel %s)   host call (pinned) %7.3f ms (%s, %d chunks)   equal: %s"
+          % ("none" if not every else "1 in %d" % every, t_dev, form[s_dev], t_host, form[s_host], ctx.info().last_host_chunks, same), flush=True)
