@@ -1204,7 +1204,8 @@ static int ensure_scan_stream(ScratchSet* S) {
   if (!S->scan_stream) {
     int least = 0, greatest = 0;
     HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIPCK(hipStreamCreateWithPriority(&S->scan_stream, hipStreamNonBlocking, greatest));
+    static const bool normal = [] { const char* e = getenv("BJJ_SCAN_STREAM_PRIORITY"); return e && e[0] == 'n'; }();   // developer A/B
+    HIPCK(hipStreamCreateWithPriority(&S->scan_stream, hipStreamNonBlocking, normal ? 0 : greatest));
     HIPCK(hipEventCreateWithFlags(&S->ev_scan_in, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&S->ev_scan_out, hipEventDisableTiming));
   }
