@@ -40,7 +40,11 @@
 
 using namespace bjj;
 
+#ifdef BJJ_TEST_HOOKS   // `make hooks`: the same library plus the failure injection of bjj_multi.inc; never the shipped one
+#define BJJ_VERSION_STRING "bjj-hip 0.6.0 gfx950 +test-hooks"
+#else
 #define BJJ_VERSION_STRING "bjj-hip 0.6.0 gfx950"
+#endif
 // Fixed-base window width.  window_bits = 0 (default) is a modest 23 bits = 11 signed digits, 5.9 GB: a library that
 // is linked into a process with other tenants of the GPU must not take half of the HBM unasked.  The wide tables are
 // opt-in: an explicit width (28 bits = 9 digits, 9 x (2^27 + 1) entries = 154.6 GB of the 288 GB; 26 = 10 digits,

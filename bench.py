@@ -45,15 +45,17 @@ import torch.distributed as dist  # noqa: E402
 
 ALGO_BYTES = {"fixed_base": 96, "var_base": 160, "verify": 193, "poseidon5": 192,
               "verify_compressed": 129, "decompress": 97, "sign": 160,  # 8(f) row 1: 32 pk + 64 sig + 32 msg -> 1; 32 -> 64 + 1
-              "point_add": 192, "compress": 96}  # the reference's other criterion cases: 2 x 64 -> 64; 64 -> 32
+              "point_add": 192, "compress": 96,  # the reference's other criterion cases: 2 x 64 -> 64; 64 -> 32
+              "fixed_base_compressed": 64}  # 8(f) row 1 "compress on output": 32 -> 32
 UNITS = {"fixed_base": "scalar mults/s", "var_base": "scalar mults/s", "verify": "verifies/s", "poseidon5": "hashes/s",
          "verify_compressed": "verifies/s", "decompress": "points/s", "sign": "signatures/s", "point_add": "point additions/s",
-         "compress": "points/s"}
+         "compress": "points/s", "fixed_base_compressed": "scalar mults/s"}
 METRIC = {"fixed_base": "fixed-base scalar mults/sec", "var_base": "variable-base scalar mults/sec",
           "verify": "EdDSA-Poseidon verifies/sec", "poseidon5": "Poseidon(t=6) hashes/sec",
           "verify_compressed": "EdDSA-Poseidon verifies/sec (compressed pk + signature)",
           "decompress": "point decompressions/sec", "sign": "EdDSA-Poseidon signatures/sec",
-          "point_add": "projective add + affine (criterion case `add`)/sec", "compress": "point compressions/sec"}
+          "point_add": "projective add + affine (criterion case `add`)/sec", "compress": "point compressions/sec",
+          "fixed_base_compressed": "fixed-base scalar mults/sec, compressed output"}
 WORKLOAD_TEXT = {"fixed_base": "1M fixed-base scalar mults (generator B8), BASELINE configs[1]",
                  "var_base": "1M variable-base scalar mults on random group points, BASELINE configs[2]",
                  "verify": "1M EdDSA-Poseidon verifies, 1/64 corrupted, BASELINE configs[3]",
@@ -62,18 +64,20 @@ WORKLOAD_TEXT = {"fixed_base": "1M fixed-base scalar mults (generator B8), BASEL
                  "decompress": "1M decompress_point (SURVEY 8f row 1)",
                  "sign": "1M PrivateKey::sign (Blake-512 x2, 2 fixed-base mults, Poseidon; SURVEY 8f row 2)",
                  "point_add": "1M p.projective().add(&q.projective()).affine() (benches/bench_babyjubjub.rs:26-31)",
-                 "compress": "1M Point::compress (benches/bench_babyjubjub.rs:40-41)"}
+                 "compress": "1M Point::compress (benches/bench_babyjubjub.rs:40-41)",
+                 "fixed_base_compressed": "1M B8.mul_scalar(n).compress(), compression fused into K1's epilogue (SURVEY 8f row 1)"}
 # the kernel a launch that runs ALONE on one stream gets (what roofline / valu and the rocprofv3 summaries describe)
 KERNEL = {"fixed_base": "bjj_k_mul_fixed_base", "var_base": "bjj_k_mul_var_base_tiles", "verify": "bjj_k_eddsa_verify_groups",
           "poseidon5": "bjj_k_poseidon5", "verify_compressed": "bjj_k_eddsa_verify_groups", "decompress": "bjj_k_decompress_points",
-          "sign": "bjj_k_sign", "point_add": "bjj_k_point_add", "compress": "bjj_k_compress_points"}
+          "sign": "bjj_k_sign", "point_add": "bjj_k_point_add", "compress": "bjj_k_compress_points",
+          "fixed_base_compressed": "bjj_k_mul_fixed_base_c32"}
 # Streams the timed loop alternates over by default.  The context keeps one scratch set per stream (two sets), so with two
 # streams consecutive launches overlap: the head of launch k+1 fills the partly empty last wave-round of launch k (verify is
 # 8.1 rounds of the resident waves, variable base 5.3), and for K1 the library switches to its two-workgroups-per-CU shape,
 # in which one launch's serial section (the workgroup-wide inversion, the epilogue) is covered by the other launch's main loop.
 # `value` is the rate of the K timed launches under that protocol; `roofline` / `valu` keep describing ONE launch on one stream
 # (per-launch HIP events; what the rocprofv3 summaries under profiles/ profile), and `single_stream` carries its rate.
-DEFAULT_STREAMS = {"fixed_base": 2, "verify": 2, "var_base": 2, "verify_compressed": 2}
+DEFAULT_STREAMS = {"fixed_base": 2, "verify": 2, "var_base": 2, "verify_compressed": 2, "fixed_base_compressed": 2}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 T8 = (4342719913949491028786768530115087822524712248835451589697801404893164183326,
       4826523245007015323400664741523384119579596407052839571721035538011798951543)  # a point of order 8 (SURVEY.md 8d cfg 3)
@@ -307,9 +311,9 @@ class Workload:
         c, n, kind, s = self.ctx, self.n, self.kind, 0
         B = Batch()
         B.offset = offset
-        if kind == "fixed_base":
+        if kind in ("fixed_base", "fixed_base_compressed"):
             B.d_sc = self._up(w.scalars_254(n, offset))
-            B.d_out = self._empty(n * 64)
+            B.d_out = self._empty(n * (64 if kind == "fixed_base" else 32))
         elif kind == "var_base":
             # cfg 3 points: k*B8 + c*T8 (the whole group, cofactor components included), made by the parity-tested kernels
             B.d_sc = self._up(w.scalars_254(n, offset))
@@ -385,6 +389,8 @@ class Workload:
         kind = self.kind
         if kind == "fixed_base":
             c.mul_fixed_base_dev(B.d_sc.data_ptr(), n, B.d_out.data_ptr(), s)
+        elif kind == "fixed_base_compressed":
+            c.mul_fixed_base_compressed_dev(B.d_sc.data_ptr(), n, B.d_out.data_ptr(), s)
         elif kind == "var_base":
             c.mul_var_base_dev(B.d_pts.data_ptr(), B.d_sc.data_ptr(), n, B.d_out.data_ptr(), s)
         elif kind == "poseidon5":
@@ -416,6 +422,8 @@ class Workload:
         r = lambda t, wd: self.rows(t, wd, idx, B)  # noqa: E731
         if k == "fixed_base":
             return orc.mul_fixed_base(r("d_sc", 32))
+        if k == "fixed_base_compressed":
+            return orc.compress(orc.mul_fixed_base(r("d_sc", 32)))
         if k == "var_base":
             return orc.mul_var_base(r("d_pts", 64), r("d_sc", 32))
         if k == "poseidon5":
@@ -441,7 +449,7 @@ class Workload:
         want = self.oracle_run(orc, idx, B)
         if k in ("fixed_base", "var_base", "point_add"):
             return bool((self.rows("d_out", 64, idx, B) == want).all())
-        if k in ("poseidon5", "compress"):
+        if k in ("poseidon5", "compress", "fixed_base_compressed"):
             return bool((self.rows("d_out", 32, idx, B) == want).all())
         if k == "sign":
             return bool((self.rows("d_out", 64, idx, B) == want[0]).all()) and bool((self.rows("d_s", 32, idx, B) == want[1]).all()) \
@@ -589,7 +597,7 @@ def cpu_baseline(kind, wl, orc, budget_cpu_s=12.0):
         return time.perf_counter() - t0
 
     orc.threads = 1
-    m1 = min({"fixed_base": 1024, "var_base": 1024, "verify": 384, "poseidon5": 2048, "verify_compressed": 384,
+    m1 = min({"fixed_base": 1024, "fixed_base_compressed": 1024, "var_base": 1024, "verify": 384, "poseidon5": 2048, "verify_compressed": 384,
               "decompress": 2048, "sign": 512, "point_add": 16384, "compress": 1 << 18}[kind], wl.n)
     run(min(m1, 64))            # page in
     rate1 = m1 / run(m1)
@@ -726,6 +734,8 @@ def kernel_that_ran(kind, info, overlapped):
     dec = lambda b, alt: b.decode() if b else alt   # noqa: E731  (an older A/B build fills fewer fields of bjj_info)
     if kind == "fixed_base":
         return dec(info.kernel_fixed_base_overlap, "bjj_k_mul_fixed_base_2x256") if info.last_fixed_base_shape == 1 else dec(info.kernel_fixed_base, KERNEL[kind])
+    if kind == "fixed_base_compressed":
+        return "bjj_k_mul_fixed_base_2x256_c32" if info.last_fixed_base_shape == 1 else KERNEL[kind]
     if kind == "var_base":
         return dec(info.kernel_var_base_overlap, "bjj_k_mul_var_base") if info.last_var_base_form == 0 else dec(info.kernel_var_base, KERNEL[kind])
     if kind in ("verify", "verify_compressed"):
@@ -914,6 +924,12 @@ def host_api_block(ctx, n, orc):
         t_fb, t_fb_med = best(lambda: ctx._ck(ctx.lib.bjj_mul_fixed_base(ctx.handle, h_sc.ctypes.data, n, out.ctypes.data), "bjj_mul_fixed_base"), 7)
         i_fb = ctx.info()
         good = bool((np.asarray(out).reshape(n, 64)[idx] == orc.mul_fixed_base(sc.reshape(n, 32)[idx])).all())
+        # ... and the same multiplications leaving as Point::compress records (src/lib.rs:166-178): half the bytes back across PCIe
+        out32 = alloc(n * 32)
+        out32[:] = 0
+        t_fc, t_fc_med = best(lambda: ctx._ck(ctx.lib.bjj_mul_fixed_base_compressed(ctx.handle, h_sc.ctypes.data, n, out32.ctypes.data), "bjj_mul_fixed_base_compressed"), 7)
+        i_fc = ctx.info()
+        good = good and bool((np.asarray(out32).reshape(n, 32)[idx] == orc.compress(orc.mul_fixed_base(sc.reshape(n, 32)[idx]))).all())
         # variable base (Point::mul_scalar on a caller's own points, src/lib.rs:149-164): the points just computed, the same scalars
         h_pts, out_vb = alloc(n * 64), alloc(n * 64)
         h_pts[:] = out
@@ -935,6 +951,10 @@ def host_api_block(ctx, n, orc):
                               "items": n, "bytes_moved": n * 96, "entry_point": "bjj_mul_fixed_base",
                               "arrays_direct": i_fb.last_host_direct_arrays, "arrays_staged": i_fb.last_host_staged_arrays,
                               "chunks": i_fb.last_host_chunks},
+               "fixed_base_compressed": {"value": n / t_fc, "unit": UNITS["fixed_base"], "ms_per_call": t_fc * 1e3, "ms_per_call_median": t_fc_med * 1e3,
+                                         "items": n, "bytes_moved": n * 64, "entry_point": "bjj_mul_fixed_base_compressed",
+                                         "arrays_direct": i_fc.last_host_direct_arrays, "arrays_staged": i_fc.last_host_staged_arrays,
+                                         "chunks": i_fc.last_host_chunks},
                "var_base": {"value": n / t_vb, "unit": UNITS["var_base"], "ms_per_call": t_vb * 1e3, "ms_per_call_median": t_vb_med * 1e3,
                             "items": n, "bytes_moved": n * 160, "entry_point": "bjj_mul_var_base",
                             "arrays_direct": i_vb.last_host_direct_arrays, "arrays_staged": i_vb.last_host_staged_arrays,
@@ -945,7 +965,7 @@ def host_api_block(ctx, n, orc):
                           "chunks": i_v.last_host_chunks, "device_one_launch_ms": t_dev * 1e3, "vs_device_one_launch": t_v / t_dev},
                "parity_sample_ok": good}
         if kind_mem == "pinned":
-            for a in [h_sc, out, ok, h_pts, out_vb] + hv:
+            for a in [h_sc, out, out32, ok, h_pts, out_vb] + hv:
                 ctx.host_free(a)
         return res
 
@@ -973,8 +993,10 @@ def host_api_block(ctx, n, orc):
                     "staged through pinned buffers by %d copy workers.  Calls back to back for 0.5 s before the timed ones (sustained "
                     "clocks), then best of 7 (fixed_base) / 3 (verify) and the median.  Reported beside the line, never as `value`."
                     % ctx.info().host_copy_threads,
-            "fixed_base": pinned["fixed_base"], "var_base": pinned["var_base"], "verify": pinned["verify"],
-            "pageable": {"fixed_base": pageable["fixed_base"], "var_base": pageable["var_base"], "verify": pageable["verify"]},
+            "fixed_base": pinned["fixed_base"], "fixed_base_compressed": pinned["fixed_base_compressed"], "var_base": pinned["var_base"],
+            "verify": pinned["verify"],
+            "pageable": {"fixed_base": pageable["fixed_base"], "fixed_base_compressed": pageable["fixed_base_compressed"],
+                         "var_base": pageable["var_base"], "verify": pageable["verify"]},
             "copy_threads": ctx.info().host_copy_threads,
             "parity_sample_ok": pinned["parity_sample_ok"] and pageable["parity_sample_ok"]}
 
@@ -1289,6 +1311,18 @@ def optional_sections(args, hl, ctx, bjj, kind, n, rank, local_rank, world, dev,
                                                  "parity_sample_ok": ok23}
             del w23
             c23.close()
+
+        # K1 with Point::compress fused into its epilogue (bjj_mul_fixed_base_compressed_dev): same protocol as the headline
+        if kind == "fixed_base" and one_gpu:
+            wc = Workload(ctx, "fixed_base_compressed", n, rank * n, dev, stream, nb=2)
+            wc.streams = [stream, stream_b]
+            dc, kc = timed_steps(wc, 100, 20, 1, 0.5, streams=[stream, stream_b])
+            okc = wc.check_sample(orc)
+            parity = parity and okc
+            also["fixed_base_compressed"] = {"value": n * 100 / dc, "unit": UNITS["fixed_base"], "ms_per_step": dc / 100 * 1e3, "device_ms_per_launch": kc,
+                                             "streams": 2, "kernel": kernel_that_ran("fixed_base_compressed", ctx.info(), True),
+                                             "workload": WORKLOAD_TEXT["fixed_base_compressed"], "parity_sample_ok": okc}
+            del wc
 
         # PCIe-inclusive rates of the host-pointer API -- what a host holding its data in ordinary (pageable) memory gets from
         # bjj_mul_fixed_base / bjj_eddsa_verify: the chunked host-pointer pipeline around the same kernels (pinned memory copied directly,

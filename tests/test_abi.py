@@ -133,3 +133,18 @@ def test_library_is_not_older_than_its_sources():
             "sign.hpp", "bjj_constants.inc", "slot_queue.hpp", os.path.join("..", "..", "include", "bjj_hip.h")]
     newest = max(os.path.getmtime(os.path.join(d, s)) for s in srcs)
     assert os.path.getmtime(so) >= newest, "rebuild: python -c 'import __graft_entry__ as g; g.build()'"
+
+
+def test_failure_injection_is_not_in_the_shipped_library():
+    """BJJ_MULTI_INJECT_FAIL_GROUP (bjj_multi.inc) walks the RCCL failure path for tools/scale_session.sh: it is compiled in only with
+    -DBJJ_TEST_HOOKS (`make hooks` -> tests/hooks/libbjj_hip_hooks.so).  The library a caller links does not know the variable."""
+    import os
+    from conftest import ROOT
+    from babyjubjub_rs_amd import _lib
+    shipped = open(os.path.join(ROOT, "babyjubjub-rs_amd", "csrc", "libbjj_hip.so"), "rb").read()
+    assert b"BJJ_MULTI_INJECT_FAIL_GROUP" not in shipped and b"+test-hooks" not in shipped
+    hooks = os.path.join(ROOT, "tests", "hooks", "libbjj_hip_hooks.so")
+    if os.path.exists(hooks):
+        h = open(hooks, "rb").read()
+        assert b"BJJ_MULTI_INJECT_FAIL_GROUP" in h and b"+test-hooks" in h
+    assert _lib.LIB_PATH.endswith(os.path.join("csrc", "libbjj_hip.so")) or os.environ.get("BJJ_LIB_PATH")

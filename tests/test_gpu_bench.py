@@ -144,6 +144,12 @@ def test_bench_one_gpu_line_has_every_block():
     assert h["verify"]["device_one_launch_ms"] > 0 and 0.5 < h["verify"]["vs_device_one_launch"] < 5.0 and "cfg-4" in h["note"]
     assert (h["var_base"]["arrays_direct"], h["var_base"]["arrays_staged"]) == (3, 0) and hp["var_base"]["arrays_staged"] == 3
     assert h["var_base"]["value"] > 0 and h["var_base"]["vs_device_one_launch"] > 0.5
+    # round 6: the compressed-output form of K1 on device pointers (same two-stream protocol) and through the host-pointer pipeline
+    fc = j["also"]["fixed_base_compressed"]
+    assert fc["parity_sample_ok"] and fc["kernel"] == "bjj_k_mul_fixed_base_2x256_c32" and fc["value"] > 0.5 * j["value"]
+    assert h["fixed_base_compressed"]["value"] > 0 and h["fixed_base_compressed"]["bytes_moved"] == (1 << 16) * 64
+    assert (h["fixed_base_compressed"]["arrays_direct"], hp["fixed_base_compressed"]["arrays_staged"]) == (2, 2)
+    assert r.compact["also"]["host_api"]["fixed_base_compressed"]["value"] > 0 and r.compact["also"]["fixed_base_compressed"]["value"] > 0
     w23 = j["also"]["fixed_base_window_bits_23"]
     assert w23["kernel"] == "bjj_k_mul_fixed_base" and w23["streams"] == 1 and "clock_mhz" in w23 and w23["init_ms"] > 0
     if j["clock"].get("available"):

@@ -42,7 +42,7 @@ if [ "$NG" -gt 1 ]; then
   step native_bench python3 bench.py --gpus $NG --native-multi --transport rccl --chunks 4
   last_json $O/native_bench.log > $P/${TAG}_scale_native_bench.json
   # ---- (4) the failure path over live communicators: drain, ncclCommAbort, retired handle, fresh handle
-  BJJ_MULTI_INJECT_FAIL_GROUP=2 step native_failure python3 tools/native_multi_cases.py --devices $DEVS --transport rccl --expect-failure --out $P/${TAG}_scale_native_failure.json
+  BJJ_LIB_PATH=$R/tests/hooks/libbjj_hip_hooks.so BJJ_MULTI_INJECT_FAIL_GROUP=2 step native_failure python3 tools/native_multi_cases.py --devices $DEVS --transport rccl --expect-failure --out $P/${TAG}_scale_native_failure.json
 else
   export BJJ_BENCH_WINDOW_BITS=16 BJJ_BENCH_TELEMETRY_MS=20
   step tests python3 -m pytest tests -m gpu -q -x -k "multi_block_arithmetic or multi_dev_form_rccl_one_device"
@@ -54,7 +54,7 @@ else
   step native_bench python3 bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --native-multi --transport peer --chunks 4 --batch 32768 --strong-total 1048576
   last_json $O/native_bench.log > $P/${TAG}_scale_dryrun_native_bench.json
   # real RCCL with one rank: the serial schedule's gather is group 1 of the call
-  BJJ_MULTI_INJECT_FAIL_GROUP=1 step native_failure python3 tools/native_multi_cases.py --devices 0 --transport rccl --window-bits 16 --expect-failure --out $P/${TAG}_scale_dryrun_native_failure.json
+  BJJ_LIB_PATH=$R/tests/hooks/libbjj_hip_hooks.so BJJ_MULTI_INJECT_FAIL_GROUP=1 step native_failure python3 tools/native_multi_cases.py --devices 0 --transport rccl --window-bits 16 --expect-failure --out $P/${TAG}_scale_dryrun_native_failure.json
 fi
 cp $O/steps.jsonl $P/${TAG}_scale_steps.jsonl; cp $O/session.json $P/${TAG}_scale_session.json
 cat $O/steps.jsonl
