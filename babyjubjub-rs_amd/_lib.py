@@ -69,6 +69,7 @@ class BjjInfo(ctypes.Structure):
         ("kernel_fixed_base_overlap", ctypes.c_char_p),
         ("kernel_var_base_overlap", ctypes.c_char_p),
         ("last_var_base_split", ctypes.c_int),
+        ("last_host_zero_copy", ctypes.c_uint32),
     ]
 
 

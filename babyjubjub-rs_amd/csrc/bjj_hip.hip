@@ -188,6 +188,8 @@ struct bjj_ctx {
   size_t pipe_chunk = 0, pipe_first = 0;   // chunk schedule (items): first chunk, doubling up to pipe_chunk
   bool pipe_env_schedule = false;          // ... given in the environment: it overrides the entry points' own schedules too
   bool pipe_ready = false;                 // ensure_pipe's first-use block ran to its end
+  bool pipe_zero_copy = true;              // BJJ_PIPE_ZERO_COPY=0: results always leave through the copy engines (A/B, tests)
+  u32 last_host_zero_copy = 0;
   bool in_pipeline = false;                // a host-pointer call is enqueueing (enqueue_verify: where the scans run)
   bool pipe_scan_inline = true;            // BJJ_PIPE_SCAN=prio (developer): scans of the pipeline's chunks on the priority streams
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
@@ -455,6 +457,11 @@ struct PipeSpec {
   //                         but the very last one -- as in ONE launch (profiles/r06_var_base_host_schedule.txt)
   size_t tail_chunk = 0;
   bool last_on_priority_lane = false;
+  // The kernels of this entry point write every output byte exactly once and never read it (their scratch is elsewhere): when ALL
+  // output arrays are pinned, the launches get the arrays' DEVICE MAPPINGS instead of staging and there is no copy-out stage at all.
+  // Only for kernel-bound calls: a kernel's stores to mapped host memory run at the copy engines' rate (54.9 GB/s), but a workgroup
+  // holds its slot until PCIe has taken them -- K1, which is copy-bound, lost 5 % this way (profiles/r05_host_pipeline.txt).
+  bool zero_copy_out = false;
 };
 // Work of a pipelined call that does not belong to ONE chunk.  All three run on the calling thread while it enqueues:
 //   begin          once per super-batch, before the first copy; d_in / d_out = the staging arrays of the whole super-batch
@@ -465,6 +472,7 @@ struct PipeSpec {
 //                  stream of the pipeline and ev_tail are done -- host-side work on the results
 struct PipeExtra {
   void* d_extra = nullptr;     // n * PipeSpec::extra_dev_per_item bytes of the super-batch's device staging (set before begin)
+  bool zero_copy = false;      // begin's d_out[] are the device mappings of the caller's pinned output arrays (PipeSpec::zero_copy_out)
   virtual int begin(size_t n, void** d_in, void** d_out) = 0;
   virtual int chunk_arrived(size_t lo, size_t cnt, hipEvent_t arrived) = 0;
   virtual int all_arrived(hipEvent_t ev_tail) = 0;
@@ -517,6 +525,45 @@ static size_t env_items(const char* name, size_t dflt) {
   const unsigned long long v = strtoull(e, nullptr, 0);
   return v >= 64 && v <= ((size_t)1 << 24) ? ((size_t)v + 63) & ~(size_t)63 : dflt;
 }
+// The context's high-priority streams, created AND first used in a fixed order when the context is made.  HIP binds a stream to a
+// hardware queue at its first use: the streams of one priority share FOUR queues, a fifth stream takes the queue of the first, and
+// packets of streams that share a queue run one after the other.  Created on demand, the assignment depended on what the caller
+// did first: after two-stream verifications (both sets' scan streams in use) the pipeline's second lane landed on the first scan
+// stream's queue -- the stream the host-pointer pipelines run their scans and exact launches on, whose small kernels wait for
+// wave slots while the lanes' kernels fill the chip -- and a chunk's launch on that lane queued behind them: 2^20 variable-base
+// multiplications on pinned memory took 17.0 ms instead of 15.9 (profiles/r06_var_base_host_schedule.txt).  Now: copy-in, copy-out,
+// second lane, first scan stream = queues 0..3, always; the second set's scan stream (two-stream device-pointer callers only) is
+// the one that shares -- with the copy-in stream, which carries nothing while a device-pointer launch is what the caller is doing.
+//   * the second lane is a high-priority stream as well: a library that parks two normal-priority streams in the four queues of
+//     that priority (the context's own stream is one) leaves the caller's streams to share what is left -- two torch streams first
+//     used after a host-pointer call landed on ONE hardware queue and their launches ran one after the other
+//     (tools/queue_map_probe.py, profiles/r05_host_pipeline.txt)
+static int ensure_scan_stream(ScratchSet* S);
+static int ensure_pipe_streams(bjj_ctx* c) {
+  if (c->s_in && c->s_out && c->stream2 && c->ev_tail && c->set[0].scan_stream) return BJJ_OK;
+  int least = 0, greatest = 0;
+  HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  int prio_in = greatest, prio_out = greatest;
+  if (const char* e = getenv("BJJ_PIPE_COPY_PRIORITY")) {   // developer: "nn" / "hn" / "nh" / "hh" = normal / high for s_in, s_out
+    if (e[0] == 'n') prio_in = 0;
+    if (e[0] && e[1] == 'n') prio_out = 0;
+  }
+  if (!c->ev_tail) HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+  hipStream_t* order[3] = {&c->s_in, &c->s_out, &c->stream2};
+  const int prio[3] = {prio_in, prio_out, greatest};
+  for (int k = 0; k < 3; k++)
+    if (!*order[k]) {
+      HIPCK(hipStreamCreateWithPriority(order[k], hipStreamNonBlocking, prio[k]));
+      HIPCK(hipEventRecord(c->ev_tail, *order[k]));              // first use: binds the hardware queue
+      HIPCK(hipStreamSynchronize(*order[k]));
+    }
+  if (!c->set[0].scan_stream) {
+    int rc = ensure_scan_stream(&c->set[0]); if (rc) return rc;
+    HIPCK(hipEventRecord(c->ev_tail, c->set[0].scan_stream));
+    HIPCK(hipStreamSynchronize(c->set[0].scan_stream));
+  }
+  return BJJ_OK;
+}
 // streams of the pipeline, events for `chunks` chunks, dev_bytes of device staging and -- only when a pageable array takes
 // part -- the pinned rings (in_ring / out_ring bytes per slot) and the copy workers
 static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ring, size_t out_ring) {
@@ -532,21 +579,8 @@ static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ri
     if (const char* e = getenv("BJJ_PIPE_STAGING_MB")) { const long v = atol(e); if (v >= 1 && v <= 65536) c->pipe_budget = (size_t)v << 20; }
     if (const char* e = getenv("BJJ_HOST_FORCE_STAGED")) c->force_staged = e[0] == '1';
     if (const char* e = getenv("BJJ_PIPE_SCAN")) c->pipe_scan_inline = e[0] != 'p';
-    int least = 0, greatest = 0;
-    HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    int prio_in = greatest, prio_out = greatest;
-    if (const char* e = getenv("BJJ_PIPE_COPY_PRIORITY")) {   // developer: "nn" / "hn" / "nh" / "hh" = normal / high for s_in, s_out
-      if (e[0] == 'n') prio_in = 0;
-      if (e[0] && e[1] == 'n') prio_out = 0;
-    }
-    if (!c->s_in) HIPCK(hipStreamCreateWithPriority(&c->s_in, hipStreamNonBlocking, prio_in));
-    if (!c->s_out) HIPCK(hipStreamCreateWithPriority(&c->s_out, hipStreamNonBlocking, prio_out));
-    // the second lane is a high-priority stream as well: HIP gives the streams of one priority FOUR hardware queues, and a
-    // library that parks two normal-priority streams in them (the context's own stream is one) leaves the caller's streams to
-    // share what is left -- two torch streams first used after a host-pointer call landed on ONE hardware queue and their
-    // launches ran one after the other (tools/queue_map_probe.py, profiles/r05_host_pipeline.txt)
-    if (!c->stream2) HIPCK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, greatest));
-    if (!c->ev_tail) HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    if (const char* e = getenv("BJJ_PIPE_ZERO_COPY")) c->pipe_zero_copy = e[0] != '0';
+    { int rc = ensure_pipe_streams(c); if (rc) return rc; }
     c->pipe_ready = true;
   }
   try {
@@ -646,10 +680,20 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
   for (int i = 0; i < sp.n_out; i++) if (!out_direct[i]) { r_out_off[i] = out_ring; out_ring += up16((sp.out_at_end ? n : max_chunk) * sp.out_stride[i]); }
   { int rc = ensure_pipe(c, nchunks, dev_tot, in_ring, out_ring); if (rc) return rc; }
   const bool chunk_out_ring = out_ring && !sp.out_at_end;   // pageable outputs travel chunk by chunk through the ring
+  // zero-copy outputs: every output array pinned AND mapped into the device's address space
+  uint8_t* mapped_out[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool zc = sp.zero_copy_out && !out_ring && sp.n_out > 0 && !sp.out_at_end && c->pipe_zero_copy;
+  for (int i = 0; i < sp.n_out && zc; i++) {
+    void* dp = nullptr;
+    if (!out_direct[i] || hipHostGetDevicePointer(&dp, sp.out[i], 0) != hipSuccess || !dp) { (void)hipGetLastError(); zc = false; }
+    mapped_out[i] = (uint8_t*)dp;
+  }
+  c->last_host_zero_copy = zc ? 1u : 0u;
   if (sp.extra) {
     void* bi[4]; void* bo[4];
     for (int i = 0; i < sp.n_in; i++) bi[i] = c->dstage + d_in_off[i];
-    for (int i = 0; i < sp.n_out; i++) bo[i] = c->dstage + d_out_off[i];
+    for (int i = 0; i < sp.n_out; i++) bo[i] = zc ? (void*)mapped_out[i] : (void*)(c->dstage + d_out_off[i]);
+    sp.extra->zero_copy = zc;
     sp.extra->d_extra = sp.extra_dev_per_item ? c->dstage + d_extra_off : nullptr;
     int rc = sp.extra->begin(n, bi, bo); if (rc) return rc;
   }
@@ -718,7 +762,7 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
     HIPCK(hipStreamWaitEvent(lane, c->ev_in[ch], 0));
     void* d_in[4]; void* d_out[4];
     for (int i = 0; i < sp.n_in; i++) d_in[i] = c->dstage + d_in_off[i] + lo * sp.in_stride[i];
-    for (int i = 0; i < sp.n_out; i++) d_out[i] = c->dstage + d_out_off[i] + lo * sp.out_stride[i];
+    for (int i = 0; i < sp.n_out; i++) d_out[i] = (zc ? mapped_out[i] : c->dstage + d_out_off[i]) + lo * sp.out_stride[i];
     int r = launch(d_in, d_out, cnt, (void*)lane); if (r) return r;
     HIPCK(hipEventRecord(c->ev_k[ch], lane));                  // behind a kernel: its completion signal, no extra packet
     tmark(2 + 3 * ch, lane);                                   // kernels done
@@ -730,7 +774,7 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
   auto enqueue_out = [&](size_t ch) -> int {
     const int b = (int)(ch % BJJ_PIPE_BUFS);
     const size_t lo = lo_of[ch], cnt = cnt_of(ch);
-    if (sp.out_at_end) { tr("kernels seen complete", ch); return BJJ_OK; }   // nothing leaves chunk by chunk
+    if (sp.out_at_end || zc) { tr("kernels seen complete", ch); return BJJ_OK; }   // nothing leaves chunk by chunk / the kernels wrote the caller's arrays themselves
     if (chunk_out_ring && ch >= BJJ_PIPE_BUFS) { int r = finish_out(ch - BJJ_PIPE_BUFS); if (r) return r; }   // frees pin_out[b]
     for (int i = 0; i < sp.n_out; i++)
       HIPCK(hipMemcpyAsync(out_direct[i] ? sp.out[i] + lo * sp.out_stride[i] : c->pin_out[b] + r_out_off[i], c->dstage + d_out_off[i] + lo * sp.out_stride[i],
@@ -844,6 +888,7 @@ static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch
   }
   c->in_pipeline = false;
   c->last_host_direct = n_direct; c->last_host_staged = n_staged; c->last_host_chunks = chunks;
+  if (!sp.zero_copy_out) c->last_host_zero_copy = 0;
   // the call has synchronised for the caller: a verify / variable-base workgroup that gave up waiting for a table slot makes
   // it an error here, not at some later bjj_sync.  Only the pipeline's OWN streams have been waited for: while a
   // device-pointer launch of the caller is still in flight on one of the sets, its workgroups are popping and pushing the rings --
@@ -983,6 +1028,7 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   if (se == hipSuccess) se = hipHostMalloc((void**)&c->vb_seen, (BJJ_SCRATCH_SETS + 1) * sizeof(u32), hipHostMallocDefault);
   if (se != hipSuccess) { (void)hipGetLastError(); ctx_destroy(c); return set_err(BJJ_E_HIP, std::string("bjj_init: stream/event: ") + hipGetErrorString(se)); }
   memset(c->vb_seen, 0, (BJJ_SCRATCH_SETS + 1) * sizeof(u32));
+  { const int rc_ = ensure_pipe_streams(c); if (rc_) { ctx_destroy(c); return rc_; } }   // the hardware-queue plan of the context, fixed now
   {  // XCDs of this device (the verify kernels keep one queue of table slots per XCD)
     u32* d_word = nullptr;
     if (hipMalloc((void**)&d_word, sizeof(u32)) == hipSuccess) {
@@ -1143,6 +1189,7 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   info->last_fixed_base_shape = c->last_k1;
   info->last_var_base_form = c->last_k2;
   info->last_var_base_split = c->last_vb_split;
+  info->last_host_zero_copy = c->last_host_zero_copy;
   info->last_verify_dispatch = c->last_verify_mode;
   info->last_host_direct_arrays = c->last_host_direct;
   info->last_host_staged_arrays = c->last_host_staged;
@@ -1308,7 +1355,7 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
 //   when everything has landed: the host lays the few exact results over their slots in the caller's array
 // Before: K6 behind K2 in EVERY chunk's lane -- one off-curve point in 4 096 cost 2^20 items on pinned memory +71 % (15.9 ->
 // 27.3 ms, profiles/r05_var_base_offcurve.txt).
-static int var_base_bulk_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t scalar_bytes, size_t n, void* d_out, void* stream) {
+static int var_base_bulk_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t scalar_bytes, size_t n, void* d_out, uint8_t* xy, void* stream) {
   SET_ENTER(c, stream, n, false);
   // one tile per workgroup, whatever else is in flight: the chunks' launches are then work-conserving among themselves -- a
   // workgroup retires after its tile and the slot goes to whichever launch has tiles pending -- where the grid-strided form's
@@ -1319,17 +1366,18 @@ static int var_base_bulk_launch(bjj_ctx* c, const void* d_pts, const void* d_sca
   if (kv == 1) c->rings_used = true;
   c->last_vb_split = 1;
   LAUNCHCK(bjjk::mul_var_base_main(st, c->cus, c->lanes_var, kv, (const uint8_t*)d_pts, (const uint8_t*)d_scalars, (int)(scalar_bytes / 4), n, (uint8_t*)d_out,
-                                   S->scratch, S->vb_tables, nullptr, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)), "variable base (bulk)");
+                                   S->scratch, S->vb_tables, nullptr, S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16), xy), "variable base (bulk)");
   SET_LEAVE(c);
 }
 struct VarBasePipe : PipeExtra {
   bjj_ctx* c;
   int sc_words;
   const uint8_t *pts = nullptr, *scalars = nullptr;
+  uint8_t* out = nullptr;      // zero_copy: the device mapping of the caller's pinned output array (K6 writes its items' slots itself)
   size_t n = 0;
   VarBasePipe(bjj_ctx* c_, size_t scalar_bytes) : c(c_), sc_words((int)(scalar_bytes / 4)) {}
   int begin(size_t n_, void** d_in, void** d_out) override {
-    (void)d_out;
+    out = (uint8_t*)d_out[0];
     n = n_;
     pts = (const uint8_t*)d_in[0]; scalars = (const uint8_t*)d_in[1];
     ScratchSet* S = &c->set[0];
@@ -1350,14 +1398,15 @@ struct VarBasePipe : PipeExtra {
   }
   int all_arrived(hipEvent_t ev_tail) override {
     ScratchSet* S = &c->set[0];
-    LAUNCHCK(bjjk::mul_var_base_exact(S->scan_stream, c->cus * 4, pts, scalars, sc_words, nullptr, c->pipe_wl, (uint8_t*)d_extra,
-                                      &c->vb_seen[BJJ_SCRATCH_SETS]), "variable-base (exact)");
+    // zero-copy: d_extra is K2's stash and K6 stores straight into the caller's array; else d_extra takes K6's results compactly
+    LAUNCHCK(bjjk::mul_var_base_exact(S->scan_stream, c->cus * 4, pts, scalars, sc_words, zero_copy ? out : nullptr, c->pipe_wl,
+                                      zero_copy ? nullptr : (uint8_t*)d_extra, &c->vb_seen[BJJ_SCRATCH_SETS]), "variable-base (exact)");
     HIPCK(hipEventRecord(ev_tail, S->scan_stream));
     return BJJ_OK;
   }
   int finish(uint8_t* const* host_out, size_t) override {
     const size_t cnt = __atomic_load_n(&c->vb_seen[BJJ_SCRATCH_SETS], __ATOMIC_ACQUIRE);   // K6 is done (ev_tail): its count is in
-    if (!cnt) return BJJ_OK;
+    if (!cnt || zero_copy) return BJJ_OK;
     if (cnt > n) return set_err(BJJ_E_HIP, "variable base: the exact list is longer than the batch");
     const size_t need = cnt * 68;
     if (need > c->patch_host_bytes) {
@@ -1388,10 +1437,17 @@ static int var_base_host(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars,
     return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return var_base_launch(c, i[0], i[1], scalar_bytes, cnt, o[0], st, "bjj_mul_var_base"); });
   VarBasePipe vp(c, scalar_bytes);
   sp.extra = &vp;
-  sp.extra_dev_per_item = 64;         // K6's compact results: as many as there are items, at worst
-  sp.tail_chunk = (size_t)1 << 16;
+  sp.extra_dev_per_item = 64;         // K6's compact results (as many as there are items, at worst) -- or, zero-copy, K2's phase-1 stash
   sp.last_on_priority_lane = true;
-  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return var_base_bulk_launch(c, i[0], i[1], scalar_bytes, cnt, o[0], st); });
+  // Pinned output array: the kernels store into it themselves (64 MB of results over the 15 ms the kernels take anyway) -- no copy-out
+  // stage, so nothing favours small chunks once the inputs are in: the chunks double without a cap (2^16, 2^17, 2^18, the rest), and
+  // the call ends when the last tile does, like one device-pointer launch.  Pageable output: copies chunk by chunk as before, the last
+  // chunk small (its copy-out is the one nothing hides).
+  if (c->pipe_zero_copy && !c->force_staged && host_range_pinned(out, n * 64)) { sp.zero_copy_out = true; sp.max_chunk = (size_t)1 << 24; }
+  else sp.tail_chunk = (size_t)1 << 16;
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) {
+    const size_t lo = (size_t)((const uint8_t*)i[0] - vp.pts) / 64;           // this chunk's first item within the super-batch
+    return var_base_bulk_launch(c, i[0], i[1], scalar_bytes, cnt, o[0], vp.zero_copy ? (uint8_t*)vp.d_extra + lo * 64 : nullptr, st); });
 }
 int bjj_mul_var_base_dev(bjj_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* stream) {
   return var_base_launch(c, d_pts, d_scalars, 32, n, d_out, stream, "bjj_mul_var_base_dev");
@@ -1756,6 +1812,7 @@ int bjj_mul_fixed_base(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* ou
 int bjj_mul_fixed_base_compressed(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* out32) {
   HOST_PROLOGUE("bjj_mul_fixed_base_compressed", !scalars || !out32);
   PipeSpec sp = {1, 1, {scalars}, {32}, {out32}, {32}, false};
+  sp.tail_chunk = (size_t)1 << 15;   // 32 B in, 32 B out per item: the two PCIe directions are level, the last chunk's kernel + copy-out is what nothing hides
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_fixed_base_compressed_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_mul_var_base(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out) {
@@ -1828,6 +1885,7 @@ int bjj_public_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out_xy) 
 int bjj_public_keys_compressed(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out32) {
   HOST_PROLOGUE("bjj_public_keys_compressed", !keys || !out32);
   PipeSpec sp = {1, 1, {keys}, {32}, {out32}, {32}, true};
+  sp.tail_chunk = (size_t)1 << 15;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_public_keys_compressed_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_sign_compressed(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_sig64, uint8_t* ok) {

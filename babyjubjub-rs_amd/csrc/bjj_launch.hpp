@@ -53,7 +53,8 @@ hipError_t mul_fixed_base_scan(hipStream_t st, int cus, const uint32_t* table, i
 // K2 (slow != nullptr: appends the off-curve items it skips; nullptr: they are on somebody else's list), the on-curve scan that makes
 // such a list, and K6 over a list (patch: compact results beside the indices instead of the items' own slots; seen: host word <- count)
 hipError_t mul_var_base_main(hipStream_t st, int cus, int lanes_per_cu, int variant, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
-                             uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow, uint32_t* slotq, uint32_t slot_cap);
+                             uint8_t* out, uint32_t* scratch, uint32_t* vb_tables, uint32_t* slow, uint32_t* slotq, uint32_t slot_cap,
+                             uint8_t* xy = nullptr);   // xy: phase-1 stash apart from `out` (which may then be mapped host memory)
 hipError_t var_base_list_reset(hipStream_t st, uint32_t* list);
 hipError_t var_base_scan(hipStream_t st, int grid, const uint8_t* pts, size_t first, size_t end, uint32_t* list);
 hipError_t mul_var_base_exact(hipStream_t st, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, uint8_t* out,

@@ -103,7 +103,9 @@ __device__ __forceinline__ void epilogue_stash_skipped(u32* scr_item) {
 }
 // Epilogue forms (template flags; the default -- affine output, no skipped items -- is what K1 and the signer use, and its code
 // does not change when the other forms are instantiated next to it)
-enum : unsigned { EPI_AFFINE = 0u, EPI_COMPRESS = 1u, EPI_SKIPPABLE = 2u };
+//   EPI_STASH_APART: the affine form with the phase-1 stash in `xy` when that is given (run time) instead of in the output slots -- for
+//   an output array that must be written exactly once and never read: the caller's pinned HOST memory behind its device mapping
+enum : unsigned { EPI_AFFINE = 0u, EPI_COMPRESS = 1u, EPI_SKIPPABLE = 2u, EPI_STASH_APART = 4u };
 // Phase-2: given inv = 1 / (product of this lane's Z_0..Z_i) as a PLAIN (non-Montgomery) integer, finish item i
 // and step inv down to 1 / (Z_0..Z_{i-1}).  A Montgomery product of a plain and a Montgomery operand is the plain
 // product, so Y * (1/Z) lands directly on the canonical output integer.  Output: reference-curve (x, y), or with EPI_COMPRESS
@@ -146,6 +148,7 @@ __device__ __forceinline__ void epilogue_run(Fr run, size_t n, size_t tid, size_
   for (size_t m = cnt; m-- > 0;) {
     size_t i = tid + m * nthreads;
     if (FORM & EPI_COMPRESS) epilogue_finish<FORM>(inv, out + i * 32, xy + i * 64, scratch + i * 16);
+    else if (FORM & EPI_STASH_APART) epilogue_finish<FORM>(inv, out + i * 64, (xy ? xy : out) + i * 64, scratch + i * 16);
     else epilogue_finish<FORM>(inv, out + i * 64, out + i * 64, scratch + i * 16);
   }
 }

@@ -61,7 +61,11 @@ __device__ void wide_scalar_mod_order(const u32* __restrict__ w, int nw, u32 out
 template <bool WIDE>
 __device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars, int sc_words,
                                               size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch,
-                                              u32* __restrict__ tbl, u32* __restrict__ slow, u32* lds, size_t tid, size_t nthreads) {
+                                              u32* __restrict__ tbl, u32* __restrict__ slow, u32* lds, size_t tid, size_t nthreads,
+                                              uint8_t* __restrict__ xy) {
+  // xy != nullptr: X, Y of phase 1 are stashed there and `out` is written once, by phase 2, and never read -- `out` may then be the
+  // caller's pinned host array behind its device mapping (the host-pointer pipeline: no copy-out stage, bjj_hip.hip)
+  uint8_t* const stash = xy ? xy : out;
   Fr run = fr_one();
 #pragma unroll 1
   for (size_t i = tid; i < n; i += nthreads) {
@@ -79,29 +83,29 @@ __device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, c
         load_w8(scalars + i * 32, sc);
         p = var_base_fast(x, y, sc, tbl, c_K);
       }
-      epilogue_stash(p, run, out + i * 64, scratch + i * 16);
+      epilogue_stash(p, run, stash + i * 64, scratch + i * 16);
     } else {
       if (slow) slow[8 + atomicAdd(&slow[0], 1u)] = (u32)i;
       epilogue_stash_skipped(scratch + i * 16);                 // K6's item: its output slot is not ours
     }
   }
-  epilogue_run<BJJ_K2_BLOCK, EPI_SKIPPABLE>(run, n, tid, nthreads, out, scratch, lds);
+  epilogue_run<BJJ_K2_BLOCK, EPI_SKIPPABLE | EPI_STASH_APART>(run, n, tid, nthreads, out, scratch, lds, xy);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
                                                                 const uint8_t* __restrict__ scalars, size_t n,
                                                                 uint8_t* __restrict__ out, u32* __restrict__ scratch,
-                                                                u32* __restrict__ vb_tables, u32* __restrict__ slow) {
+                                                                u32* __restrict__ vb_tables, u32* __restrict__ slow, uint8_t* __restrict__ xy) {
   __shared__ u32 lds[NL * 64];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  var_base_body<false>(pts, scalars, 8, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x);
+  var_base_body<false>(pts, scalars, 8, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x, xy);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_wide(const uint8_t* __restrict__ pts,
                                                                      const uint8_t* __restrict__ scalars, int sc_words, size_t n,
                                                                      uint8_t* __restrict__ out, u32* __restrict__ scratch,
-                                                                     u32* __restrict__ vb_tables, u32* __restrict__ slow) {
+                                                                     u32* __restrict__ vb_tables, u32* __restrict__ slow, uint8_t* __restrict__ xy) {
   __shared__ u32 lds[NL * 64];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  var_base_body<true>(pts, scalars, sc_words, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x);
+  var_base_body<true>(pts, scalars, sc_words, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x, xy);
 }
 // ---- dispatch mode 1: one tile of BJJ_K2_BLOCK consecutive items per workgroup ------------------------------------------
 // The grid-strided form above is one resident set of workgroups whose lanes own 5 or 6 items of a 2^20-item batch: the
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var
 template <bool WIDE>
 __device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars, int sc_words, size_t n,
                                               uint8_t* __restrict__ out, u32* __restrict__ scratch, u32* __restrict__ vb_tables,
-                                              u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap_nx) {
+                                              u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap_nx, uint8_t* __restrict__ xy) {
   __shared__ u32 lds[NL * 64];
   __shared__ u32 sh_slot;
   u32* q = slot_queue_of_this_xcd(slotq, cap_nx);
@@ -123,20 +127,20 @@ __device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, c
   const size_t base = (size_t)blockIdx.x * BJJ_K2_BLOCK;
   const size_t hi = base + BJJ_K2_BLOCK < n ? base + BJJ_K2_BLOCK : n;
   var_base_body<WIDE>(pts, scalars, sc_words, hi, out, scratch, vb_tables + ((size_t)slot * BJJ_K2_BLOCK + threadIdx.x) * VB_TABLE_WORDS, slow,
-                      lds, base + threadIdx.x, (size_t)BJJ_K2_BLOCK);
+                      lds, base + threadIdx.x, (size_t)BJJ_K2_BLOCK, xy);
   slot_release_wave();   // every wave of the tile wrote tables into the slot: all acknowledged before the barrier, the push behind it
   __syncthreads();
   if (threadIdx.x == 0) slot_push_one(q, cap_nx, slot);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_tiles(const uint8_t* __restrict__ pts,
     const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch, u32* __restrict__ vb_tables,
-    u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap) {
-  var_base_tile<false>(pts, scalars, 8, n, out, scratch, vb_tables, slow, slotq, cap);
+    u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap, uint8_t* __restrict__ xy) {
+  var_base_tile<false>(pts, scalars, 8, n, out, scratch, vb_tables, slow, slotq, cap, xy);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_wide_tiles(const uint8_t* __restrict__ pts,
     const uint8_t* __restrict__ scalars, int sc_words, size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch,
-    u32* __restrict__ vb_tables, u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap) {
-  var_base_tile<true>(pts, scalars, sc_words, n, out, scratch, vb_tables, slow, slotq, cap);
+    u32* __restrict__ vb_tables, u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap, uint8_t* __restrict__ xy) {
+  var_base_tile<true>(pts, scalars, sc_words, n, out, scratch, vb_tables, slow, slotq, cap, xy);
 }
 // The on-curve scan of items first .. end-1 (2 conversions + 5 multiplications per item against K2's ~3 000): the items K6 owns,
 // appended to `list` (same layout as `slow`; somebody else has reset it).  Runs on the priority stream while K2 fills the chip:
@@ -254,7 +258,7 @@ int occ_point_add() {
 // K2 alone.  slow != nullptr: the list is reset here and filled by the kernel (K6 must follow on `st`: mul_var_base_exact);
 // slow == nullptr: the off-curve items are somebody else's (var_base_scan + mul_var_base_exact on another stream).
 hipError_t mul_var_base_main(hipStream_t st, int cus, int lanes_per_cu, int variant, const uint8_t* pts, const uint8_t* scalars, int sc_words, size_t n,
-                             uint8_t* out, u32* scratch, u32* vb_tables, u32* slow, u32* slotq, u32 slot_cap) {
+                             uint8_t* out, u32* scratch, u32* vb_tables, u32* slow, u32* slotq, u32 slot_cap, uint8_t* xy) {
   if (slow) {
     hipError_t e = hipMemsetAsync(slow, 0, 8 * sizeof(u32), st);
     if (e != hipSuccess) return e;
@@ -263,17 +267,17 @@ hipError_t mul_var_base_main(hipStream_t st, int cus, int lanes_per_cu, int vari
   if (variant == 1) {
   if (sc_words == 8)
     BJJ_LAUNCH(bjj_k_mul_var_base_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow,
-                       slotq, slot_cap);
+                       slotq, slot_cap, xy);
   else
     BJJ_LAUNCH(bjj_k_mul_var_base_wide_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
-                       vb_tables, slow, slotq, slot_cap);
+                       vb_tables, slow, slotq, slot_cap, xy);
   } else {
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
   if (sc_words == 8)
-    BJJ_LAUNCH(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow);
+    BJJ_LAUNCH(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow, xy);
   else
     BJJ_LAUNCH(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
-                       vb_tables, slow);
+                       vb_tables, slow, xy);
   }
   return hipGetLastError();
 }

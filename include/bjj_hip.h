@@ -321,6 +321,7 @@ typedef struct {
   const char* kernel_var_base_overlap;
   /* since 0.6.0 */
   int last_var_base_split;     /* variable base, the exact kernel for off-curve points: 0 = behind the batch kernel, 1 = beside it (scan first) */
+  uint32_t last_host_zero_copy; /* last host-pointer call: 1 = the kernels stored their results into the (pinned) output array themselves, no copy-out stage */
 } bjj_info;
 int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
 

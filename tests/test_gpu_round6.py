@@ -284,6 +284,7 @@ def test_host_pipeline_every_density_every_item(oracle, mem):
                 i = ctx.info()
                 assert i.last_host_chunks == 3 and i.last_var_base_split == 1
                 assert (i.last_host_direct_arrays, i.last_host_staged_arrays) == ((3, 0) if mem == "pinned" else (0, 3))
+                assert i.last_host_zero_copy == (1 if mem == "pinned" else 0)      # pinned output: the kernels (K2 and K6) store into it themselves
                 got = np.asarray(a_o).reshape(n, 64).copy()
                 ref = _one_launch(ctx, pts, s_in, 64 if wide else 32)
                 assert (got == ref).all(), (density, wide, np.nonzero((got != ref).any(axis=1))[0][:8], int(bad.sum()))
@@ -315,3 +316,32 @@ def test_host_pipeline_super_batches_patch_their_own_range(oracle, monkeypatch):
         assert (got[sel] == oracle.mul_var_base(pts[sel], sc[sel])).all()
     finally:
         ctx.close()
+
+
+def test_host_pipeline_through_the_copy_engines_when_zero_copy_is_off(oracle, monkeypatch):
+    """BJJ_PIPE_ZERO_COPY=0: pinned outputs leave by D2H copies chunk by chunk and the exact kernel's results are laid over them by the
+    host afterwards -- the path pageable outputs always take; a pinned INPUT with a pageable OUTPUT takes it too"""
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    n = (1 << 16) + (1 << 17) + 70003
+    for env in ("0", None):
+        if env is not None:
+            monkeypatch.setenv("BJJ_PIPE_ZERO_COPY", env)
+        ctx = bjj.Context(0, 16)
+        try:
+            pts, bad = _points(ctx, n, 300, 7)
+            sc = w.scalars_254(n, offset=3)
+            a_p, a_s = _pinned_copy(ctx, pts), _pinned_copy(ctx, sc)
+            a_o = ctx.host_empty(n * 64) if env is not None else np.zeros(n * 64, np.uint8)
+            a_o[:] = 0xAB
+            assert ctx.lib.bjj_mul_var_base(ctx.handle, a_p.ctypes.data, a_s.ctypes.data, ctypes.c_size_t(n), a_o.ctypes.data) == 0
+            i = ctx.info()
+            assert i.last_host_zero_copy == 0 and i.last_var_base_split == 1 and i.last_host_chunks == 3
+            got = np.asarray(a_o).reshape(n, 64)
+            assert (got == _one_launch(ctx, pts, sc)).all()
+            sel = np.nonzero(bad)[0]
+            assert sel.size > 500 and (got[sel] == oracle.mul_var_base(pts[sel], sc[sel])).all()
+        finally:
+            ctx.close()
+        if env is not None:
+            monkeypatch.delenv("BJJ_PIPE_ZERO_COPY")
