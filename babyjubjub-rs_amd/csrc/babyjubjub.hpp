@@ -244,6 +244,28 @@ inline std::vector<Signature> sign_batch(const std::vector<PrivateKey>& k, const
   return out;
 }
 
+// wire-format OUTPUT, one pass each (the compression is fused into the producing kernel): sk.public().compress() (lib.rs:304-306 +
+// 166-178), B8.mul_scalar(n).compress() (149-164 + 166-178), sk.sign(msg)?.compress() (308-342 + 245-258; ok[i] == 0 and an all-zero
+// record where sign returns Err)
+inline std::vector<std::array<uint8_t, 32>> public_keys_compressed_batch(const std::vector<PrivateKey>& k, Context& c = Context::global()) {
+  std::vector<std::array<uint8_t, 32>> out(k.size());
+  check(bjj_public_keys_compressed(c.handle(), (const uint8_t*)k.data(), k.size(), (uint8_t*)out.data()), "bjj_public_keys_compressed");
+  return out;
+}
+inline std::vector<std::array<uint8_t, 32>> mul_fixed_base_compressed_batch(const std::vector<U256>& n, Context& c = Context::global()) {
+  std::vector<std::array<uint8_t, 32>> out(n.size());
+  check(bjj_mul_fixed_base_compressed(c.handle(), (const uint8_t*)n.data(), n.size(), (uint8_t*)out.data()), "bjj_mul_fixed_base_compressed");
+  return out;
+}
+inline std::vector<std::array<uint8_t, 64>> sign_compressed_batch(const std::vector<PrivateKey>& k, const std::vector<U256>& msg,
+                                                                 std::vector<uint8_t>& ok, Context& c = Context::global()) {
+  if (k.size() != msg.size()) throw std::runtime_error("sign_compressed_batch: length mismatch");
+  std::vector<std::array<uint8_t, 64>> out(k.size()); ok.assign(k.size(), 0);
+  check(bjj_sign_compressed(c.handle(), (const uint8_t*)k.data(), (const uint8_t*)msg.data(), k.size(), (uint8_t*)out.data(), ok.data()),
+        "bjj_sign_compressed");
+  return out;
+}
+
 // Schnorr signer, batch (lib.rs:344-361): ok[i] == 0 where sign_schnorr returns Err (msg > Q)
 inline std::vector<Point> sign_schnorr_batch(const std::vector<PrivateKey>& k, const std::vector<U256>& msg,
                                              const std::vector<std::array<uint8_t, BJJ_SCHNORR_NONCE_BYTES>>& nonces,

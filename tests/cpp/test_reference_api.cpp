@@ -72,6 +72,25 @@ static void test_circomlib_testvector() {  // lib.rs:689-738 (everything downstr
   U256 big = U256::from_str("21888242871839275222246405745257275088548364400416034343698204186575808495618");  // Q + 1
   ASSERT_TRUE(!verify(pk, sig, big));  // lib.rs:396-398
 }
+static void test_compressed_outputs() {  // the circomlib vector (lib.rs:689-738) through the fused wire-format outputs
+  std::vector<uint8_t> kb(32); for (int i = 0; i < 32; i++) kb[i] = (uint8_t)(i % 10);
+  PrivateKey sk = PrivateKey::import(kb);
+  U256 msg; for (int i = 0; i < 10; i++) msg.le[i] = (uint8_t)i;
+  std::vector<PrivateKey> ks(300, sk); std::vector<U256> ms(300, msg);
+  ms[7] = U256::from_str("21888242871839275222246405745257275088548364400416034343698204186575808495618");  // Q + 1: Err
+  auto pkc = public_keys_compressed_batch(ks);
+  ASSERT_TRUE(pkc[0] == sk.public_key().compress() && pkc[299] == pkc[0]);
+  std::vector<uint8_t> ok;
+  auto sigc = sign_compressed_batch(ks, ms, ok);
+  Signature made = sk.sign(msg);
+  ASSERT_TRUE(ok[0] == 1 && sigc[0] == made.compress() && sigc[299] == sigc[0]);
+  std::array<uint8_t, 64> zero{}; ASSERT_TRUE(ok[7] == 0 && sigc[7] == zero);
+  auto back = decompress_signature(sigc[0]);                   // lib.rs:260-268
+  ASSERT_TRUE(back.r_b8.equals(made.r_b8)); ASSERT_EQ(back.s, made.s);
+  ASSERT_TRUE(verify_compressed_batch({pkc[0]}, {sigc[0]}, {msg})[0] == 1);
+  std::vector<U256> n(100, sk.scalar_key());
+  ASSERT_TRUE(mul_fixed_base_compressed_batch(n)[99] == pkc[0]);     // public() == B8.mul_scalar(scalar_key), lib.rs:304-306
+}
 static void test_point_compress_decompress() {  // lib.rs:575-594
   Point p = P();
   auto c = p.compress();
@@ -165,7 +184,7 @@ static void test_batch_pinned() {  // the batch forms on page-locked vectors: co
 
 int main() {
   try {
-    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_point_compress_decompress(); test_schnorr_signature(); test_batch(); test_batch_pinned(); test_multi();
+    test_add_same_point(); test_add_different_points(); test_mul_scalar(); test_circomlib_testvector(); test_point_compress_decompress(); test_compressed_outputs(); test_schnorr_signature(); test_batch(); test_batch_pinned(); test_multi();
   } catch (const std::exception& e) { printf("EXCEPTION %s\n", e.what()); return 2; }
   printf(failures ? "FAILED %d\n" : "ok (reference tests re-stated in C++)\n", failures);
   return failures ? 1 : 0;
