@@ -1443,7 +1443,7 @@ static int var_base_host(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars,
   // stage, so nothing favours small chunks once the inputs are in: the chunks double without a cap (2^16, 2^17, 2^18, the rest), and
   // the call ends when the last tile does, like one device-pointer launch.  Pageable output: copies chunk by chunk as before, the last
   // chunk small (its copy-out is the one nothing hides).
-  if (c->pipe_zero_copy && !c->force_staged && host_range_pinned(out, n * 64)) { sp.zero_copy_out = true; sp.max_chunk = (size_t)1 << 24; }
+  if (c->pipe_zero_copy && c->k2_variant != 0 && !c->force_staged && host_range_pinned(out, n * 64)) { sp.zero_copy_out = true; sp.max_chunk = (size_t)1 << 24; }   // (the stash apart exists for the tiles)
   else sp.tail_chunk = (size_t)1 << 16;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) {
     const size_t lo = (size_t)((const uint8_t*)i[0] - vp.pts) / 64;           // this chunk's first item within the super-batch
@@ -1813,6 +1813,8 @@ int bjj_mul_fixed_base_compressed(bjj_ctx* c, const uint8_t* scalars, size_t n, 
   HOST_PROLOGUE("bjj_mul_fixed_base_compressed", !scalars || !out32);
   PipeSpec sp = {1, 1, {scalars}, {32}, {out32}, {32}, false};
   sp.tail_chunk = (size_t)1 << 15;   // 32 B in, 32 B out per item: the two PCIe directions are level, the last chunk's kernel + copy-out is what nothing hides
+  static const bool zc = [] { const char* e = getenv("BJJ_FB_COMPRESSED_ZERO_COPY"); return e && e[0] == '1'; }();   // experiment (tools/fb_compressed_sweep.py)
+  if (zc) { sp.zero_copy_out = true; sp.tail_chunk = 0; }
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_fixed_base_compressed_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_mul_var_base(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out) {

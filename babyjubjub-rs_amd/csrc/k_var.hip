@@ -58,14 +58,15 @@ __device__ void wide_scalar_mod_order(const u32* __restrict__ w, int nw, u32 out
 // 156-157); for an on-curve point n*P == (n mod 8l)*P exactly.
 // ---------------------------------------------------------------------------
 // The items of one lane are tid, tid + nthreads, ... below n; tbl = this lane's table scratch.
-template <bool WIDE>
+template <bool WIDE, bool APART = false>
 __device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars, int sc_words,
                                               size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch,
                                               u32* __restrict__ tbl, u32* __restrict__ slow, u32* lds, size_t tid, size_t nthreads,
                                               uint8_t* __restrict__ xy) {
-  // xy != nullptr: X, Y of phase 1 are stashed there and `out` is written once, by phase 2, and never read -- `out` may then be the
-  // caller's pinned host array behind its device mapping (the host-pointer pipeline: no copy-out stage, bjj_hip.hip)
-  uint8_t* const stash = xy ? xy : out;
+  // APART (the *_zc kernels): X, Y of phase 1 are stashed in `xy` and `out` is written once, by phase 2, and never read -- `out` may
+  // then be the caller's pinned host array behind its device mapping (the host-pointer pipeline: no copy-out stage, bjj_hip.hip).
+  // A compile-time form: the kernels every device-pointer caller gets do not carry the second pointer.
+  uint8_t* const stash = APART ? xy : out;
   Fr run = fr_one();
 #pragma unroll 1
   for (size_t i = tid; i < n; i += nthreads) {
@@ -89,23 +90,23 @@ __device__ __forceinline__ void var_base_body(const uint8_t* __restrict__ pts, c
       epilogue_stash_skipped(scratch + i * 16);                 // K6's item: its output slot is not ours
     }
   }
-  epilogue_run<BJJ_K2_BLOCK, EPI_SKIPPABLE | EPI_STASH_APART>(run, n, tid, nthreads, out, scratch, lds, xy);
+  epilogue_run<BJJ_K2_BLOCK, APART ? (EPI_SKIPPABLE | EPI_STASH_APART) : EPI_SKIPPABLE>(run, n, tid, nthreads, out, scratch, lds, xy);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base(const uint8_t* __restrict__ pts,
                                                                 const uint8_t* __restrict__ scalars, size_t n,
                                                                 uint8_t* __restrict__ out, u32* __restrict__ scratch,
-                                                                u32* __restrict__ vb_tables, u32* __restrict__ slow, uint8_t* __restrict__ xy) {
+                                                                u32* __restrict__ vb_tables, u32* __restrict__ slow) {
   __shared__ u32 lds[NL * 64];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  var_base_body<false>(pts, scalars, 8, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x, xy);
+  var_base_body<false>(pts, scalars, 8, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x, nullptr);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_wide(const uint8_t* __restrict__ pts,
                                                                      const uint8_t* __restrict__ scalars, int sc_words, size_t n,
                                                                      uint8_t* __restrict__ out, u32* __restrict__ scratch,
-                                                                     u32* __restrict__ vb_tables, u32* __restrict__ slow, uint8_t* __restrict__ xy) {
+                                                                     u32* __restrict__ vb_tables, u32* __restrict__ slow) {
   __shared__ u32 lds[NL * 64];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  var_base_body<true>(pts, scalars, sc_words, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x, xy);
+  var_base_body<true>(pts, scalars, sc_words, n, out, scratch, vb_tables + tid * VB_TABLE_WORDS, slow, lds, tid, (size_t)gridDim.x * blockDim.x, nullptr);
 }
 // ---- dispatch mode 1: one tile of BJJ_K2_BLOCK consecutive items per workgroup ------------------------------------------
 // The grid-strided form above is one resident set of workgroups whose lanes own 5 or 6 items of a 2^20-item batch: the
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var
 // workgroups, which are in other phases, keep the SIMDs busy), retires, and the hardware dispatches the next tile -- of
 // this launch or of the other one in flight: the pair is work-conserving.  The per-lane table scratch comes from a
 // per-XCD slot queue (k_common.hpp), one slot = the tables of one workgroup.
-template <bool WIDE>
+template <bool WIDE, bool APART = false>
 __device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars, int sc_words, size_t n,
                                               uint8_t* __restrict__ out, u32* __restrict__ scratch, u32* __restrict__ vb_tables,
                                               u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap_nx, uint8_t* __restrict__ xy) {
@@ -126,7 +127,7 @@ __device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, c
   const u32 slot = sh_slot;
   const size_t base = (size_t)blockIdx.x * BJJ_K2_BLOCK;
   const size_t hi = base + BJJ_K2_BLOCK < n ? base + BJJ_K2_BLOCK : n;
-  var_base_body<WIDE>(pts, scalars, sc_words, hi, out, scratch, vb_tables + ((size_t)slot * BJJ_K2_BLOCK + threadIdx.x) * VB_TABLE_WORDS, slow,
+  var_base_body<WIDE, APART>(pts, scalars, sc_words, hi, out, scratch, vb_tables + ((size_t)slot * BJJ_K2_BLOCK + threadIdx.x) * VB_TABLE_WORDS, slow,
                       lds, base + threadIdx.x, (size_t)BJJ_K2_BLOCK, xy);
   slot_release_wave();   // every wave of the tile wrote tables into the slot: all acknowledged before the barrier, the push behind it
   __syncthreads();
@@ -134,13 +135,24 @@ __device__ __forceinline__ void var_base_tile(const uint8_t* __restrict__ pts, c
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_tiles(const uint8_t* __restrict__ pts,
     const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch, u32* __restrict__ vb_tables,
-    u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap, uint8_t* __restrict__ xy) {
-  var_base_tile<false>(pts, scalars, 8, n, out, scratch, vb_tables, slow, slotq, cap, xy);
+    u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap) {
+  var_base_tile<false>(pts, scalars, 8, n, out, scratch, vb_tables, slow, slotq, cap, nullptr);
 }
 __global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_wide_tiles(const uint8_t* __restrict__ pts,
     const uint8_t* __restrict__ scalars, int sc_words, size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch,
+    u32* __restrict__ vb_tables, u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap) {
+  var_base_tile<true>(pts, scalars, sc_words, n, out, scratch, vb_tables, slow, slotq, cap, nullptr);
+}
+// The tiles with the phase-1 stash apart from the output array (zero-copy outputs of the host-pointer pipeline)
+__global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_tiles_zc(const uint8_t* __restrict__ pts,
+    const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch, u32* __restrict__ vb_tables,
+    u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap, uint8_t* __restrict__ xy) {
+  var_base_tile<false, true>(pts, scalars, 8, n, out, scratch, vb_tables, slow, slotq, cap, xy);
+}
+__global__ void __launch_bounds__(BJJ_K2_BLOCK, BJJ_K2_MIN_BLOCKS) bjj_k_mul_var_base_wide_tiles_zc(const uint8_t* __restrict__ pts,
+    const uint8_t* __restrict__ scalars, int sc_words, size_t n, uint8_t* __restrict__ out, u32* __restrict__ scratch,
     u32* __restrict__ vb_tables, u32* __restrict__ slow, u32* __restrict__ slotq, u32 cap, uint8_t* __restrict__ xy) {
-  var_base_tile<true>(pts, scalars, sc_words, n, out, scratch, vb_tables, slow, slotq, cap, xy);
+  var_base_tile<true, true>(pts, scalars, sc_words, n, out, scratch, vb_tables, slow, slotq, cap, xy);
 }
 // The on-curve scan of items first .. end-1 (2 conversions + 5 multiplications per item against K2's ~3 000): the items K6 owns,
 // appended to `list` (same layout as `slow`; somebody else has reset it).  Runs on the priority stream while K2 fills the chip:
@@ -246,6 +258,8 @@ namespace bjjk {
 int var_base_block() { return BJJ_K2_BLOCK; }
 int var_base_lanes_per_cu() {   // resident lanes of K2 per CU (sizes the per-lane table scratch and the grid): the least of all forms
   int a = occupancy_of(bjj_k_mul_var_base_tiles, BJJ_K2_BLOCK), b = occupancy_of(bjj_k_mul_var_base_wide_tiles, BJJ_K2_BLOCK);
+  const int az = occupancy_of(bjj_k_mul_var_base_tiles_zc, BJJ_K2_BLOCK), bz = occupancy_of(bjj_k_mul_var_base_wide_tiles_zc, BJJ_K2_BLOCK);
+  a = a < az ? a : az; b = b < bz ? b : bz;
   const int a0 = occupancy_of(bjj_k_mul_var_base, BJJ_K2_BLOCK), b0 = occupancy_of(bjj_k_mul_var_base_wide, BJJ_K2_BLOCK);
   a = a < a0 ? a : a0; b = b < b0 ? b : b0;
   return (a < b ? a : b) * BJJ_K2_BLOCK;   // one grid size (and one per-lane table allocation) serves both kernels
@@ -264,20 +278,28 @@ hipError_t mul_var_base_main(hipStream_t st, int cus, int lanes_per_cu, int vari
     if (e != hipSuccess) return e;
   }
   const size_t want = (n + BJJ_K2_BLOCK - 1) / BJJ_K2_BLOCK, cap = (size_t)cus * (size_t)(lanes_per_cu / BJJ_K2_BLOCK);
-  if (variant == 1) {
+  if (xy && variant != 1) return hipErrorInvalidValue;   // the stash apart exists for the tiles only (what the pipeline launches)
+  if (variant == 1 && xy) {
   if (sc_words == 8)
-    BJJ_LAUNCH(bjj_k_mul_var_base_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow,
+    BJJ_LAUNCH(bjj_k_mul_var_base_tiles_zc, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow,
                        slotq, slot_cap, xy);
   else
-    BJJ_LAUNCH(bjj_k_mul_var_base_wide_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
+    BJJ_LAUNCH(bjj_k_mul_var_base_wide_tiles_zc, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
                        vb_tables, slow, slotq, slot_cap, xy);
+  } else if (variant == 1) {
+  if (sc_words == 8)
+    BJJ_LAUNCH(bjj_k_mul_var_base_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow,
+                       slotq, slot_cap);
+  else
+    BJJ_LAUNCH(bjj_k_mul_var_base_wide_tiles, dim3((unsigned)(want ? want : 1)), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
+                       vb_tables, slow, slotq, slot_cap);
   } else {
   const int grid = (int)(want < cap ? (want ? want : 1) : cap);
   if (sc_words == 8)
-    BJJ_LAUNCH(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow, xy);
+    BJJ_LAUNCH(bjj_k_mul_var_base, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, n, out, scratch, vb_tables, slow);
   else
     BJJ_LAUNCH(bjj_k_mul_var_base_wide, dim3(grid), dim3(BJJ_K2_BLOCK), 0, st, pts, scalars, sc_words, n, out, scratch,
-                       vb_tables, slow, xy);
+                       vb_tables, slow);
   }
   return hipGetLastError();
 }

@@ -11,7 +11,7 @@ fi
 if has ab; then
   (echo "# this library vs the round-5 library (tools/ab_r05.so = a8a9861 rebuilt), interleaved, tools/ab_lib.sh"; ROUNDS=2 STEPS=10 bash tools/ab_lib.sh tools/ab_r05.so -- fixed_base var_base verify) > $O/ab_r05_vs_r06.txt 2>&1
   cat $O/ab_r05_vs_r06.txt
-  for e in "BJJ_VB_SPLIT=0" "BJJ_VB_SPLIT=1" ""; do echo "# env: ${e:-(default: by the context's history)}"; env $e python3 tools/vb_beside_ab.py 2>&1 | grep -v amdgpu; done > $O/var_base_beside_ab.txt
+  for e in "BJJ_VB_SPLIT=0" "BJJ_VB_SPLIT=1" ""; do echo "# env: ${e:-default: by the history of the context}"; env $e python3 tools/vb_beside_ab.py 2>&1 | grep -v amdgpu; done > $O/var_base_beside_ab.txt
   cat $O/var_base_beside_ab.txt
 fi
 if has latency; then
