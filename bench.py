@@ -983,9 +983,18 @@ def host_api_block(ctx, n, orc):
         ctx.mul_var_base_dev(d_pts.data_ptr(), d_sc.data_ptr(), n, d_vb.data_ptr(), 0)
         ctx.sync()
     t_dev_vb, _ = best(one_launch_vb, 3)
-    pinned = run("pinned")
-    pageable = run("pageable")
-    return {"note": "PCIe-inclusive: host pointers in, host pointers out, synchronous call.  fixed_base / verify = caller arrays in "
+    # the hwmon poller reads the SMU every 5 ms; round 6 found that such reads can hold the SOC clock -- and with it the copy engines'
+    # device-to-host rate -- up (profiles/r06_host_d2h_power_states.txt): the host-pointer rows are measured WITHOUT it
+    if TELEMETRY:
+        TELEMETRY.paused = True
+    try:
+        pinned = run("pinned")
+        pageable = run("pageable")
+    finally:
+        if TELEMETRY:
+            TELEMETRY.paused = False
+    return {"telemetry_paused": True,
+            "note": "PCIe-inclusive: host pointers in, host pointers out, synchronous call.  fixed_base / verify = caller arrays in "
                     "pinned memory (bjj_host_alloc): copied directly, chunked pipeline (2^15 items first, doubling to 2^18; "
                     "verify 2^16 to 2^19, its off-curve items as one launch beside the chunks'), chunk kernels alternating over the context's two "
                     "compute streams; verify inputs = the cfg-4 workload of `also.verify` (1 in 64 corrupted), `vs_device_one_launch` = the call "
