@@ -438,7 +438,12 @@ static int ensure_scratch(bjj_ctx* c, ScratchSet* S, size_t n) {
 //   and the size doubles up to 2^18; a remainder below half a chunk is merged into the
 //   last chunk (a small last launch leaves the chip half empty).  BJJ_PIPE_FIRST_CHUNK / BJJ_PIPE_CHUNK (items) override.
 // ---------------------------------------------------------------------------
-#define BJJ_PIPE_CHUNK ((size_t)1 << 18)
+// The cap was 2^18 until round 6.  With 2^18-item chunks (16 MB copy-outs for 64-byte results) the copy engines' device-to-host rate has two
+// states per process -- 56 or 44 GB/s, the SOC clock domain awake or asleep between calls, depending on what the process did before
+// (profiles/r06_host_d2h_power_states.txt): 2^20 fixed-base multiplications take 1.575 or 1.92 ms.  With 2^17-item chunks the slow state
+// does not occur (1.565-1.60 ms in every sequence tried) and the fast state loses nothing.  The compressed fixed-base forms keep 2^18
+// (1.155 ms in the fast state against 1.26 with 2^17; 1.30-1.36 in the slow state with either).
+#define BJJ_PIPE_CHUNK ((size_t)1 << 17)
 #define BJJ_PIPE_FIRST_CHUNK ((size_t)1 << 15)
 struct PipeSpec {
   int n_in, n_out;
@@ -1429,6 +1434,7 @@ struct VarBasePipe : PipeExtra {
 static int var_base_host(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t scalar_bytes, size_t n, uint8_t* out) {
   PipeSpec sp = {2, 1, {pts, scalars}, {64, scalar_bytes}, {out}, {64}, false};
   sp.first_chunk = (size_t)1 << 16;   // 14 ms of kernels over 3 ms of copies: a 2^15-item launch holds its lane for a whole round with a quarter of the chip
+  sp.max_chunk = (size_t)1 << 18;
   static const bool per_chunk = [] { const char* e = getenv("BJJ_PIPE_VAR_BASE_SPLIT"); return e && e[0] == '0'; }();   // developer: the round-5 form
   { ENTER_DEVICE(c->device); int rc_ = ensure_pipe(c, 0, 0, 0, 0); if (rc_) return rc_; }
   const size_t first = c->pipe_env_schedule ? c->pipe_first : sp.first_chunk;
@@ -1444,7 +1450,7 @@ static int var_base_host(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars,
   // the call ends when the last tile does, like one device-pointer launch.  Pageable output: copies chunk by chunk as before, the last
   // chunk small (its copy-out is the one nothing hides).
   if (c->pipe_zero_copy && c->k2_variant != 0 && !c->force_staged && host_range_pinned(out, n * 64)) { sp.zero_copy_out = true; sp.max_chunk = (size_t)1 << 24; }   // (the stash apart exists for the tiles)
-  else sp.tail_chunk = (size_t)1 << 16;
+  else { sp.tail_chunk = (size_t)1 << 16; sp.max_chunk = (size_t)1 << 18; }
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) {
     const size_t lo = (size_t)((const uint8_t*)i[0] - vp.pts) / 64;           // this chunk's first item within the super-batch
     return var_base_bulk_launch(c, i[0], i[1], scalar_bytes, cnt, o[0], vp.zero_copy ? (uint8_t*)vp.d_extra + lo * 64 : nullptr, st); });
@@ -1813,6 +1819,7 @@ int bjj_mul_fixed_base_compressed(bjj_ctx* c, const uint8_t* scalars, size_t n, 
   HOST_PROLOGUE("bjj_mul_fixed_base_compressed", !scalars || !out32);
   PipeSpec sp = {1, 1, {scalars}, {32}, {out32}, {32}, false};
   sp.tail_chunk = (size_t)1 << 15;   // 32 B in, 32 B out per item: the two PCIe directions are level, the last chunk's kernel + copy-out is what nothing hides
+  sp.max_chunk = (size_t)1 << 18;
   static const bool zc = [] { const char* e = getenv("BJJ_FB_COMPRESSED_ZERO_COPY"); return e && e[0] == '1'; }();   // experiment (tools/fb_compressed_sweep.py)
   if (zc) { sp.zero_copy_out = true; sp.tail_chunk = 0; }
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_fixed_base_compressed_dev(c, i[0], cnt, o[0], st); });
@@ -1888,6 +1895,7 @@ int bjj_public_keys_compressed(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_
   HOST_PROLOGUE("bjj_public_keys_compressed", !keys || !out32);
   PipeSpec sp = {1, 1, {keys}, {32}, {out32}, {32}, true};
   sp.tail_chunk = (size_t)1 << 15;
+  sp.max_chunk = (size_t)1 << 18;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_public_keys_compressed_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_sign_compressed(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_sig64, uint8_t* ok) {

@@ -108,7 +108,7 @@
  * long) as ONE launch for the whole call beside the chunks' launches, and their verdicts leave the device once, at the end:
  * 2^20 signatures of which 1 in 128 is off the curve take about 19 ms pinned, 18.2 ms as one device-pointer launch.
  * More environment knobs (read when the context first runs a host-pointer call): BJJ_PIPE_CHUNK / BJJ_PIPE_FIRST_CHUNK
- * (items per pipeline chunk: the first chunk, doubling up to the cap; defaults 32768 / 262144, for the verifiers 65536 /
+ * (items per pipeline chunk: the first chunk, doubling up to the cap; defaults 32768 / 131072 -- 262144 for the compressed fixed-base forms --, for the verifiers 65536 /
  * 524288 and for the variable-base multiplications 65536 / 262144; a value in the environment applies to all), BJJ_PIPE_STAGING_MB
  * (device staging a call may take, default 1024; larger batches run as consecutive super-batches), BJJ_HOST_FORCE_STAGED=1
  * (treat every host array as pageable), BJJ_STAGE_THREADS.
