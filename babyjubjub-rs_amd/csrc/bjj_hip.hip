@@ -668,6 +668,19 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
     }
     if (tail) lo_of.push_back(body_n);
     lo_of.push_back(n);
+    // developer: BJJ_PIPE_SCHEDULE="a,b,c,..." = the chunk sizes themselves (items; the last one repeats, the remainder joins the last chunk)
+    static const std::vector<size_t> forced = [] {
+      std::vector<size_t> v;
+      if (const char* e = getenv("BJJ_PIPE_SCHEDULE"))
+        for (const char* p = e; *p;) { char* q = nullptr; const unsigned long long x = strtoull(p, &q, 0); if (q == p) break; if (x >= 64) v.push_back((size_t)x & ~(size_t)63); p = *q ? q + 1 : q; }
+      return v;
+    }();
+    if (!forced.empty()) {
+      lo_of.clear();
+      size_t at = 0, k = 0;
+      while (at < n) { lo_of.push_back(at); at += forced[k < forced.size() ? k : forced.size() - 1]; k++; }
+      lo_of.push_back(n);
+    }
   }
   const size_t nchunks = lo_of.size() - 1;
   static const int parity_env = [] { const char* e = getenv("BJJ_PIPE_LANE_PARITY"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();   // developer A/B
