@@ -16,7 +16,17 @@ def _flip(rng, arr, frac):
     return rows
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def _more_seeds(default, var="BJJ_SOAK_HOST_VERIFY_SEEDS"):
+    """BJJ_SOAK_HOST_VERIFY_SEEDS / BJJ_SOAK_HOST_VAR_BASE_SEEDS / BJJ_SOAK_ALL_SEEDS = first:count in the environment (developer): a longer run"""
+    import os
+    e = os.environ.get(var)
+    if not e:
+        return default
+    a, b = e.split(":")
+    return list(range(int(a), int(a) + int(b)))
+
+
+@pytest.mark.parametrize("seed", _more_seeds([1, 2, 3, 4, 5, 6], "BJJ_SOAK_ALL_SEEDS"))
 def test_soak_all_entry_points(gpu_ctx, oracle, seed):
     rng = np.random.default_rng(seed)
     n = int(rng.integers(1, 1500))
@@ -30,11 +40,18 @@ def test_soak_all_entry_points(gpu_ctx, oracle, seed):
     assert (ok == oko).all() and (r == ro).all() and (s == so).all()
     pk = gpu_ctx.public_keys(keys)
     assert (pk == oracle.public_keys(keys)).all()
+    # the same results leaving in wire format, compression fused into the producing kernels (round 6)
+    sigc, okc = gpu_ctx.sign_compressed(keys, msgs)
+    wantc = np.concatenate([oracle.compress(ro), so], axis=1)
+    wantc[oko == 0] = 0
+    assert (okc == oko).all() and (sigc == wantc).all()
+    assert (gpu_ctx.public_keys_compressed(keys) == oracle.compress(pk)).all()
     # scalar multiplications on (possibly corrupted = off-curve) points with arbitrary 256-bit scalars
     pts = pk.copy()
     _flip(rng, pts, 0.1)
     sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     assert (gpu_ctx.mul_fixed_base(sc) == oracle.mul_fixed_base(sc)).all()
+    assert (gpu_ctx.mul_fixed_base_compressed(sc) == oracle.compress(oracle.mul_fixed_base(sc))).all()
     assert (gpu_ctx.mul_var_base(pts, sc) == oracle.mul_var_base(pts, sc)).all()
     assert (gpu_ctx.point_add(pts, pk) == oracle.point_add(pts, pk)).all()
     # raw projective add / affine on arbitrary (x, y, z) records, and scalars wider than 256 bits
@@ -76,16 +93,6 @@ def test_soak_all_entry_points(gpu_ctx, oracle, seed):
     # hash
     h = rng.integers(0, 256, (n, 160), dtype=np.uint8)
     assert (gpu_ctx.poseidon5(h) == oracle.poseidon5(h)).all()
-
-
-def _more_seeds(default):
-    """BJJ_SOAK_HOST_VERIFY_SEEDS=first:count in the environment (developer): a longer run of the test below"""
-    import os
-    e = os.environ.get("BJJ_SOAK_HOST_VERIFY_SEEDS")
-    if not e:
-        return default
-    a, b = e.split(":")
-    return list(range(int(a), int(a) + int(b)))
 
 
 @pytest.mark.parametrize("seed", _more_seeds([11, 12, 13, 14]))
@@ -143,3 +150,60 @@ def test_soak_host_verify_across_chunks(gpu_ctx, oracle, seed):
             gpu_ctx.host_free(b)
         if gpu_ctx.host_is_pinned(ok):
             gpu_ctx.host_free(ok)
+
+
+@pytest.mark.parametrize("seed", _more_seeds([21, 22, 23, 24, 25, 26], "BJJ_SOAK_HOST_VAR_BASE_SEEDS"))
+def test_soak_host_var_base_across_chunks(gpu_ctx, oracle, seed):
+    """bjj_mul_var_base / _wide on host pointers at sizes of several chunks (round 6: per-chunk scans into one list, ONE exact launch per call beside
+    the chunks' tile launches; a pinned output array is written by the kernels themselves, a pageable one gets the exact results laid over it by the
+    host).  Random size, random density of off-curve points (none ... 1 in 3), each array pinned or pageable at random; every item against ONE
+    device-pointer launch of the same inputs, the off-curve items and a stride against the oracle."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(100000, 400000))
+    dev = torch.device("cuda", 0)
+    pts = gpu_ctx.mul_fixed_base(rng.integers(0, 256, (n, 32), dtype=np.uint8)).copy()
+    dens = [0.0, 1 / 4096, 1 / 128, 1 / 16, 1 / 3, 1 / 1000][seed % 6]
+    off = rng.random(n) < dens
+    pts[off, int(rng.integers(0, 64))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    wide = int(rng.integers(1, 4)) if seed % 2 else 1               # 32-byte or 64 / 96-byte scalars
+    sc = rng.integers(0, 256, (n, 32 * wide), dtype=np.uint8)
+    d_p, d_s = torch.from_numpy(pts.reshape(-1)).to(dev), torch.from_numpy(sc.reshape(-1)).to(dev)
+    d_o = torch.full((n * 64,), 0xEE, dtype=torch.uint8, device=dev)
+    if wide == 1:
+        gpu_ctx.mul_var_base_dev(d_p.data_ptr(), d_s.data_ptr(), n, d_o.data_ptr())
+    else:
+        gpu_ctx.mul_var_base_wide_dev(d_p.data_ptr(), d_s.data_ptr(), 32 * wide, n, d_o.data_ptr())
+    gpu_ctx.sync()
+    want = d_o.cpu().numpy().reshape(n, 64)
+    held, ptrs, pinned = [], [], []
+    for a in (pts.reshape(-1), sc.reshape(-1)):
+        if rng.random() < 0.5:
+            b = gpu_ctx.host_empty(a.size); b[:] = a; held.append(b); ptrs.append(b.ctypes.data); pinned.append(True)
+        else:
+            ptrs.append(a.ctypes.data); pinned.append(False)
+    out_pinned = bool(rng.random() < 0.5)
+    out = gpu_ctx.host_empty(n * 64) if out_pinned else np.empty(n * 64, np.uint8)
+    out[:] = 0xCD
+    if wide == 1:
+        rc = gpu_ctx.lib.bjj_mul_var_base(gpu_ctx.handle, ptrs[0], ptrs[1], ctypes.c_size_t(n), out.ctypes.data)
+    else:
+        rc = gpu_ctx.lib.bjj_mul_var_base_wide(gpu_ctx.handle, ptrs[0], ptrs[1], ctypes.c_size_t(32 * wide), ctypes.c_size_t(n), out.ctypes.data)
+    assert rc == 0, gpu_ctx.lib.bjj_last_error()
+    i = gpu_ctx.info()
+    import os
+    zc_on = os.environ.get("BJJ_PIPE_ZERO_COPY", "1") != "0"         # (developer runs of this soak with the copy-out stage forced)
+    assert i.last_host_chunks >= 2 and i.last_var_base_split == 1 and i.last_host_zero_copy == (1 if out_pinned and zc_on else 0)
+    assert i.last_host_direct_arrays == sum(pinned) + out_pinned
+    got = np.asarray(out).reshape(n, 64).copy()
+    assert (got == want).all(), (n, dens, wide, int((got != want).any(axis=1).sum()))
+    idx = np.unique(np.concatenate([np.arange(0, n, max(1, n // 60)), np.nonzero(off)[0][:60]]))
+    ref = np.empty((idx.size, 64), np.uint8)
+    for k, j in enumerate(idx):
+        oracle.lib.bjjref_mul_scalar(oracle._p(pts[j]), oracle._p(sc[j]), ctypes.c_size_t(32 * wide), oracle._p(ref[k]))
+    assert (got[idx] == ref).all()
+    for b in held:
+        gpu_ctx.host_free(b)
+    if out_pinned:
+        gpu_ctx.host_free(out)
