@@ -1352,12 +1352,13 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
   c->last_vb_split = split ? 1 : 0;
   if (split) {
     { int rc_ = ensure_scan_stream(S); if (rc_) return rc_; }
+    hipStream_t xs = S->scan_stream;   // (the copy streams or the second lane instead: no difference, profiles/r06_var_base_beside_ab.txt)
     HIPCK(hipEventRecord(S->ev_scan_in, st));
-    HIPCK(hipStreamWaitEvent(S->scan_stream, S->ev_scan_in, 0));
-    LAUNCHCK(bjjk::var_base_list_reset(S->scan_stream, S->slow), "variable-base list");
-    LAUNCHCK(bjjk::var_base_scan(S->scan_stream, grid_for(c, n, c->occ_vb_scan, 64), pts, 0, n, S->slow), "variable-base scan");
-    LAUNCHCK(bjjk::mul_var_base_exact(S->scan_stream, c->cus * 4, pts, sc, sc_words, (uint8_t*)d_out, S->slow, nullptr, seen), "variable-base (exact)");
-    HIPCK(hipEventRecord(S->ev_scan_out, S->scan_stream));
+    HIPCK(hipStreamWaitEvent(xs, S->ev_scan_in, 0));
+    LAUNCHCK(bjjk::var_base_list_reset(xs, S->slow), "variable-base list");
+    LAUNCHCK(bjjk::var_base_scan(xs, grid_for(c, n, c->occ_vb_scan, 64), pts, 0, n, S->slow), "variable-base scan");
+    LAUNCHCK(bjjk::mul_var_base_exact(xs, c->cus * 4, pts, sc, sc_words, (uint8_t*)d_out, S->slow, nullptr, seen), "variable-base (exact)");
+    HIPCK(hipEventRecord(S->ev_scan_out, xs));
   }
   LAUNCHCK_S(bjjk::mul_var_base_main(st, c->cus, c->lanes_var, kv, pts, sc, sc_words, n, (uint8_t*)d_out, S->scratch, S->vb_tables, split ? nullptr : S->slow,
                                      S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)), who);

@@ -167,6 +167,27 @@ __global__ void __launch_bounds__(64) bjj_k_var_base_scan(const uint8_t* __restr
     if (!ref_on_curve(x, y, c_K)) list[8 + atomicAdd(&list[0], 1u)] = (u32)i;
   }
 }
+#ifdef BJJ_K6_EXPERIMENT
+__device__ int bjj_k6_xmode = 0;
+// mode 4 / 5: instead of K6 a kernel WITHOUT scratch (and without LDS) that sleeps ~4.9 ms: one wave (4) or 169 waves (5)
+__global__ void __launch_bounds__(64) bjj_k_xsleep(const u32* __restrict__ slow) {
+  if (slow[0] == 0) return;
+  for (int k = 0; k < 1400; k++) __builtin_amdgcn_s_sleep(127);
+}
+// mode 6: the same with 2 KB of LDS; mode 7: the same with 160 VGPRs allocated (a clobbered high register)
+__global__ void __launch_bounds__(64) bjj_k_xsleep_lds(const u32* __restrict__ slow, u32* sink) {
+  __shared__ u32 pad[512];
+  pad[threadIdx.x] = slow[1];
+  if (slow[0] == 0) return;
+  for (int k = 0; k < 1400; k++) __builtin_amdgcn_s_sleep(127);
+  if (pad[(threadIdx.x + 1) & 63] == 0xdeadbeefu) sink[0] = 1;
+}
+__global__ void __launch_bounds__(64) bjj_k_xsleep_vgpr(const u32* __restrict__ slow) {
+  if (slow[0] == 0) return;
+  asm volatile("v_mov_b32 v159, 0" ::: "v159");
+  for (int k = 0; k < 1400; k++) __builtin_amdgcn_s_sleep(127);
+}
+#endif
 // K6: exact replay of the reference's loop for the (rare) off-curve inputs, one per lane; sc_words words per scalar.
 //   patch == nullptr : result j goes to its item's slot out + i * 64
 //   patch != nullptr : result j goes to patch + j * 64, next to its index slow[8 + j] (the host-pointer pipeline: a chunk's results
@@ -180,7 +201,17 @@ __global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __
   // three K2 waves, and at equal priority the instruction arbiter gives it a quarter of the issue slots: the chain stretches to
   // the length of the whole K2 launch and becomes the critical path.  Raised wave priority keeps it at its own latency; the few
   // K6 waves cost K2 nothing measurable.
+#ifdef BJJ_K6_EXPERIMENT   // A/B build only (make EXTRA=-DBJJ_K6_EXPERIMENT): what about K6 beside K2 costs K2 ~0.25 ms per busy K6 wave?
+  const int xmode = bjj_k6_xmode;
+  if (xmode != 1) __builtin_amdgcn_s_setprio(3);
+  if (xmode >= 2) {           // 2: resident and asleep for ~4.8 ms; 3: resident and spinning on the scalar unit -- no arithmetic, no memory, wrong results
+    if (blockIdx.x * blockDim.x < slow[0])
+      for (int k = 0; k < (xmode == 2 ? 1400 : 350000); k++) { if (xmode == 2) __builtin_amdgcn_s_sleep(127); else asm volatile("s_nop 15"); }
+    return;
+  }
+#else
   __builtin_amdgcn_s_setprio(3);
+#endif
   const u32 cnt = slow[0];
   if (seen && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(seen, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
@@ -310,6 +341,13 @@ hipError_t var_base_scan(hipStream_t st, int grid, const uint8_t* pts, size_t fi
 }
 hipError_t mul_var_base_exact(hipStream_t st, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, uint8_t* out, const u32* slow,
                               uint8_t* patch, u32* seen) {
+#ifdef BJJ_K6_EXPERIMENT
+  { const char* e = getenv("BJJ_K6_XMODE"); const int v = e ? atoi(e) : 0;
+    if (v == 4 || v == 5) { BJJ_LAUNCH(bjj_k_xsleep, dim3(v == 4 ? 1 : 169), dim3(64), 0, st, slow); return hipGetLastError(); }
+    if (v == 6) { BJJ_LAUNCH(bjj_k_xsleep_lds, dim3(4), dim3(64), 0, st, slow, (u32*)slow + 4); return hipGetLastError(); }
+    if (v == 7) { BJJ_LAUNCH(bjj_k_xsleep_vgpr, dim3(4), dim3(64), 0, st, slow); return hipGetLastError(); } }
+  { static const int m = [] { const char* e = getenv("BJJ_K6_XMODE"); const int v = e ? atoi(e) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(bjj_k6_xmode), &v, sizeof(int)); return v; }(); (void)m; }
+#endif
   BJJ_LAUNCH(bjj_k_mul_var_base_exact, dim3(grid_exact), dim3(64), 0, st, pts, scalars, sc_words, out, slow, patch, seen);
   return hipGetLastError();
 }
