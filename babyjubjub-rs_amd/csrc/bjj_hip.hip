@@ -175,6 +175,7 @@ struct bjj_ctx {
   // (CopyPool), never by the enqueueing thread
   hipStream_t s_in = nullptr, s_out = nullptr, stream2 = nullptr;
   std::vector<hipEvent_t> ev_in, ev_k, ev_out;   // per chunk of a super-batch (grown on demand)
+  std::vector<hipEvent_t> ev_dec;          // wire-format verifier through the pipeline: behind a chunk's decompressions (VerifyCompressedPipe)
   hipEvent_t ev_tail = nullptr;            // behind the extra stages of a call (PipeExtra: verify's batch-wide exact launch)
   u32* pipe_wl = nullptr;                  // verify through the pipeline: ONE list of off-curve items per super-batch (VerifyPipe)
   size_t pipe_wl_items = 0;
@@ -473,6 +474,8 @@ struct PipeSpec {
 //   chunk_arrived  behind the H2D of items lo .. lo+cnt-1 (ev_in of the chunk has been recorded: make a stream wait for it)
 //   all_arrived    behind the last chunk; whatever it enqueues is covered by ev_tail, which the call waits for before it copies
 //                  `out_at_end` outputs and returns
+//   all_launched   behind the last chunk's launch -- for stages that need what the chunks' own launches produce (the wire-format verifier scans
+//                  points its chunks' launches have decompressed); a stage that uses it records ev_tail there instead of in all_arrived
 //   finish         last: every copy of the super-batch has landed in the caller's arrays (host_out = where its outputs begin), every
 //                  stream of the pipeline and ev_tail are done -- host-side work on the results
 struct PipeExtra {
@@ -481,6 +484,7 @@ struct PipeExtra {
   virtual int begin(size_t n, void** d_in, void** d_out) = 0;
   virtual int chunk_arrived(size_t lo, size_t cnt, hipEvent_t arrived) = 0;
   virtual int all_arrived(hipEvent_t ev_tail) = 0;
+  virtual int all_launched(hipEvent_t ev_tail) { (void)ev_tail; return BJJ_OK; }   // behind the LAST chunk's launch (what it enqueues is covered by ev_tail, too)
   virtual int finish(uint8_t* const* host_out, size_t n) { (void)host_out; (void)n; return BJJ_OK; }
   virtual ~PipeExtra() {}
 };
@@ -782,6 +786,7 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
     for (int i = 0; i < sp.n_in; i++) d_in[i] = c->dstage + d_in_off[i] + lo * sp.in_stride[i];
     for (int i = 0; i < sp.n_out; i++) d_out[i] = (zc ? mapped_out[i] : c->dstage + d_out_off[i]) + lo * sp.out_stride[i];
     int r = launch(d_in, d_out, cnt, (void*)lane); if (r) return r;
+    if (sp.extra && ch + 1 == nchunks) { r = sp.extra->all_launched(c->ev_tail); if (r) return r; }
     HIPCK(hipEventRecord(c->ev_k[ch], lane));                  // behind a kernel: its completion signal, no extra packet
     tmark(2 + 3 * ch, lane);                                   // kernels done
     tr("kernels enqueued", ch);
@@ -971,6 +976,7 @@ static void ctx_destroy(bjj_ctx* c) {
   if (c->ev_tail) hipEventDestroy(c->ev_tail);
   if (c->pipe_wl) hipFree(c->pipe_wl);
   for (hipEvent_t e : c->ev_k) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_dec) hipEventDestroy(e);
   if (c->err_words) hipHostFree(c->err_words);
   if (c->vb_seen) hipHostFree(c->vb_seen);
   if (c->patch_host) hipHostFree(c->patch_host);
@@ -1617,6 +1623,84 @@ static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_
   // than the copy-bound default (2^16 / 2^19: 19.17 ms, 2^15 / 2^18: 19.36 ms; profiles/r05_host_verify_exact_split.txt)
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return verify_bulk_launch(c, schnorr, i[0], i[1], i[2], i[3], cnt, o[0], st); });
 }
+// ---- the wire-format verifier through the pipeline (round 6) ------------------------------------------------------------------
+// bjj_eddsa_verify_compressed on host pointers used to be the device entry point per chunk: decompressions, scan and a launch that carried the
+// chunk's own exact groups -- the form the plain verifiers left in round 5 -- and with the pipeline's default chunks it took 31.7 ms for 2^20
+// signatures of which 1 in 64 is corrupted (39.5 ms with the 2^17-item cap of round 6) against 23.5 ms for one device-pointer launch.  Now, like
+// VerifyPipe, with one more stage in front:
+//   per chunk, on its lane:     decompress pk, decompress R (+ s) into the super-batch's staging (d_extra: 162 B per item), an event;
+//                               behind the event, on the priority stream, the on-curve scan of the chunk into ONE batch-wide list;
+//                               the bulk launch of the chunk on its lane
+//   behind the last chunk:      ONE exact launch over the list, then ONE pass that writes verdict 2 where pk or R did not decompress (such an item
+//                               decompresses to (0, 0), which is off the curve: it is on the list, the exact launch writes it last, the pass after it)
+struct VerifyCompressedPipe : PipeExtra {
+  bjj_ctx* c;
+  const uint8_t *pk32 = nullptr, *sig64 = nullptr, *msg = nullptr;
+  uint8_t *ok = nullptr, *pk_xy = nullptr, *r_xy = nullptr, *s32 = nullptr, *f_pk = nullptr, *f_r = nullptr;
+  size_t n = 0, launched = 0;
+  explicit VerifyCompressedPipe(bjj_ctx* c_) : c(c_) {}
+  int begin(size_t n_, void** d_in, void** d_out) override {
+    n = n_; launched = 0;
+    pk32 = (const uint8_t*)d_in[0]; sig64 = (const uint8_t*)d_in[1]; msg = (const uint8_t*)d_in[2];
+    ok = (uint8_t*)d_out[0];
+    pk_xy = (uint8_t*)d_extra; r_xy = pk_xy + n * 64; s32 = r_xy + n * 64; f_pk = s32 + n * 32; f_r = f_pk + n;
+    ScratchSet* S = &c->set[0];
+    { int rc_ = ensure_scratch(c, S, 1); if (rc_) return rc_; }
+    { int rc_ = ensure_scan_stream(S); if (rc_) return rc_; }
+    { int rc_ = set_enter(c, S, S->scan_stream); if (rc_) return rc_; }     // (as VerifyPipe: the exact launch works in this set's tables)
+    if (n > c->pipe_wl_items) {
+      if (c->pipe_wl) { HIPCK(hipDeviceSynchronize()); HIPCK(hipFree(c->pipe_wl)); c->pipe_wl = nullptr; c->pipe_wl_items = 0; }
+      HIPCK(hipMalloc((void**)&c->pipe_wl, (n + 16) * sizeof(u32)));
+      c->pipe_wl_items = n;
+    }
+    LAUNCHCK(bjjk::verify_list_reset(S->scan_stream, c->pipe_wl), "verify list");
+    return BJJ_OK;
+  }
+  int chunk_arrived(size_t, size_t, hipEvent_t) override { return BJJ_OK; }
+  int all_arrived(hipEvent_t) override { return BJJ_OK; }
+  // one chunk on its lane (called by the pipeline's launch closure): items lo .. lo + cnt - 1 of the super-batch
+  int launch_chunk(size_t lo, size_t cnt, hipStream_t lane) {
+    ScratchSet* S = &c->set[0];
+    const int g = grid_for(c, cnt, c->occ_decomp);
+    LAUNCHCK(bjjk::decompress_points(lane, g, pk32 + lo * 32, 32, cnt, pk_xy + lo * 64, f_pk + lo, nullptr), "decompress(pk)");
+    LAUNCHCK(bjjk::decompress_points(lane, g, sig64 + lo * 64, 64, cnt, r_xy + lo * 64, f_r + lo, s32 + lo * 32), "decompress(sig)");
+    try {
+      while (c->ev_dec.size() <= launched) { hipEvent_t e = nullptr; HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_dec.push_back(e); }
+    } catch (...) { return set_err(BJJ_E_NOMEM, "host-pointer pipeline: out of host memory"); }
+    hipEvent_t ev = c->ev_dec[launched++];
+    HIPCK(hipEventRecord(ev, lane));
+    HIPCK(hipStreamWaitEvent(S->scan_stream, ev, 0));
+    const int sg = grid_for(c, cnt, c->occ_scan, 64) * 64 / bjjk::verify_scan_block();
+    LAUNCHCK(bjjk::verify_scan_range(S->scan_stream, sg, pk_xy, r_xy, msg, lo, lo + cnt, c->pipe_wl), "verify scan");
+    return verify_bulk_launch(c, false, pk_xy + lo * 64, r_xy + lo * 64, s32 + lo * 32, msg + lo * 32, cnt, ok + lo, (void*)lane);
+  }
+  int all_launched(hipEvent_t ev_tail) override {
+    ScratchSet* S = &c->set[0];
+    c->rings_used = true;
+    LAUNCHCK(bjjk::verify_main(S->scan_stream, 1, 0, false, c->table, c->W, c->nwin, pk_xy, r_xy, s32, msg, n, ok, S->vb_tables, c->pipe_wl, S->slotq,
+                               S->slot_cap | ((u32)c->xccs << 16), bjjk::VERIFY_EXACT), "verify (exact)");
+    LAUNCHCK(bjjk::merge_codec_flags(S->scan_stream, grid_for(c, n, 8), ok, f_pk, f_r, n), "merge_codec_flags");
+    HIPCK(hipEventRecord(ev_tail, S->scan_stream));
+    return BJJ_OK;
+  }
+};
+static int verify_compressed_host(bjj_ctx* c, const uint8_t* pk32, const uint8_t* sig64, const uint8_t* msg, size_t n, uint8_t* ok) {
+  PipeSpec sp = {3, 1, {pk32, sig64, msg}, {32, 64, 32}, {ok}, {1}, false};
+  static const bool per_chunk = [] { const char* e = getenv("BJJ_PIPE_VERIFY_SPLIT"); return e && e[0] == '0'; }();   // developer: the form until round 6
+  { ENTER_DEVICE(c->device); int rc_ = ensure_pipe(c, 0, 0, 0, 0); if (rc_) return rc_; }
+  const size_t first = c->pipe_env_schedule ? c->pipe_first : (size_t)1 << 16;
+  sp.first_chunk = first;
+  sp.max_chunk = (size_t)1 << 19;          // the verifiers' schedule: 23 ms of kernels hide 2.5 ms of copies several times over
+  if (c->verify_mode == 0 || per_chunk || n < first + first / 2)
+    return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_eddsa_verify_compressed_dev(c, i[0], i[1], i[2], cnt, o[0], st); });
+  VerifyCompressedPipe vp(c);
+  sp.extra = &vp;
+  sp.extra_dev_per_item = 162;             // decompressed pk (64) + R (64) + s (32) + the two decompression flags
+  sp.out_at_end = true;
+  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) {
+    (void)o;
+    return vp.launch_chunk((size_t)((const uint8_t*)i[0] - vp.pk32) / 32, cnt, (hipStream_t)st); });
+}
 int bjj_schnorr_verify_dev(bjj_ctx* c, const void* d_pk, const void* d_r, const void* d_s, const void* d_msg, size_t n,
                            void* d_ok, void* stream) {
   return verify_launch(c, true, d_pk, d_r, d_s, d_msg, n, d_ok, stream, "bjj_schnorr_verify_dev");
@@ -1891,8 +1975,7 @@ int bjj_decompress_points(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out_
 int bjj_eddsa_verify_compressed(bjj_ctx* c, const uint8_t* pk32, const uint8_t* sig64, const uint8_t* msg, size_t n,
                                 uint8_t* ok) {
   HOST_PROLOGUE("bjj_eddsa_verify_compressed", !pk32 || !sig64 || !msg || !ok);
-  PipeSpec sp = {3, 1, {pk32, sig64, msg}, {32, 64, 32}, {ok}, {1}, false};
-  return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_eddsa_verify_compressed_dev(c, i[0], i[1], i[2], cnt, o[0], st); });
+  return verify_compressed_host(c, pk32, sig64, msg, n, ok);
 }
 // signer side: the inputs are key material, so the staging buffers are wiped when the call is done (PipeSpec::secret)
 int bjj_scalar_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out) {

@@ -893,6 +893,19 @@ def host_api_block(ctx, n, orc):
     ctx.public_keys_dev(d_keys.data_ptr(), n, d_pk.data_ptr(), 0)
     ctx.sign_dev(d_keys.data_ptr(), d_m.data_ptr(), n, d_r.data_ptr(), d_s.data_ptr(), d_f.data_ptr(), 0)
     ctx.sync()
+    # the same signatures in wire format (32-byte pk, 64-byte signature), corrupted the way `--workload verify_compressed` corrupts them -- made BEFORE the
+    # affine copies are corrupted (a corrupted point does not compress to anything meaningful)
+    d_pkc, d_rc = torch.empty(n * 32, dtype=torch.uint8, device=dev), torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    ctx.compress_points_dev(d_pk.data_ptr(), n, d_pkc.data_ptr(), 0)
+    ctx.compress_points_dev(d_r.data_ptr(), n, d_rc.data_ptr(), 0)
+    ctx.sync()
+    z_ = torch.zeros(n, 32, dtype=torch.uint8, device=dev)
+    A_t, R_t = torch.cat([d_pkc.view(n, 32), z_], dim=1), torch.cat([z_, d_rc.view(n, 32)], dim=1)
+    d_sw, d_mw = d_s.clone(), d_m.clone()
+    bad_w = w.corrupt(A_t, R_t, d_sw.view(n, 32), d_mw.view(n, 32), n, 0)
+    d_pkw = A_t[:, :32].contiguous().reshape(-1)
+    d_sigw = torch.cat([R_t[:, 32:], d_sw.view(n, 32)], dim=1).contiguous().reshape(-1)
+    w_host = [t.cpu().numpy() for t in (d_pkw, d_sigw, d_mw)]
     bad = w.corrupt(d_pk.view(n, 64), d_r.view(n, 64), d_s.view(n, 32), d_m.view(n, 32), n, 0)
     v_host = [t.cpu().numpy() for t in (d_pk, d_r, d_s, d_m)]
     d_ok = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -947,6 +960,18 @@ def host_api_block(ctx, n, orc):
         good = good and bool((np.asarray(ok) == (~bad).astype(np.uint8)).all())             # every verdict against the corruption mask
         good = good and bool((np.asarray(ok)[vi] == orc.verify(v_host[0].reshape(n, 64)[vi], v_host[1].reshape(n, 64)[vi], v_host[2].reshape(n, 32)[vi],
                                                                v_host[3].reshape(n, 32)[vi])).all())
+        hw = [alloc(a.size) for a in w_host]
+        for b, a in zip(hw, w_host):
+            b[:] = a
+        okw = alloc(n)
+        okw[:] = 0
+        t_vc, t_vc_med = best(lambda: ctx._ck(ctx.lib.bjj_eddsa_verify_compressed(ctx.handle, hw[0].ctypes.data, hw[1].ctypes.data, hw[2].ctypes.data, n,
+                                                                               okw.ctypes.data), "bjj_eddsa_verify_compressed"), 3)
+        i_vc = ctx.info()
+        gw = np.asarray(okw)
+        good = good and bool((gw[~bad_w] == 1).all()) and bool((gw[bad_w] != 1).all())
+        wi = np.unique(np.concatenate([idx, np.nonzero(bad_w)[0][:64]]))
+        good = good and bool((gw[wi] == orc.verify_compressed(w_host[0].reshape(n, 32)[wi], w_host[1].reshape(n, 64)[wi], w_host[2].reshape(n, 32)[wi])).all())
         res = {"fixed_base": {"value": n / t_fb, "unit": UNITS["fixed_base"], "ms_per_call": t_fb * 1e3, "ms_per_call_median": t_fb_med * 1e3,
                               "items": n, "bytes_moved": n * 96, "entry_point": "bjj_mul_fixed_base",
                               "arrays_direct": i_fb.last_host_direct_arrays, "arrays_staged": i_fb.last_host_staged_arrays,
@@ -963,9 +988,13 @@ def host_api_block(ctx, n, orc):
                           "items": n, "bytes_moved": n * 193, "entry_point": "bjj_eddsa_verify",
                           "arrays_direct": i_v.last_host_direct_arrays, "arrays_staged": i_v.last_host_staged_arrays,
                           "chunks": i_v.last_host_chunks, "device_one_launch_ms": t_dev * 1e3, "vs_device_one_launch": t_v / t_dev},
+               "verify_compressed": {"value": n / t_vc, "unit": UNITS["verify"], "ms_per_call": t_vc * 1e3, "ms_per_call_median": t_vc_med * 1e3,
+                                     "items": n, "bytes_moved": n * 129, "entry_point": "bjj_eddsa_verify_compressed",
+                                     "arrays_direct": i_vc.last_host_direct_arrays, "arrays_staged": i_vc.last_host_staged_arrays,
+                                     "chunks": i_vc.last_host_chunks, "device_one_launch_ms": t_dev_vc * 1e3, "vs_device_one_launch": t_vc / t_dev_vc},
                "parity_sample_ok": good}
         if kind_mem == "pinned":
-            for a in [h_sc, out, out32, ok, h_pts, out_vb] + hv:
+            for a in [h_sc, out, out32, ok, okw, h_pts, out_vb] + hv + hw:
                 ctx.host_free(a)
         return res
 
@@ -983,6 +1012,11 @@ def host_api_block(ctx, n, orc):
         ctx.mul_var_base_dev(d_pts.data_ptr(), d_sc.data_ptr(), n, d_vb.data_ptr(), 0)
         ctx.sync()
     t_dev_vb, _ = best(one_launch_vb, 3)
+
+    def one_launch_vc():
+        ctx.eddsa_verify_compressed_dev(d_pkw.data_ptr(), d_sigw.data_ptr(), d_mw.data_ptr(), n, d_ok.data_ptr(), 0)
+        ctx.sync()
+    t_dev_vc, _ = best(one_launch_vc, 3)
     # the hwmon poller reads the SMU every 5 ms; round 6 found that such reads can hold the SOC clock -- and with it the copy engines'
     # device-to-host rate -- up (profiles/r06_host_d2h_power_states.txt): the host-pointer rows are measured WITHOUT it
     if TELEMETRY:
@@ -1003,9 +1037,9 @@ def host_api_block(ctx, n, orc):
                     "clocks), then best of 7 (fixed_base) / 3 (verify) and the median.  Reported beside the line, never as `value`."
                     % ctx.info().host_copy_threads,
             "fixed_base": pinned["fixed_base"], "fixed_base_compressed": pinned["fixed_base_compressed"], "var_base": pinned["var_base"],
-            "verify": pinned["verify"],
+            "verify": pinned["verify"], "verify_compressed": pinned["verify_compressed"],
             "pageable": {"fixed_base": pageable["fixed_base"], "fixed_base_compressed": pageable["fixed_base_compressed"],
-                         "var_base": pageable["var_base"], "verify": pageable["verify"]},
+                         "var_base": pageable["var_base"], "verify": pageable["verify"], "verify_compressed": pageable["verify_compressed"]},
             "copy_threads": ctx.info().host_copy_threads,
             "parity_sample_ok": pinned["parity_sample_ok"] and pageable["parity_sample_ok"]}
 

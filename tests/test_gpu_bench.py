@@ -150,6 +150,7 @@ def test_bench_one_gpu_line_has_every_block():
     assert h["fixed_base_compressed"]["value"] > 0 and h["fixed_base_compressed"]["bytes_moved"] == (1 << 16) * 64
     assert (h["fixed_base_compressed"]["arrays_direct"], hp["fixed_base_compressed"]["arrays_staged"]) == (2, 2)
     assert r.compact["also"]["host_api"]["fixed_base_compressed"]["value"] > 0 and r.compact["also"]["fixed_base_compressed"]["value"] > 0
+    assert h["verify_compressed"]["value"] > 0 and 0.5 < h["verify_compressed"]["vs_device_one_launch"] < 5.0 and hp["verify_compressed"]["arrays_staged"] == 4
     w23 = j["also"]["fixed_base_window_bits_23"]
     assert w23["kernel"] == "bjj_k_mul_fixed_base" and w23["streams"] == 1 and "clock_mhz" in w23 and w23["init_ms"] > 0
     if j["clock"].get("available"):

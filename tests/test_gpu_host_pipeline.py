@@ -236,6 +236,7 @@ def test_every_host_entry_point_on_pinned_memory_equals_the_staged_path(ctx16, o
             want = (len(ins) + len(outs), 0) if mem == "pinned" else (0, len(ins) + len(outs))
             # the verifiers and the variable-base multiplications bring their own schedule (first chunk 2^16: their kernels hide the copies, bjj_hip.hip)
             chunks = {"bjj_eddsa_verify": len(_schedule(n, 1 << 16, 1 << 19)), "bjj_schnorr_verify": len(_schedule(n, 1 << 16, 1 << 19)),
+                      "bjj_eddsa_verify_compressed": len(_schedule(n, 1 << 16, 1 << 19)),      # round 6: the verifiers' schedule and split
                       "bjj_mul_var_base": len(_schedule(n, 1 << 16, 1 << 18)), "bjj_mul_var_base_wide": len(_schedule(n, 1 << 16, 1 << 18))}.get(name, 3)
             assert (i.last_host_direct_arrays, i.last_host_staged_arrays) == want and i.last_host_chunks == chunks, (name, mem, i.last_host_chunks)
             got[mem] = [np.asarray(b).copy() for b in a_out]

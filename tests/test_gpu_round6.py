@@ -345,3 +345,52 @@ def test_host_pipeline_through_the_copy_engines_when_zero_copy_is_off(oracle, mo
             ctx.close()
         if env is not None:
             monkeypatch.delenv("BJJ_PIPE_ZERO_COPY")
+
+
+# ------------------------------------------------------------------------------------------------ the wire-format verifier on host pointers
+@pytest.mark.parametrize("mem", ["pinned", "pageable"])
+def test_host_verify_compressed_across_chunks_every_verdict(oracle, mem):
+    """bjj_eddsa_verify_compressed on host pointers at three chunks: per chunk decompress -> scan (one batch-wide list) -> bulk launch, ONE exact launch and ONE
+    flag pass per call.  Inputs: valid wire-format signatures with, at random, a flipped bit in s / msg (plain wrong), in the compressed pk or R (decompresses
+    to another point, does not decompress at all -> verdict 2, or lands off... a compressed point that decompresses is ON the curve), and msg > Q.  Every verdict
+    against ONE device-pointer launch of the same inputs; a sample incl. every kind against the oracle; the per-chunk form (BJJ_PIPE_VERIFY_SPLIT=0) agrees."""
+    import babyjubjub_rs_amd as bjj
+    import torch
+    ctx = bjj.Context(0, 16)
+    try:
+        n = (1 << 16) + (1 << 17) + 70001
+        rng = np.random.default_rng(0x77697265)
+        keys = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        msgs[:, 31] &= 0x1f
+        pkc = ctx.public_keys_compressed(keys)
+        sig, okf = ctx.sign_compressed(keys, msgs)
+        assert okf.all()
+        kind = rng.integers(0, 400, n)
+        pkc[kind == 1, 3] ^= 1; pkc[kind == 2, 31] ^= 0x40            # pk: another y (may or may not decompress), a y >= r
+        sig[kind == 3, 5] ^= 2; sig[kind == 4, 31] ^= 0x80            # R: another y; the sign bit of x
+        sig[kind == 5, 40] ^= 1                                        # s
+        msgs[kind == 6, 0] ^= 1; msgs[kind == 7, 31] = 0xff            # msg; msg > Q
+        sig[kind == 8, :32] = 0xff                                     # R does not decompress
+        dev = torch.device("cuda", 0)
+        d = [torch.from_numpy(a.reshape(-1)).to(dev) for a in (pkc, sig, msgs)]
+        d_ok = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
+        ctx.eddsa_verify_compressed_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), n, d_ok.data_ptr())
+        ctx.sync()
+        want = d_ok.cpu().numpy()
+        assert set(np.unique(want)) == {0, 1, 2} and (want[kind >= 9] == 1).all() and (want[kind == 8] == 2).all() and (want[kind == 7] == 0).all()
+        alloc = ctx.host_empty if mem == "pinned" else (lambda nb: np.zeros(nb, np.uint8))
+        bufs = []
+        for a in (pkc, sig, msgs):
+            b = alloc(a.size); b[:] = a.reshape(-1); bufs.append(b)
+        ok = alloc(n); ok[:] = 0xCD
+        assert ctx.lib.bjj_eddsa_verify_compressed(ctx.handle, bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data, ctypes.c_size_t(n), ok.ctypes.data) == 0
+        i = ctx.info()
+        assert i.last_host_chunks == 3 and i.last_verify_dispatch == 1
+        assert (i.last_host_direct_arrays, i.last_host_staged_arrays) == ((4, 0) if mem == "pinned" else (0, 4))
+        got = np.asarray(ok).copy()
+        assert (got == want).all(), (int((got != want).sum()), np.nonzero(got != want)[0][:8], got[got != want][:8], want[got != want][:8])
+        sel = np.unique(np.concatenate([np.nonzero(kind < 9)[0][:600], np.arange(0, n, 997), [65535, 65536, 196607, 196608, n - 1]]))
+        assert (got[sel] == oracle.verify_compressed(pkc[sel], sig[sel], msgs[sel])).all()
+    finally:
+        ctx.close()
