@@ -207,3 +207,50 @@ def test_soak_host_var_base_across_chunks(gpu_ctx, oracle, seed):
         gpu_ctx.host_free(b)
     if out_pinned:
         gpu_ctx.host_free(out)
+
+
+@pytest.mark.parametrize("seed", _more_seeds([31, 32, 33, 34], "BJJ_SOAK_HOST_VERIFY_COMPRESSED_SEEDS"))
+def test_soak_host_verify_compressed_across_chunks(gpu_ctx, oracle, seed):
+    """bjj_eddsa_verify_compressed on host pointers at sizes of two to three chunks (round 6: per-chunk decompressions, one batch-wide list, ONE exact launch
+    and ONE flag pass per call): random size, random density of corruption anywhere in the wire-format records (a corrupted compressed point decompresses to
+    another point or not at all), each array pinned or pageable at random; every verdict against ONE device-pointer launch, a sample against the oracle."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(100000, 400000))
+    dev = torch.device("cuda", 0)
+    keys = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msgs[:, 31] &= 0x1f
+    pkc = gpu_ctx.public_keys_compressed(keys)
+    sig, okf = gpu_ctx.sign_compressed(keys, msgs)
+    dens = [0.0, 1 / 128, 1 / 16, 1 / 3][seed % 4]
+    touched = np.zeros(n, bool)
+    for arr in (pkc, sig, msgs):
+        rows = np.nonzero(rng.random(n) < dens / 3)[0]
+        for r_ in rows:
+            bit = int(rng.integers(0, arr.shape[1] * 8))
+            arr[r_, bit // 8] ^= np.uint8(1 << (bit % 8))
+        touched[rows] = True
+    d = [torch.from_numpy(a.reshape(-1)).to(dev) for a in (pkc, sig, msgs)]
+    d_ok = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
+    gpu_ctx.eddsa_verify_compressed_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), n, d_ok.data_ptr())
+    gpu_ctx.sync()
+    want = d_ok.cpu().numpy()
+    held, ptrs = [], []
+    for a in (pkc.reshape(-1), sig.reshape(-1), msgs.reshape(-1)):
+        if rng.random() < 0.5:
+            b = gpu_ctx.host_empty(a.size); b[:] = a; held.append(b); ptrs.append(b.ctypes.data)
+        else:
+            ptrs.append(a.ctypes.data)
+    ok = gpu_ctx.host_empty(n) if rng.random() < 0.5 else np.empty(n, np.uint8)
+    ok[:] = 0xCD
+    assert gpu_ctx.lib.bjj_eddsa_verify_compressed(gpu_ctx.handle, ptrs[0], ptrs[1], ptrs[2], ctypes.c_size_t(n), ok.ctypes.data) == 0
+    assert gpu_ctx.info().last_host_chunks >= 2
+    got = np.asarray(ok).copy()
+    assert (got == want).all(), (n, dens, int((got != want).sum()))
+    assert (got[~touched] == 1).all()
+    idx = np.unique(np.concatenate([np.arange(0, n, max(1, n // 60)), np.nonzero(touched)[0][:80]]))
+    assert (got[idx] == oracle.verify_compressed(pkc[idx], sig[idx], msgs[idx])).all()
+    for b in held:
+        gpu_ctx.host_free(b)
