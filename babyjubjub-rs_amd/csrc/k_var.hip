@@ -167,6 +167,45 @@ __global__ void __launch_bounds__(64) bjj_k_var_base_scan(const uint8_t* __restr
     if (!ref_on_curve(x, y, c_K)) list[8 + atomicAdd(&list[0], 1u)] = (u32)i;
   }
 }
+// The reference's loop (src/lib.rs:157-162), one item on TWO lanes.  Per bit it does  if bit { r = r + e }  e = e + e  with ONE addition formula
+// (PointProjective::add) for both; the two chains only meet in `r + e`.  One lane per item runs both chains -- and, in a wave whose lanes hold
+// different scalars, BOTH additions at every bit: 2 x 254 formula evaluations, ~4.9 ms.  Here lane 2k keeps e (doubles it every step), lane 2k+1
+// keeps r: in step i both evaluate the SAME formula once -- e_i + e_i on the even lane, r + e_i on the odd one, e_i fetched from the partner lane --
+// and keep the sum or not (a select: no divergence).  254 evaluations per item instead of 508, the same field operations in the same order on the
+// same values: bit-exact by construction.  All 64 lanes of the wave call this together.
+__device__ __forceinline__ Fr fr_from_partner(const Fr& f) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = (u32)__shfl_xor((int)f.v[i], 1, 64);
+  return r;
+}
+__device__ void ref_mul_scalar_pair(bool valid, const Fr& x, const Fr& y, const u32* sc, int nw, bool accumulator, Fr& ox, Fr& oy) {
+  int bits = 0;
+  if (valid)
+    for (int i = nw - 1; i >= 0; i--)
+      if (sc[i]) { bits = 32 * i + 32 - __builtin_clz(sc[i]); break; }
+  int steps = bits;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(steps, d, 64); steps = o > steps ? o : steps; }
+  RefProj acc;                                   // even lane: e = P;  odd lane: r = (0, 1, 1)
+  acc.x = fr_select(accumulator, fr_zero(), x); acc.y = fr_select(accumulator, fr_one(), y); acc.z = fr_one();
+#pragma unroll 1
+  for (int i = 0; i < steps; i++) {
+    RefProj e;                                   // the pair's e_i (the even lane's accumulator; on the even lane: its own)
+    e.x = fr_select(accumulator, fr_from_partner(acc.x), acc.x);
+    e.y = fr_select(accumulator, fr_from_partner(acc.y), acc.y);
+    e.z = fr_select(accumulator, fr_from_partner(acc.z), acc.z);
+    const RefProj sum = ref_add(acc, e, c_K);    // even: e_i + e_i;  odd: r + e_i
+    const bool in_range = i < bits;
+    const bool keep = accumulator ? (in_range && ((sc[i >> 5] >> (i & 31)) & 1u)) : in_range;
+    acc.x = fr_select(keep, sum.x, acc.x); acc.y = fr_select(keep, sum.y, acc.y); acc.z = fr_select(keep, sum.z, acc.z);
+  }
+  ox = fr_zero(); oy = fr_zero();
+  if (accumulator && !fr_is_zero(acc.z)) {       // src/lib.rs:71-76: z == 0 -> (0, 0)
+    const Fr zi = fr_inv(acc.z);
+    ox = fr_mul(acc.x, zi); oy = fr_mul(acc.y, zi);
+  }
+}
 #ifdef BJJ_K6_EXPERIMENT
 __device__ int bjj_k6_xmode = 0;
 // mode 4 / 5: instead of K6 a kernel WITHOUT scratch (and without LDS) that sleeps ~4.9 ms: one wave (4) or 169 waves (5)
@@ -188,7 +227,7 @@ __global__ void __launch_bounds__(64) bjj_k_xsleep_vgpr(const u32* __restrict__ 
   for (int k = 0; k < 1400; k++) __builtin_amdgcn_s_sleep(127);
 }
 #endif
-// K6: exact replay of the reference's loop for the (rare) off-curve inputs, one per lane; sc_words words per scalar.
+// K6: exact replay of the reference's loop for the (rare) off-curve inputs, one item per PAIR of lanes (ref_mul_scalar_pair); sc_words words per scalar.
 //   patch == nullptr : result j goes to its item's slot out + i * 64
 //   patch != nullptr : result j goes to patch + j * 64, next to its index slow[8 + j] (the host-pointer pipeline: a chunk's results
 //                      may have left the device before K6 is done; the host lays the few patched results over them, bjj_hip.hip)
@@ -197,10 +236,9 @@ __global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __
                                                                const uint8_t* __restrict__ scalars, int sc_words,
                                                                uint8_t* __restrict__ out, const u32* __restrict__ slow,
                                                                uint8_t* __restrict__ patch, u32* __restrict__ seen) {
-  // A K6 wave is one serial chain of ~6 000 dependent multiplications (4.5 ms alone).  Beside K2 it shares its SIMD with two or
-  // three K2 waves, and at equal priority the instruction arbiter gives it a quarter of the issue slots: the chain stretches to
-  // the length of the whole K2 launch and becomes the critical path.  Raised wave priority keeps it at its own latency; the few
-  // K6 waves cost K2 nothing measurable.
+  // A K6 wave is one serial chain of ~3 000 dependent multiplications (254 evaluations of the reference's addition formula; 508 and ~4.9 ms
+  // until the chains were split over lane pairs).  Beside K2 it shares its SIMD with two or three K2 waves; it runs at raised wave priority.
+  // What K6 beside K2 costs K2 -- 0.7-0.9 ms while any K6 wave is busy -- and what does NOT cause it: profiles/r06_k6_beside_experiments.txt.
 #ifdef BJJ_K6_EXPERIMENT   // A/B build only (make EXTRA=-DBJJ_K6_EXPERIMENT): what about K6 beside K2 costs K2 ~0.25 ms per busy K6 wave?
   const int xmode = bjj_k6_xmode;
   if (xmode != 1) __builtin_amdgcn_s_setprio(3);
@@ -214,16 +252,23 @@ __global__ void __launch_bounds__(64) bjj_k_mul_var_base_exact(const uint8_t* __
 #endif
   const u32 cnt = slow[0];
   if (seen && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(seen, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
-    const size_t i = slow[8 + j];
+  const int lane = threadIdx.x & 63;
+  const bool accumulator = (lane & 1) != 0;
+#pragma unroll 1
+  for (u32 base = blockIdx.x * 32u; base < cnt; base += gridDim.x * 32u) {   // wave-uniform trip count: the lanes of a pair exchange registers
+    const u32 j = base + (u32)(lane >> 1);
+    const bool valid = j < cnt;
+    const size_t i = slow[8 + (valid ? j : base)];
     u32 w[8];
     load_w8(pts + i * 64, w);      Fr x = fr_to_mont_words(w);
     load_w8(pts + i * 64 + 32, w); Fr y = fr_to_mont_words(w);
     Fr ox, oy;
-    ref_mul_scalar(x, y, (const u32*)(scalars + i * (size_t)sc_words * 4), sc_words, ox, oy, c_K);
-    uint8_t* dst = patch ? patch + (size_t)j * 64 : out + i * 64;
-    fr_from_mont_words(ox, w); store_w8(dst, w);
-    fr_from_mont_words(oy, w); store_w8(dst + 32, w);
+    ref_mul_scalar_pair(valid, x, y, (const u32*)(scalars + i * (size_t)sc_words * 4), sc_words, accumulator, ox, oy);
+    if (valid && accumulator) {
+      uint8_t* dst = patch ? patch + (size_t)j * 64 : out + i * 64;
+      fr_from_mont_words(ox, w); store_w8(dst, w);
+      fr_from_mont_words(oy, w); store_w8(dst + 32, w);
+    }
   }
 }
 
