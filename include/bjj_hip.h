@@ -81,8 +81,8 @@
  *
  * Malformed points on the variable-base path.  Point has pub fields and no check (src/lib.rs:134-138), so an
  * (x, y) that is not on the curve is a legal input; its result is whatever the reference's formula sequence
- * yields, and the library reproduces it bit for bit with a strictly serial replay of that loop (~4.5 ms for one
- * item on one lane, whatever the batch size).  bjj_mul_var_base(_wide)_dev runs that exact kernel BEHIND the
+ * yields, and the library reproduces it bit for bit with a strictly serial replay of that loop (~2.1 ms for one
+ * item on a pair of lanes, whatever the batch size).  bjj_mul_var_base(_wide)_dev runs that exact kernel BEHIND the
  * batch kernel while every completed call of the context has been clean (a clean batch pays nothing), and -- from
  * the first call after one that met an off-curve point -- BESIDE it on a priority stream, behind a scan of the
  * points (0.7 % of a launch): the malformed items then cost their share of the chip instead of a launch-long tail
