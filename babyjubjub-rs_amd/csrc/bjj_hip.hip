@@ -189,6 +189,8 @@ struct bjj_ctx {
   size_t pipe_chunk = 0, pipe_first = 0;   // chunk schedule (items): first chunk, doubling up to pipe_chunk
   bool pipe_env_schedule = false;          // ... given in the environment: it overrides the entry points' own schedules too
   bool pipe_ready = false;                 // ensure_pipe's first-use block ran to its end
+  bool pipe_zero_copy_in = true;           // BJJ_PIPE_ZERO_COPY_IN=0: inputs always arrive through the copy engines (A/B, tests)
+  bool k1_half_now = false;                // a host-pointer call is enqueueing chunk launches of K1 that take ONE workgroup slot per CU each
   bool pipe_zero_copy = true;              // BJJ_PIPE_ZERO_COPY=0: results always leave through the copy engines (A/B, tests)
   u32 last_host_zero_copy = 0;
   bool in_pipeline = false;                // a host-pointer call is enqueueing (enqueue_verify: where the scans run)
@@ -284,9 +286,15 @@ static bool expect_overlap(bjj_ctx* c, const ScratchSet* S) {
   return c->idle_alternations < 2;
 }
 static int fixed_base_variant(bjj_ctx* c, const ScratchSet* S) {
-  const int kv = c->k1_variant >= 0 ? c->k1_variant : (expect_overlap(c, S) ? 1 : 0);
+  const int kv = c->k1_half_now ? 1 : (c->k1_variant >= 0 ? c->k1_variant : (expect_overlap(c, S) ? 1 : 0));
   c->last_k1 = kv;
   return kv;
+}
+// lanes per CU the launch may take: everything its shape can hold, or -- chunk launches of a host-pointer call, PipeSpec::k1_half --
+// one 256-lane workgroup per CU, so that the neighbouring chunk's launch has the other slot
+static int fixed_base_lanes(const bjj_ctx* c, int kv) {
+  if (c->k1_half_now && kv == 1) return 256;
+  return kv ? c->lanes_fixed_2x256 : c->lanes_fixed;
 }
 // completion mark of a call that used no scratch (bjj_sync waits for these)
 static int mark_stream(bjj_ctx* c, hipStream_t st) {
@@ -468,6 +476,19 @@ struct PipeSpec {
   // Only for kernel-bound calls: a kernel's stores to mapped host memory run at the copy engines' rate (54.9 GB/s), but a workgroup
   // holds its slot until PCIe has taken them -- K1, which is copy-bound, lost 5 % this way (profiles/r05_host_pipeline.txt).
   bool zero_copy_out = false;
+  // The first kernel of a chunk reads every input byte exactly once, coalesced, at the start of an item's work: when ALL input arrays are
+  // pinned, the launches read them through the arrays' DEVICE MAPPINGS and there is no copy-in stage -- the first kernel starts at once
+  // instead of behind a copy, and the chain of launches is no longer paced by the copy engine (43 GB/s over the small copies of a
+  // schedule) but by the kernels.  For launch chains that outrun their copy-in: K1, whose 2^20 items are 0.55 ms of kernel behind
+  // 0.77 ms of copy-in (profiles/r06_fb_zero_copy_in.txt).  Not with `extra` stages (they wait for copies).
+  bool zero_copy_in = false;
+  // K1 chunk launches (fixed base, public keys): a launch of K1 is persistent -- every lane walks its items, then ONE epilogue per
+  // workgroup (inversion, phase 2) -- and its ramp, epilogue and tail cost about one round of multiplications (~70 us) whatever
+  // its size.  A chunk launch that fills both workgroup slots of every CU runs that fixed part with nothing beside it; one that
+  // takes ONE slot per CU (256 lanes) shares each CU with the neighbouring chunk's launch on the other lane, out of phase by the
+  // pacing of the copies, and the fixed part of one is covered by the main loop of the other -- as on two caller streams
+  // (profiles/r03_ab_k1_2x256_two_streams.txt).  Calls of >= 2 chunks only (profiles/r06_fb_host_half_slots.txt).
+  bool k1_half = false;
 };
 // Work of a pipelined call that does not belong to ONE chunk.  All three run on the calling thread while it enqueues:
 //   begin          once per super-batch, before the first copy; d_in / d_out = the staging arrays of the whole super-batch
@@ -589,6 +610,7 @@ static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ri
     if (const char* e = getenv("BJJ_HOST_FORCE_STAGED")) c->force_staged = e[0] == '1';
     if (const char* e = getenv("BJJ_PIPE_SCAN")) c->pipe_scan_inline = e[0] != 'p';
     if (const char* e = getenv("BJJ_PIPE_ZERO_COPY")) c->pipe_zero_copy = e[0] != '0';
+    if (const char* e = getenv("BJJ_PIPE_ZERO_COPY_IN")) c->pipe_zero_copy_in = e[0] != '0';
     { int rc = ensure_pipe_streams(c); if (rc) return rc; }
     c->pipe_ready = true;
   }
@@ -707,10 +729,19 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
   bool zc = sp.zero_copy_out && !out_ring && sp.n_out > 0 && !sp.out_at_end && c->pipe_zero_copy;
   for (int i = 0; i < sp.n_out && zc; i++) {
     void* dp = nullptr;
-    if (!out_direct[i] || hipHostGetDevicePointer(&dp, sp.out[i], 0) != hipSuccess || !dp) { (void)hipGetLastError(); zc = false; }
+    if (!out_direct[i] || ((uintptr_t)sp.out[i] & 15u) || hipHostGetDevicePointer(&dp, sp.out[i], 0) != hipSuccess || !dp) { (void)hipGetLastError(); zc = false; }   // (the kernels move 16-byte words)
     mapped_out[i] = (uint8_t*)dp;
   }
-  c->last_host_zero_copy = zc ? 1u : 0u;
+  uint8_t* mapped_in[4] = {nullptr, nullptr, nullptr, nullptr};
+  // (calls of one or two chunks: beyond that the pacing of the copy-in is what keeps the two lanes' launches out of phase)
+  bool zi = sp.zero_copy_in && !in_ring && sp.n_in > 0 && !sp.extra && c->pipe_zero_copy_in && nchunks <= 2;
+  c->k1_half_now = sp.k1_half && nchunks >= 2;
+  for (int i = 0; i < sp.n_in && zi; i++) {
+    void* dp = nullptr;
+    if (!in_direct[i] || ((uintptr_t)sp.in[i] & 15u) || hipHostGetDevicePointer(&dp, (void*)sp.in[i], 0) != hipSuccess || !dp) { (void)hipGetLastError(); zi = false; }   // (the kernels move 16-byte words)
+    mapped_in[i] = (uint8_t*)dp;
+  }
+  c->last_host_zero_copy = (zc ? 1u : 0u) | (zi ? 2u : 0u);
   if (sp.extra) {
     void* bi[4]; void* bo[4];
     for (int i = 0; i < sp.n_in; i++) bi[i] = c->dstage + d_in_off[i];
@@ -771,19 +802,19 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
     const int b = (int)(ch % BJJ_PIPE_BUFS);
     const size_t lo = lo_of[ch], cnt = cnt_of(ch);
     tr("enqueue begin", ch);
-    for (int i = 0; i < sp.n_in; i++)
+    for (int i = 0; i < sp.n_in && !zi; i++)
       HIPCK(hipMemcpyAsync(c->dstage + d_in_off[i] + lo * sp.in_stride[i], in_direct[i] ? sp.in[i] + lo * sp.in_stride[i] : c->pin_in[b] + r_in_off[i],
                            cnt * sp.in_stride[i], hipMemcpyHostToDevice, c->s_in));
-    HIPCK(hipEventRecord(c->ev_in[ch], c->s_in));
+    if (!zi) HIPCK(hipEventRecord(c->ev_in[ch], c->s_in));
     tmark(1 + 3 * ch, c->s_in);                                // H2D done
     if (sp.extra) {
       int r = sp.extra->chunk_arrived(lo, cnt, c->ev_in[ch]); if (r) return r;
       if (ch + 1 == nchunks) { r = sp.extra->all_arrived(c->ev_tail); if (r) return r; }
     }
     hipStream_t lane = ((ch + lane_flip) & 1) ? c->stream2 : c->stream;
-    HIPCK(hipStreamWaitEvent(lane, c->ev_in[ch], 0));
+    if (!zi) HIPCK(hipStreamWaitEvent(lane, c->ev_in[ch], 0));
     void* d_in[4]; void* d_out[4];
-    for (int i = 0; i < sp.n_in; i++) d_in[i] = c->dstage + d_in_off[i] + lo * sp.in_stride[i];
+    for (int i = 0; i < sp.n_in; i++) d_in[i] = (zi ? mapped_in[i] : c->dstage + d_in_off[i]) + lo * sp.in_stride[i];
     for (int i = 0; i < sp.n_out; i++) d_out[i] = (zc ? mapped_out[i] : c->dstage + d_out_off[i]) + lo * sp.out_stride[i];
     int r = launch(d_in, d_out, cnt, (void*)lane); if (r) return r;
     if (sp.extra && ch + 1 == nchunks) { r = sp.extra->all_launched(c->ev_tail); if (r) return r; }
@@ -910,8 +941,10 @@ static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch
     rc = run_super_batch(c, cnt, sub, in_direct, out_direct, n_staged, launch, &chunks);
   }
   c->in_pipeline = false;
+  c->k1_half_now = false;
   c->last_host_direct = n_direct; c->last_host_staged = n_staged; c->last_host_chunks = chunks;
-  if (!sp.zero_copy_out) c->last_host_zero_copy = 0;
+  if (!sp.zero_copy_out) c->last_host_zero_copy &= ~1u;
+  if (!sp.zero_copy_in) c->last_host_zero_copy &= ~2u;
   // the call has synchronised for the caller: a verify / variable-base workgroup that gave up waiting for a table slot makes
   // it an error here, not at some later bjj_sync.  Only the pipeline's OWN streams have been waited for: while a
   // device-pointer launch of the caller is still in flight on one of the sets, its workgroups are popping and pushing the rings --
@@ -1296,7 +1329,7 @@ static int fixed_base_launch(bjj_ctx* c, const void* d_scalars, size_t n, void* 
   SET_ENTER(c, stream, n, false);
   if (compressed) { int rc_ = ensure_xy(c, S, n); if (rc_) return rc_; }
   const int kv = fixed_base_variant(c, S);
-  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, kv ? c->lanes_fixed_2x256 : c->lanes_fixed, kv, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
+  LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, fixed_base_lanes(c, kv), kv, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n,
                                 (uint8_t*)d_out, S->scratch, compressed ? S->xy : nullptr), "bjj_mul_fixed_base_dev");
   SET_LEAVE(c);
 }
@@ -1839,7 +1872,7 @@ static int public_keys_launch(bjj_ctx* c, const void* d_keys, size_t n, void* d_
              "mul_fixed_base_scan");
   } else {
     const int kv = fixed_base_variant(c, S);
-    LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, kv ? c->lanes_fixed_2x256 : c->lanes_fixed, kv, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy,
+    LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, fixed_base_lanes(c, kv), kv, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy,
                                   S->scratch, xy), "mul_fixed_base");
   }
   HIPCK(hipMemsetAsync(S->codec, 0, n * 32, st));
@@ -1907,19 +1940,32 @@ int bjj_sign_schnorr_dev(bjj_ctx* c, const void* d_keys, const void* d_msgs, con
   if (n == 0) return BJJ_OK;                                                  \
   if (cond) return set_err(BJJ_E_INVALID, name ": NULL buffer")
 
+// Chunk schedule of the K1 entry points with 32-byte results (the copy-out does not bound them: the launches do): chunks of 2^17
+// items behind a first one of 2^16 -- one round of multiplications for every lane of a launch that takes one workgroup slot per CU
+// (PipeSpec::k1_half).  2^18 .. 2^20 items: 8-15 % less than the schedule of the rounds before (doubling to 2^18, a 2^15-item last
+// chunk; BJJ_PIPE_K1_HALF=0 brings it back for an A/B), profiles/r06_fb_host_half_slots.txt.  The affine forms keep the default
+// schedule and full launches: their copy-out (64 bytes per item) is what bounds them, and they measured the same either way.
+// Long calls (more than 1.5 * 2^20 items) take chunks of 2^18: their steady state is the copy engines', which move 8 MB blocks faster
+// than 4 MB blocks (2^21 .. 2^23 items: 5-15 % less than with 2^17; 2^20 items: 14 % more).
+static void k1_chunk_schedule(PipeSpec* sp, size_t n) {
+  static const bool half = [] { const char* e = getenv("BJJ_PIPE_K1_HALF"); return !(e && e[0] == '0'); }();
+  if (half) { sp->k1_half = true; sp->first_chunk = (size_t)1 << 16; sp->max_chunk = (size_t)1 << (n > ((size_t)3 << 19) ? 18 : 17); }
+  else { sp->tail_chunk = (size_t)1 << 15; sp->max_chunk = (size_t)1 << 18; }
+}
 int bjj_mul_fixed_base(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* out) {
   HOST_PROLOGUE("bjj_mul_fixed_base", !scalars || !out);
   PipeSpec sp = {1, 1, {scalars}, {32}, {out}, {64}, false};
+  sp.zero_copy_in = true;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_fixed_base_dev(c, i[0], cnt, o[0], st); });
 }
 // 32 bytes per result across PCIe instead of 64: the copy-out is what bounds the affine form (1.19 ms of 1.58 per 2^20 items)
 int bjj_mul_fixed_base_compressed(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* out32) {
   HOST_PROLOGUE("bjj_mul_fixed_base_compressed", !scalars || !out32);
   PipeSpec sp = {1, 1, {scalars}, {32}, {out32}, {32}, false};
-  sp.tail_chunk = (size_t)1 << 15;   // 32 B in, 32 B out per item: the two PCIe directions are level, the last chunk's kernel + copy-out is what nothing hides
-  sp.max_chunk = (size_t)1 << 18;
+  k1_chunk_schedule(&sp, n);
   static const bool zc = [] { const char* e = getenv("BJJ_FB_COMPRESSED_ZERO_COPY"); return e && e[0] == '1'; }();   // experiment (tools/fb_compressed_sweep.py)
   if (zc) { sp.zero_copy_out = true; sp.tail_chunk = 0; }
+  sp.zero_copy_in = true;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_fixed_base_compressed_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_mul_var_base(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out) {
@@ -1986,13 +2032,14 @@ int bjj_scalar_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out) {
 int bjj_public_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out_xy) {
   HOST_PROLOGUE("bjj_public_keys", !keys || !out_xy);
   PipeSpec sp = {1, 1, {keys}, {32}, {out_xy}, {64}, true};
+  sp.zero_copy_in = true;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_public_keys_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_public_keys_compressed(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out32) {
   HOST_PROLOGUE("bjj_public_keys_compressed", !keys || !out32);
   PipeSpec sp = {1, 1, {keys}, {32}, {out32}, {32}, true};
-  sp.tail_chunk = (size_t)1 << 15;
-  sp.max_chunk = (size_t)1 << 18;
+  k1_chunk_schedule(&sp, n);
+  sp.zero_copy_in = true;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_public_keys_compressed_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_sign_compressed(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_sig64, uint8_t* ok) {

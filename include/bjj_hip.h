@@ -101,6 +101,9 @@
  * arrays are staged through pinned buffers by worker threads of the context (BJJ_STAGE_THREADS, default 4).  The choice is per
  * array and per call; results are identical.  2^20 fixed-base multiplications: about 1.6 ms pinned (the 64 MB of results
  * crossing PCIe take 1.19 ms), 2.0 to 2.6 ms pageable, 0.6 ms on device pointers.
+ * The fixed-base and key entry points skip the copy-in for short calls on pinned, 16-byte aligned inputs (one or two pipeline
+ * chunks: up to ~2^17 items): the first kernel reads the caller's array through its device mapping, ~15 us less per call
+ * (bjj_info.last_host_zero_copy, bit 1).  The array must not be written while the call runs -- as for every host-pointer call.
  * *_dev entry points take DEVICE pointers (16-byte aligned) plus a hipStream_t
  * (passed as void*; NULL = the context's stream), enqueue the work and return
  * without synchronising -- they are what bench.py times.
@@ -108,7 +111,7 @@
  * long) as ONE launch for the whole call beside the chunks' launches, and their verdicts leave the device once, at the end:
  * 2^20 signatures of which 1 in 128 is off the curve take about 19 ms pinned, 18.2 ms as one device-pointer launch.
  * More environment knobs (read when the context first runs a host-pointer call): BJJ_PIPE_CHUNK / BJJ_PIPE_FIRST_CHUNK
- * (items per pipeline chunk: the first chunk, doubling up to the cap; defaults 32768 / 131072 -- 262144 for the compressed fixed-base forms --, for the verifiers 65536 /
+ * (items per pipeline chunk: the first chunk, doubling up to the cap; defaults 32768 / 131072 -- 65536 / 131072 (262144 beyond 1.5 M items) for the compressed fixed-base and key forms, whose chunk launches take one workgroup slot per CU each --, for the verifiers 65536 /
  * 524288 and for the variable-base multiplications 65536 / 262144; a value in the environment applies to all), BJJ_PIPE_STAGING_MB
  * (device staging a call may take, default 1024; larger batches run as consecutive super-batches), BJJ_HOST_FORCE_STAGED=1
  * (treat every host array as pageable), BJJ_STAGE_THREADS.
@@ -321,7 +324,8 @@ typedef struct {
   const char* kernel_var_base_overlap;
   /* since 0.6.0 */
   int last_var_base_split;     /* variable base, the exact kernel for off-curve points: 0 = behind the batch kernel, 1 = beside it (scan first) */
-  uint32_t last_host_zero_copy; /* last host-pointer call: 1 = the kernels stored their results into the (pinned) output array themselves, no copy-out stage */
+  uint32_t last_host_zero_copy; /* last host-pointer call, bit 0: the kernels stored their results into the (pinned) output array themselves, no copy-out stage;
+                                   bit 1: the kernels read the (pinned) input arrays themselves, no copy-in stage */
 } bjj_info;
 int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
 

@@ -3,6 +3,7 @@ producing kernels -- and (b) off-curve points on the variable-base path (Point h
 with the exact kernel BESIDE the batch kernel: the device-pointer forms by the context's history, the host-pointer pipeline as one
 exact launch per call whose results the host lays over the caller's array.  Needs a real MI355X: `pytest -m gpu`."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -127,6 +128,64 @@ def test_public_keys_and_sign_compressed_equal_the_two_pass_form(oracle, ct):
         assert (ctx.eddsa_verify_compressed(ctx.public_keys_compressed(keys)[good], sig[good], msgs[good]) == 1).all()
     finally:
         ctx.close()
+
+
+def _host_call(ctx, name, arrays_in, n, arrays_out):
+    import ctypes as C
+    args = [ctx.handle] + [a.ctypes.data for a in arrays_in] + [C.c_size_t(n)] + [a.ctypes.data for a in arrays_out]
+    ctx._ck(getattr(ctx.lib, name)(*args), name)
+    return ctx.info()
+
+
+def test_k1_host_calls_on_pinned_memory_every_chunk_count(gpu_ctx, oracle):
+    """The K1 entry points on pinned arrays (PipeSpec::zero_copy_in / k1_half, bjj_hip.hip): calls of one or two chunks read the
+    caller's array through its device mapping (bjj_info.last_host_zero_copy bit 1), the 32-byte forms run their chunk launches on one
+    workgroup slot per CU from two chunks on; every size byte for byte what the pageable call and one device-resident launch give"""
+    from babyjubjub_rs_amd import workload as w
+    ctx = gpu_ctx
+    nmax = (1 << 19) + 70001
+    keys = w.scalars_254(nmax, offset=77)
+    keys[5] = 0
+    p_in = _pinned_copy(ctx, keys)
+    want_fb, want_pk = ctx.mul_fixed_base(keys), ctx.public_keys(keys)          # pageable: staged copies, full launches per chunk
+    want = {"bjj_mul_fixed_base": (want_fb, 64), "bjj_mul_fixed_base_compressed": (ctx.compress_points(want_fb), 32),
+            "bjj_public_keys": (want_pk, 64), "bjj_public_keys_compressed": (ctx.compress_points(want_pk), 32)}
+    idx = np.arange(0, nmax, 4099)
+    assert (want_fb[idx] == oracle.mul_fixed_base(keys[idx])).all() and (want_pk[idx] == oracle.public_keys(keys[idx])).all()
+    for name, (exp, width) in want.items():
+        p_out = ctx.host_empty(nmax * width)
+        for n in (1, 63, 4097, 1 << 16, (1 << 16) + 1, (1 << 17) + 5, 3 << 16, nmax):
+            p_out[:] = 0xEE
+            i = _host_call(ctx, name, [p_in], n, [p_out])
+            got = np.asarray(p_out[:n * width]).reshape(n, width)
+            assert (got == exp[:n]).all(), (name, n, np.nonzero((got != exp[:n]).any(axis=1))[0][:8])
+            assert (np.asarray(p_out[n * width:n * width + 64]) == 0xEE).all(), (name, n)                 # nothing beyond item n
+            assert (i.last_host_direct_arrays, i.last_host_staged_arrays) == (2, 0)
+            assert bool(i.last_host_zero_copy & 2) == (i.last_host_chunks <= 2), (name, n, i.last_host_chunks, i.last_host_zero_copy)
+            if width == 32 and not any(k in os.environ for k in ("BJJ_PIPE_K1_HALF", "BJJ_PIPE_CHUNK", "BJJ_PIPE_FIRST_CHUNK", "BJJ_PIPE_SCHEDULE")):
+                # 2^16, then 2^17 each (a remainder below half a chunk joins the last one); from two chunks on in the two-workgroup shape
+                assert i.last_host_chunks == {1 << 16: 1, (1 << 16) + 1: 1, (1 << 17) + 5: 2, 3 << 16: 2, nmax: 5}.get(n, 1), (name, n, i.last_host_chunks)
+                if i.last_host_chunks >= 2 and "BJJ_K1_VARIANT" not in os.environ:
+                    assert i.last_fixed_base_shape == 1
+        ctx.host_free(p_out)
+    ctx.host_free(p_in)
+
+
+def test_k1_host_calls_fall_back_to_copies_for_a_misaligned_pinned_array(gpu_ctx):
+    """a pinned input that does not start on a 16-byte boundary cannot be read by the kernels in place (they move 16-byte words): the
+    copy engines realign it into the staging area, as before"""
+    from babyjubjub_rs_amd import workload as w
+    ctx = gpu_ctx
+    n = 5001
+    sc = w.scalars_254(n, offset=9)
+    raw = ctx.host_empty(n * 32 + 16)
+    mis = raw[8:8 + n * 32]
+    mis[:] = sc.reshape(-1)
+    out = ctx.host_empty(n * 32)
+    i = _host_call(ctx, "bjj_mul_fixed_base_compressed", [mis], n, [out])
+    assert i.last_host_zero_copy == 0 and i.last_host_direct_arrays == 2
+    assert (np.asarray(out).reshape(n, 32) == ctx.compress_points(ctx.mul_fixed_base(sc))).all()
+    ctx.host_free(raw); ctx.host_free(out)
 
 
 def test_compressed_entry_points_reject_bad_arguments(gpu_ctx):
