@@ -733,15 +733,18 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
     mapped_out[i] = (uint8_t*)dp;
   }
   uint8_t* mapped_in[4] = {nullptr, nullptr, nullptr, nullptr};
-  // (calls of one or two chunks: beyond that the pacing of the copy-in is what keeps the two lanes' launches out of phase)
-  bool zi = sp.zero_copy_in && !in_ring && sp.n_in > 0 && !sp.extra && c->pipe_zero_copy_in && nchunks <= 2;
-  c->k1_half_now = sp.k1_half && nchunks >= 2;
+  // Calls of one or two chunks: every chunk.  Longer calls: the FIRST chunk only -- the head of the chain of launches starts at once instead
+  // of behind its copy, and the copy-in of the chunks behind it, which keeps the two lanes' launches out of phase, starts earlier too.
+  bool zi = sp.zero_copy_in && !in_ring && sp.n_in > 0 && !sp.extra && c->pipe_zero_copy_in;
   for (int i = 0; i < sp.n_in && zi; i++) {
     void* dp = nullptr;
     if (!in_direct[i] || ((uintptr_t)sp.in[i] & 15u) || hipHostGetDevicePointer(&dp, (void*)sp.in[i], 0) != hipSuccess || !dp) { (void)hipGetLastError(); zi = false; }   // (the kernels move 16-byte words)
     mapped_in[i] = (uint8_t*)dp;
   }
-  c->last_host_zero_copy = (zc ? 1u : 0u) | (zi ? 2u : 0u);
+  static const int zi_first_env = [] { const char* e = getenv("BJJ_PIPE_ZERO_COPY_IN_FIRST"); return e ? atoi(e) : 1; }();   // developer A/B: leading chunks of a long call that read in place
+  const size_t zi_chunks = !zi ? 0 : (nchunks <= 2 ? nchunks : (size_t)zi_first_env);
+  c->last_host_zero_copy = (zc ? 1u : 0u) | (zi_chunks == nchunks ? 2u : 0u);
+  c->k1_half_now = sp.k1_half && nchunks >= 2;
   if (sp.extra) {
     void* bi[4]; void* bo[4];
     for (int i = 0; i < sp.n_in; i++) bi[i] = c->dstage + d_in_off[i];
@@ -802,6 +805,7 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
     const int b = (int)(ch % BJJ_PIPE_BUFS);
     const size_t lo = lo_of[ch], cnt = cnt_of(ch);
     tr("enqueue begin", ch);
+    const bool zi = ch < zi_chunks;   // this chunk's launch reads the caller's arrays in place
     for (int i = 0; i < sp.n_in && !zi; i++)
       HIPCK(hipMemcpyAsync(c->dstage + d_in_off[i] + lo * sp.in_stride[i], in_direct[i] ? sp.in[i] + lo * sp.in_stride[i] : c->pin_in[b] + r_in_off[i],
                            cnt * sp.in_stride[i], hipMemcpyHostToDevice, c->s_in));

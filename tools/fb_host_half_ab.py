@@ -37,10 +37,13 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 SIZES = sys.argv[3] if len(sys.argv) > 3 else "10,15,16,17,18,19,20,22"
 MODES = (("0", "0", None), ("1", "0", None), ("1", "1", None))
 if len(sys.argv) > 4 and sys.argv[4] == "caps": MODES = (("1", "1", None), ("1", "1", "262144"), ("1", "1", "524288"))
+FIRST = [None]
+if len(sys.argv) > 4 and sys.argv[4] == "first": MODES, FIRST = (("1", "1", None),), ["0", "1", "2"]      # leading chunks of a long call that read in place
 for rnd in range(rounds):
-    for half, zi, cap in MODES:
-        print("# round %d: BJJ_PIPE_K1_HALF=%s BJJ_PIPE_ZERO_COPY_IN=%s%s   (ms, best of 11 calls)" % (rnd, half, zi, "  BJJ_PIPE_FIRST_CHUNK=65536 BJJ_PIPE_CHUNK=" + cap if cap else ""), flush=True)
+    for half, zi, cap, first in [m + (f,) for m in MODES for f in FIRST]:
+        print("# round %d: BJJ_PIPE_K1_HALF=%s BJJ_PIPE_ZERO_COPY_IN=%s%s%s   (ms, best of 11 calls)" % (rnd, half, zi, "  BJJ_PIPE_FIRST_CHUNK=65536 BJJ_PIPE_CHUNK=" + cap if cap else "", "  BJJ_PIPE_ZERO_COPY_IN_FIRST=" + first if first else ""), flush=True)
         env = dict(os.environ, BJJ_PIPE_K1_HALF=half, BJJ_PIPE_ZERO_COPY_IN=zi)
+        if first: env["BJJ_PIPE_ZERO_COPY_IN_FIRST"] = first
         if cap: env.update(BJJ_PIPE_FIRST_CHUNK="65536", BJJ_PIPE_CHUNK=cap)
         r = subprocess.run([sys.executable, "-c", CHILD, W, SIZES], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         print(r.stdout.rstrip() or r.stderr[-600:], flush=True)
