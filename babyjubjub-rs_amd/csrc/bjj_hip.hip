@@ -198,6 +198,7 @@ struct bjj_ctx {
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
   // what the last calls did (bjj_get_info; tests and the bench line read these)
   int last_k1 = -1, last_k2 = -1, last_verify_mode = -1;
+  size_t vb_quad_max = (size_t)1 << 14;    // variable base: calls of at most this many items run four lanes per item (BJJ_VB_QUAD_MAX; 0 = never)
   int idle_alternations = 0;               // expect_overlap: consecutive alternating calls that found the other set idle
   u32 last_host_direct = 0, last_host_staged = 0, last_host_chunks = 0;
   u32* slot_block = nullptr;               // all slot-queue rings of the context in one device allocation (slot_block_make)
@@ -1070,6 +1071,10 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   if (const char* e = getenv("BJJ_K2_VARIANT")) {
     if (e[0] == '0' || e[0] == '1') c->k2_variant = e[0] - '0';
   }
+  if (const char* e = getenv("BJJ_VB_QUAD_MAX")) {  // tests / A-B: variable-base calls of at most this many items run four lanes per item (0 = never)
+    char* q = nullptr; const unsigned long long v = strtoull(e, &q, 0);
+    if (q != e && v <= ((unsigned long long)1 << 20)) c->vb_quad_max = (size_t)v;
+  }
   if (const char* e = getenv("BJJ_K1_VARIANT")) {   // tests / A-B: force one shape of the fixed-base kernel
     if (e[0] == '0' || e[0] == '1') c->k1_variant = e[0] - '0';
   }
@@ -1385,8 +1390,13 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
   { int rc_ = var_base_check(c, d_pts, d_scalars, scalar_bytes, n, d_out, who); if (rc_) return rc_; }
   if (n == 0) return BJJ_OK;
   SET_ENTER(c, stream, n, false);
-  int kv = 0;
-  { int rc_ = var_base_form(c, S, st, n, &kv); if (rc_) return rc_; }
+  // Short calls (a single Point::mul_scalar is one): four lanes per item (k_small.hip) -- 0.50 ms per call up to 2^12 items, 0.56 ms at 2^14, against
+  // K2's 1.15-1.22 ms, which is one lane's serial chain whatever the call's size; from 2^15 items on K2 is ahead (1.27 vs 1.38 ms;
+  // profiles/r06_small_calls.txt).  32-byte scalars; off-curve points go to K6 as from K2.
+  const bool quad = scalar_bytes == 32 && n <= c->vb_quad_max && c->k2_variant < 0;   // (BJJ_K2_VARIANT forces K2, in that form)
+  int kv = 2;
+  if (quad) c->last_k2 = 2;
+  else { int rc_ = var_base_form(c, S, st, n, &kv); if (rc_) return rc_; }
   const uint8_t* pts = (const uint8_t*)d_pts;
   const uint8_t* sc = (const uint8_t*)d_scalars;
   const int sc_words = (int)(scalar_bytes / 4);
@@ -1403,6 +1413,10 @@ static int var_base_launch(bjj_ctx* c, const void* d_pts, const void* d_scalars,
     LAUNCHCK(bjjk::mul_var_base_exact(xs, c->cus * 4, pts, sc, sc_words, (uint8_t*)d_out, S->slow, nullptr, seen), "variable-base (exact)");
     HIPCK(hipEventRecord(S->ev_scan_out, xs));
   }
+  if (quad) {
+    if (!split) HIPCK(hipMemsetAsync(S->slow, 0, 8 * sizeof(u32), st));
+    LAUNCHCK_S(bjjk::mul_var_base_quad(st, pts, sc, n, (uint8_t*)d_out, split ? nullptr : S->slow), who);
+  } else
   LAUNCHCK_S(bjjk::mul_var_base_main(st, c->cus, c->lanes_var, kv, pts, sc, sc_words, n, (uint8_t*)d_out, S->scratch, S->vb_tables, split ? nullptr : S->slow,
                                      S->slotq2, S->slot_cap2 | ((u32)c->xccs << 16)), who);
   if (split) HIPCK(hipStreamWaitEvent(st, S->ev_scan_out, 0));

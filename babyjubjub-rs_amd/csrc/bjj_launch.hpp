@@ -60,6 +60,8 @@ hipError_t var_base_scan(hipStream_t st, int grid, const uint8_t* pts, size_t fi
 hipError_t mul_var_base_exact(hipStream_t st, int grid_exact, const uint8_t* pts, const uint8_t* scalars, int sc_words, uint8_t* out,
                               const uint32_t* slow, uint8_t* patch, uint32_t* seen);
 int occ_var_base_scan();
+// k_small.hip: four lanes per item, for calls that do not fill the chip one item per lane (32-byte scalars); slow as for mul_var_base_main
+hipError_t mul_var_base_quad(hipStream_t st, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out, uint32_t* slow);
 hipError_t point_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);
 hipError_t proj_add(hipStream_t st, int grid, const uint8_t* p, const uint8_t* q, size_t n, uint8_t* out);
 hipError_t proj_affine(hipStream_t st, int grid, const uint8_t* p, size_t n, uint8_t* out);

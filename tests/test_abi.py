@@ -129,7 +129,7 @@ def test_library_is_not_older_than_its_sources():
     d = os.path.join(ROOT, "babyjubjub-rs_amd", "csrc")
     so = os.path.join(d, "libbjj_hip.so")
     srcs = ["bjj_hip.hip", "bjj_multi.inc", "bjj_launch.hpp", "k_common.hpp", "k_fixed.hip", "k_var.hip", "k_hash_codec.hip",
-            "k_verify.hip", "k_sign.hip", "fr.hpp", "fr_mul_columns.inc", "curve.hpp", "poseidon.hpp", "bjj_device.hpp",
+            "k_verify.hip", "k_sign.hip", "k_small.hip", "fr.hpp", "fr_mul_columns.inc", "curve.hpp", "poseidon.hpp", "bjj_device.hpp",
             "sign.hpp", "bjj_constants.inc", "slot_queue.hpp", os.path.join("..", "..", "include", "bjj_hip.h")]
     newest = max(os.path.getmtime(os.path.join(d, s)) for s in srcs)
     assert os.path.getmtime(so) >= newest, "rebuild: python -c 'import __graft_entry__ as g; g.build()'"

@@ -1,0 +1,139 @@
+"""Short calls of Point::mul_scalar (src/lib.rs:149-164): four lanes per item (csrc/k_small.hip: bjj_k_mul_var_base_quad) instead of K2's one --
+the same group element through the same formulas, so the canonical output must be byte-identical to K2's and to the oracle's, for every
+kind of point and scalar, at every batch size around the quad / wave / switch-over boundaries, on device and host pointers, with
+off-curve points handed to the exact kernel K6 in both of its positions.  Needs a real MI355X: `pytest -m gpu`."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import pack
+
+pytestmark = pytest.mark.gpu
+
+Q = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+L = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+QUAD_MAX = 1 << 14
+
+
+def _launch(ctx, pts, sc):
+    import torch
+    dev = torch.device("cuda", 0)
+    n = pts.shape[0]
+    d_p, d_s = torch.from_numpy(np.ascontiguousarray(pts).reshape(-1)).to(dev), torch.from_numpy(np.ascontiguousarray(sc).reshape(-1)).to(dev)
+    d_o = torch.full((n * 64 + 64,), 0xEE, dtype=torch.uint8, device=dev)
+    ctx.mul_var_base_dev(d_p.data_ptr(), d_s.data_ptr(), n, d_o.data_ptr())
+    ctx.sync()
+    o = d_o.cpu().numpy()
+    assert (o[n * 64:] == 0xEE).all()                       # nothing beyond item n - 1 (quads past the batch repeat the last item and store nothing)
+    return o[:n * 64].reshape(n, 64)
+
+
+def _group_points(ctx, n, seed):
+    from babyjubjub_rs_amd import workload as w
+    return ctx.mul_fixed_base(w.scalars_254(n, offset=seed)).copy()
+
+
+@pytest.fixture(scope="module")
+def k2_ctx():
+    """a context whose short calls still run K2 (BJJ_VB_QUAD_MAX=0 is read at bjj_init)"""
+    import os
+    import babyjubjub_rs_amd as bjj
+    old = os.environ.get("BJJ_VB_QUAD_MAX")
+    os.environ["BJJ_VB_QUAD_MAX"] = "0"
+    try:
+        c = bjj.Context(0, 16)
+    finally:
+        if old is None:
+            del os.environ["BJJ_VB_QUAD_MAX"]
+        else:
+            os.environ["BJJ_VB_QUAD_MAX"] = old
+    yield c
+    c.close()
+
+
+def test_every_size_around_the_boundaries_against_k2_and_the_oracle(gpu_ctx, k2_ctx, oracle):
+    from babyjubjub_rs_amd import workload as w
+    nmax = QUAD_MAX + 70
+    pts = _group_points(gpu_ctx, nmax, 5)
+    sc = w.scalars_254(nmax, offset=40000)
+    sc[:, 31] |= np.arange(nmax, dtype=np.uint8) & 0xC0        # bits 254 / 255 set on three quarters: the raw 256-bit scalar is reduced mod 8l
+    want = oracle.mul_var_base(pts[:700], sc[:700])
+    for n in (1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 63, 64, 65, 257, 700, 4099, QUAD_MAX - 1, QUAD_MAX, QUAD_MAX + 1, nmax):
+        got = _launch(gpu_ctx, pts[:n], sc[:n])
+        form = gpu_ctx.info().last_var_base_form
+        assert form == (2 if n <= QUAD_MAX else form) and (n <= QUAD_MAX or form in (0, 1)), (n, form)
+        m = min(n, 700)
+        assert (got[:m] == want[:m]).all(), (n, np.nonzero((got[:m] != want[:m]).any(axis=1))[0][:8])
+        if n > 700:
+            ref = _launch(k2_ctx, pts[:n], sc[:n])
+            assert k2_ctx.info().last_var_base_form in (0, 1)
+            assert (got == ref).all(), (n, np.nonzero((got != ref).any(axis=1))[0][:8])
+    # ... and through the host pointers (what a single p.mul_scalar(&n) of the crate is): pageable and pinned
+    for n in (1, 7, 64, 700):
+        assert (gpu_ctx.mul_var_base(pts[:n], sc[:n]) == want[:n]).all(), n
+        assert gpu_ctx.info().last_var_base_form == 2
+    p_p, p_s, p_o = gpu_ctx.host_empty(64), gpu_ctx.host_empty(32), gpu_ctx.host_empty(64)
+    p_p[:], p_s[:] = pts[3], sc[3]
+    gpu_ctx._ck(gpu_ctx.lib.bjj_mul_var_base(gpu_ctx.handle, p_p.ctypes.data, p_s.ctypes.data, ctypes.c_size_t(1), p_o.ctypes.data), "bjj_mul_var_base")
+    assert (np.asarray(p_o) == want[3]).all()
+    for b in (p_p, p_s, p_o):
+        gpu_ctx.host_free(b)
+
+
+def test_special_points_and_scalars(gpu_ctx, oracle):
+    """the identity, the point of order two, points of order 4 and 8 (x = 0 / y = 0 and the 8-torsion the reference's cofactor clears), the generator
+    and B8, against scalars 0, 1, 2, 7, 8, l - 1, l, l + 1, 8l - 1, 8l, 8l + 1, r - 1, 2^251, 2^254 - 1, 2^255, 2^256 - 1 and all-nibbles-8 (the recoding's carry chain)"""
+    g = (995203441582195749578291179787384436505546430278305826713579947235728471134, 5472060717959818805561601436314318772137091100104008585924551046643952123905)
+    b8 = (5299619240641551281634865583518297030282874472190772894086521144482721001553, 16950150798460657717958625567821834550301663161624707787222815936182638968203)
+    pts_i = [(0, 1), (0, Q - 1), g, b8, (Q - g[0], g[1]), (Q - b8[0], b8[1])]
+    # points of order 4: y = 0, x^2 = 1/a (a = 168700); take them from the oracle: 2l * G has order dividing 4, l * G order dividing 8
+    lg = oracle.mul_var_base(pack([g[0], g[1]]).reshape(1, 64), pack([L]))
+    l2g = oracle.mul_var_base(pack([g[0], g[1]]).reshape(1, 64), pack([2 * L]))
+    scal = [0, 1, 2, 7, 8, L - 1, L, L + 1, 8 * L - 1, 8 * L, 8 * L + 1, Q - 1, 1 << 251, (1 << 254) - 1, 1 << 255, (1 << 256) - 1,
+            int("88" * 32, 16), int("77" * 32, 16), int("f" * 63, 16), int("08" * 32, 16)]
+    base = np.concatenate([pack([c for p in pts_i for c in p]).reshape(len(pts_i), 64), lg, l2g])
+    pts = np.repeat(base, len(scal), axis=0)
+    sc = np.tile(pack(scal).reshape(len(scal), 32), (base.shape[0], 1))
+    want = oracle.mul_var_base(pts, sc)
+    got = _launch(gpu_ctx, pts, sc)
+    assert gpu_ctx.info().last_var_base_form == 2
+    assert (got == want).all(), np.nonzero((got != want).any(axis=1))[0][:8]
+
+
+@pytest.mark.parametrize("force", [None, "0", "1"], ids=["by_history", "exact_behind", "exact_beside"])
+def test_off_curve_points_in_short_calls_go_to_the_exact_kernel(oracle, monkeypatch, force):
+    """Point has pub fields and no check (src/lib.rs:134-138): the quad kernel lists an off-curve item for K6 and leaves its slot alone, like K2 --
+    K6 behind it (a clean history), beside it behind a scan (after a call that met one), and both forced"""
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    if force is not None:
+        monkeypatch.setenv("BJJ_VB_SPLIT", force)
+    ctx = bjj.Context(0, 16)
+    try:
+        for rnd, n in enumerate((1, 5, 64, 333, 2000)):
+            pts = _group_points(ctx, n, 100 + rnd)
+            bad = (w.splitmix64(0x5ca1 + rnd, n, 0) % np.uint64(3)) == 0
+            bad[0] = True                                                # every call meets one: the history stays dirty
+            pts[bad, 0] ^= 1
+            pts[bad & (np.arange(n) % 2 == 0), 33] ^= 0x40
+            sc = w.scalars_254(n, offset=7000 + rnd)
+            want = oracle.mul_var_base(pts, sc)
+            got = _launch(ctx, pts, sc)
+            i = ctx.info()
+            assert i.last_var_base_form == 2 and (got == want).all(), (n, np.nonzero((got != want).any(axis=1))[0][:8])
+            if force is None:
+                assert i.last_var_base_split == (0 if rnd == 0 else 1)          # the first call found the history clean
+            else:
+                assert i.last_var_base_split == int(force)
+            assert (ctx.mul_var_base(pts, sc) == want).all()                     # host pointers
+    finally:
+        ctx.close()
+
+
+def test_wide_scalars_and_long_calls_keep_k2(gpu_ctx):
+    from babyjubjub_rs_amd import workload as w
+    pts = _group_points(gpu_ctx, 40, 9)
+    wide = np.concatenate([w.scalars_254(40, offset=1), w.scalars_254(40, offset=2)], axis=1)
+    gpu_ctx.mul_var_base_wide(pts, wide, 64)
+    assert gpu_ctx.info().last_var_base_form in (0, 1)

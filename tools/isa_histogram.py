@@ -29,7 +29,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "babyjubjub-rs_amd", "csrc")
-UNITS = ["k_fixed", "k_var", "k_hash_codec", "k_verify", "k_sign"]
+UNITS = ["k_fixed", "k_var", "k_hash_codec", "k_verify", "k_sign", "k_small"]
 CYC = {"mad64": 4.54, "quarter": 4.20, "plain": 2.40}
 PLAIN = re.compile(r"^v_(mov_b32|add_u32|sub_u32|subrev_u32|and_b32|or_b32|xor_b32|not_b32|lshlrev_b32|lshrrev_b32|ashrrev_i32|"
                    r"cndmask_b32|bfe_u32|bfi_b32|and_or_b32|or3_b32|lshl_or_b32|lshl_add_u32|add_lshl_u32|min_u32|max_u32|"

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Developer probe: bjj_mul_var_base on pinned host pointers over call sizes, four lanes per item (k_small.hip) against K2 (BJJ_VB_QUAD_MAX=0) --
+a fresh process per mode.  usage: small_call_probe.py [W]"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import sys, time, ctypes as C
+sys.path.insert(0, %r)
+import numpy as np
+import babyjubjub_rs_amd as bjj
+from babyjubjub_rs_amd import workload as w
+N = 1 << 17
+ctx = bjj.Context(0, int(sys.argv[1]))
+pts = ctx.mul_fixed_base(w.scalars_254(N, offset=3))
+sc = w.scalars_254(N, offset=900000)
+h_p, h_s, h_o = ctx.host_empty(N * 64), ctx.host_empty(N * 32), ctx.host_empty(N * 64)
+h_p[:] = pts.reshape(-1); h_s[:] = sc.reshape(-1)
+row = []
+for n in (1, 4, 16, 64, 256, 1024, 4096, 8192, 16384, 32768, 65536, 131072):
+    f = lambda: ctx._ck(ctx.lib.bjj_mul_var_base(ctx.handle, h_p.ctypes.data, h_s.ctypes.data, C.c_size_t(n), h_o.ctypes.data), "vb")
+    t0 = time.perf_counter(); f()
+    while time.perf_counter() - t0 < 0.2: f()
+    ts = []
+    for _ in range(15):
+        t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
+    ts.sort()
+    row.append("%%6d: %%7.1f (%%7.1f) form %%d" %% (n, ts[len(ts) // 2] * 1e6, ts[0] * 1e6, ctx.info().last_var_base_form))
+print("\n".join(row))
+''' % ROOT
+W = sys.argv[1] if len(sys.argv) > 1 else "23"
+for qmax in ("0", "1048576"):
+    print("# BJJ_VB_QUAD_MAX=%s: microseconds per call, median (min)" % qmax, flush=True)
+    r = subprocess.run([sys.executable, "-c", CHILD, W], env=dict(os.environ, BJJ_VB_QUAD_MAX=qmax), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    print(r.stdout.rstrip() or r.stderr[-800:], flush=True)
