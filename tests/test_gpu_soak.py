@@ -254,3 +254,33 @@ def test_soak_host_verify_compressed_across_chunks(gpu_ctx, oracle, seed):
     assert (got[idx] == oracle.verify_compressed(pkc[idx], sig[idx], msgs[idx])).all()
     for b in held:
         gpu_ctx.host_free(b)
+
+
+@pytest.mark.parametrize("seed", _more_seeds([41, 42, 43, 44, 45, 46], "BJJ_SOAK_SHORT_VAR_BASE_SEEDS"))
+def test_soak_short_var_base_calls(gpu_ctx, oracle, seed):
+    """short Point::mul_scalar calls (four lanes per item, csrc/k_small.hip): a seeded size, points that are multiples of G (order 8l) rather than of B8,
+    raw 256-bit scalars, a seeded share of off-curve and of small-order points -- every item against the oracle, host pointers (pageable) and a device launch"""
+    import torch
+    rng = np.random.default_rng(0x51ab0000 + seed)
+    n = int(rng.integers(1, 1500))
+    g = (995203441582195749578291179787384436505546430278305826713579947235728471134, 5472060717959818805561601436314318772137091100104008585924551046643952123905)
+    G = np.frombuffer(g[0].to_bytes(32, "little") + g[1].to_bytes(32, "little"), np.uint8)
+    ks = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x3f
+    ks[rng.random(n) < 0.05] = 0                                                  # the identity as a base point
+    l8 = np.frombuffer((2736030358979909402780800718157159386076813972158567259200215660948447373041).to_bytes(32, "little"), np.uint8)
+    ks[rng.random(n) < 0.05] = l8                                                  # l * G: a point of order 8
+    pts = oracle.mul_var_base(np.tile(G, (n, 1)), ks).copy()
+    off = rng.random(n) < float(rng.choice([0.0, 0.01, 0.3]))
+    pts[off, int(rng.integers(0, 31))] ^= 1 << int(rng.integers(0, 8))
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)                             # raw: bits 254 and 255 set on three quarters of them
+    want = oracle.mul_var_base(pts, sc)
+    got = gpu_ctx.mul_var_base(pts, sc)
+    assert gpu_ctx.info().last_var_base_form == 2
+    assert (got == want).all(), (seed, n, np.nonzero((got != want).any(axis=1))[0][:8])
+    dev = torch.device("cuda", 0)
+    d_p, d_s = torch.from_numpy(pts.reshape(-1)).to(dev), torch.from_numpy(sc.reshape(-1)).to(dev)
+    d_o = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+    gpu_ctx.mul_var_base_dev(d_p.data_ptr(), d_s.data_ptr(), n, d_o.data_ptr())
+    gpu_ctx.sync()
+    assert (d_o.cpu().numpy().reshape(n, 64) == want).all(), (seed, n)
