@@ -70,6 +70,7 @@ class BjjInfo(ctypes.Structure):
         ("kernel_var_base_overlap", ctypes.c_char_p),
         ("last_var_base_split", ctypes.c_int),
         ("last_host_zero_copy", ctypes.c_uint32),
+        ("last_poseidon_form", ctypes.c_int),
     ]
 
 

@@ -198,6 +198,9 @@ struct bjj_ctx {
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
   // what the last calls did (bjj_get_info; tests and the bench line read these)
   int last_k1 = -1, last_k2 = -1, last_verify_mode = -1;
+  size_t verify_small_max = (size_t)1 << 13;   // EdDSA verify: calls of at most this many signatures run eight lanes per signature (BJJ_VERIFY_SMALL_MAX; 0 = never)
+  size_t p5_coop_max = (size_t)1 << 14;    // Poseidon: calls of at most this many hashes run six lanes per hash (BJJ_P5_COOP_MAX; 0 = never)
+  int last_p5 = -1;
   size_t vb_quad_max = (size_t)1 << 14;    // variable base: calls of at most this many items run four lanes per item (BJJ_VB_QUAD_MAX; 0 = never)
   int idle_alternations = 0;               // expect_overlap: consecutive alternating calls that found the other set idle
   u32 last_host_direct = 0, last_host_staged = 0, last_host_chunks = 0;
@@ -1071,6 +1074,14 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   if (const char* e = getenv("BJJ_K2_VARIANT")) {
     if (e[0] == '0' || e[0] == '1') c->k2_variant = e[0] - '0';
   }
+  if (const char* e = getenv("BJJ_VERIFY_SMALL_MAX")) {  // tests / A-B
+    char* q = nullptr; const unsigned long long v = strtoull(e, &q, 0);
+    if (q != e && v <= ((unsigned long long)1 << 20)) c->verify_small_max = (size_t)v;
+  }
+  if (const char* e = getenv("BJJ_P5_COOP_MAX")) {  // tests / A-B
+    char* q = nullptr; const unsigned long long v = strtoull(e, &q, 0);
+    if (q != e && v <= ((unsigned long long)1 << 20)) c->p5_coop_max = (size_t)v;
+  }
   if (const char* e = getenv("BJJ_VB_QUAD_MAX")) {  // tests / A-B: variable-base calls of at most this many items run four lanes per item (0 = never)
     char* q = nullptr; const unsigned long long v = strtoull(e, &q, 0);
     if (q != e && v <= ((unsigned long long)1 << 20)) c->vb_quad_max = (size_t)v;
@@ -1256,6 +1267,7 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   info->last_var_base_form = c->last_k2;
   info->last_var_base_split = c->last_vb_split;
   info->last_host_zero_copy = c->last_host_zero_copy;
+  info->last_poseidon_form = c->last_p5;
   info->last_verify_dispatch = c->last_verify_mode;
   info->last_host_direct_arrays = c->last_host_direct;
   info->last_host_staged_arrays = c->last_host_staged;
@@ -1539,6 +1551,11 @@ int bjj_poseidon5_dev(bjj_ctx* c, const void* d_in, size_t n, void* d_out, void*
   CHECK_N(n);
   CHECK_PTR(d_in, "bjj_poseidon5_dev"); CHECK_PTR(d_out, "bjj_poseidon5_dev");
   DEV_ENTER(c, stream);
+  // Short calls (a single POSEIDON.hash is one): six lanes per hash (k_small.hip) -- the permutation's dependent chain instead of all of
+  // its ~1 000 multiplications in a row on one lane (profiles/r06_small_calls.txt)
+  c->last_p5 = n <= c->p5_coop_max ? 1 : 0;
+  if (c->last_p5) LAUNCHCK(bjjk::poseidon5_coop(st, (const uint8_t*)d_in, n, (uint8_t*)d_out), "bjj_poseidon5_dev");
+  else
   LAUNCHCK(bjjk::poseidon5(st, grid_for(c, n, c->occ_poseidon), (const uint8_t*)d_in, n, (uint8_t*)d_out), "bjj_poseidon5_dev");
   DEV_LEAVE(c);
 }
@@ -1547,6 +1564,17 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
                           const uint8_t* msg, size_t n, uint8_t* ok) {
   { int rc_ = ensure_scan_stream(S); if (rc_) return rc_; }
   const int scan_grid = grid_for(c, n, c->occ_scan, 64) * 64 / bjjk::verify_scan_block();   // occ_scan counts waves
+  // Short calls (a single `verify` is one): the bulk with eight lanes per signature (k_small.hip) between K4's scan and K4's exact
+  // launch -- the hash on six lanes, the curve arithmetic on four, instead of one lane's serial chain (profiles/r06_small_calls.txt)
+  if (!schnorr && n <= c->verify_small_max && c->verify_mode < 0) {
+    c->last_verify_mode = 2;
+    c->rings_used = true;               // the exact launch takes its table scratch from the slot queues
+    LAUNCHCK(bjjk::verify_scan(st, scan_grid, pk, r, msg, n, S->slow), "verify scan");
+    LAUNCHCK(bjjk::verify_small(st, c->table, c->W, c->nwin, pk, r, s, msg, n, ok), "verify (short call)");
+    LAUNCHCK(bjjk::verify_main(st, 1, 0, false, c->table, c->W, c->nwin, pk, r, s, msg, n, ok, S->vb_tables, S->slow, S->slotq,
+                               S->slot_cap | ((u32)c->xccs << 16), bjjk::VERIFY_EXACT), "verify (exact)");
+    return BJJ_OK;
+  }
   bool busy = expect_overlap(c, S);
   if (busy && c->verify_mode < 0 && n > BJJ_LARGE_LAUNCH) { int rc_ = wait_for_other_sets(c, S, st); if (rc_) return rc_; busy = false; }
   // k_verify.hip: persistent waves for ONE large launch that runs alone, one group per workgroup otherwise

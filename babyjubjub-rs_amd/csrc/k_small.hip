@@ -156,3 +156,255 @@ hipError_t mul_var_base_quad(hipStream_t st, const uint8_t* pts, const uint8_t* 
   return hipGetLastError();
 }
 }  // namespace bjjk
+
+// =====================================================================================================================================
+// Poseidon t = 6 (src/lib.rs:400-404; poseidon.hpp) for SHORT calls: six lanes per hash (groups of eight lanes, two of them spares).
+//
+// One lane per hash is ~1 000 multiplication-equivalents in a row, 0.51 ms, whatever the call's size: six times what the CPU needs
+// for ONE hash.  The dependent chain of the permutation is much shorter: in a (sparse-form) partial round only
+//     x0 = (st0 + k)^5                        3 multiplications
+//     st0' = m00 x0 + (v . st[1..5])          1 multiplication once x0 is there -- the dot product over the OLD st[1..5] does not wait for x0
+// are in sequence; the five updates st_j += what_j x0 and the five products of the dot product are independent of one another.  Lane j of a
+// group owns st_j: the round is FOUR multiplication slots for the whole group -- slot 1: lane 0 squares, lanes 1..5 form v_j st_j; slots 2, 3:
+// lane 0 finishes x0; x0 is broadcast, the five products are summed across the lanes (butterfly); slot 4: lane 0 m00 x0, lanes 1..5 what_j x0.
+// A full round is three slots for the six S-boxes side by side, then every lane gathers the state and forms ITS row of M . st.
+// The same constants (bjj_constants.inc: the sparse form gen_tables.py derives) and the same field elements round by round as poseidon5_t<false>,
+// so the hash is the same canonical integer: tests/test_gpu_small_calls.py, against bjj_k_poseidon5 and the oracle.
+// =====================================================================================================================================
+#define BJJ_P5C_BLOCK 64
+#define BJJ_P5C_GROUP 8
+__device__ __forceinline__ Fr grp_get(const Fr& f, int k) {          // the value lane k of this lane's group holds
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = (u32)__shfl((int)f.v[i], k, BJJ_P5C_GROUP);
+  return r;
+}
+__device__ __forceinline__ Fr grp_sum(Fr f) {                        // sum over the group, on every lane (carried; <= 8 terms of < 2r)
+#pragma unroll
+  for (int m = 1; m < BJJ_P5C_GROUP; m <<= 1) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < NL; i++) o.v[i] = (u32)__shfl_xor((int)f.v[i], m, BJJ_P5C_GROUP);
+    f = fr_add(f, o);
+  }
+  return f;
+}
+__device__ __forceinline__ Fr p5c_const(const Fr* base, int idx) {   // a per-lane element of the constant block
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = base[idx].v[i];
+  return r;
+}
+// S-boxes side by side, then this lane's row of M . state.  LAST: only row 0 is needed (the hash is element 0)
+__device__ __forceinline__ Fr p5c_full_round(int j, const Fr& mine, int r) {
+  const Fr x = fr_pow5(fr_add(mine, p5c_const(c_K.PCF, r * 6 + j)));
+  Fr s[6], row[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { s[k] = grp_get(x, k); row[k] = p5c_const(c_K.PM, j * 6 + k); }
+  return fr_dot<6>(row, s);
+}
+
+// the permutation over one group: lane j (0 .. 5; the spare lanes pass j = 5) brings element j of the state [0, in0 .. in4] (Montgomery, < 2r);
+// returns the final state's element of this lane -- the hash is lane 0's
+__device__ __forceinline__ Fr p5c_permute(int j, int gl, Fr st) {
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) st = p5c_full_round(j, st, r);
+  // 60 partial rounds, sparse form, one at a time (poseidon5_t<false>); the constants of round p + 1 are fetched while round p runs
+  const int i1 = j, i2 = j ? 5 + j : 0;
+  Fr c1 = p5c_const(c_K.PSP, i1), c2 = p5c_const(c_K.PSP, i2);
+#pragma unroll 1
+  for (int p = 0; p < 60; p++) {
+    const int pn = p < 59 ? p + 1 : 59;
+    const Fr c1n = p5c_const(c_K.PSP, pn * 11 + i1), c2n = p5c_const(c_K.PSP, pn * 11 + i2);
+    const Fr a = fr_add(st, c_K.PKP[p]);                             // (lane 0's is the one that counts)
+    const Fr r1 = fr_mul(fr_select(j == 0, a, c1), fr_select(j == 0, a, st));       // lane 0: a^2       lanes 1..5: v_j st_j
+    const Fr t2 = fr_mul(r1, r1);                                                     // lane 0: a^4
+    const Fr x0 = grp_get(fr_mul(t2, a), 0);                                          // lane 0: a^5, to every lane
+    const Fr V = grp_sum(fr_select(gl >= 1 && gl <= 5, r1, fr_zero()));               // v . st[1..5] (the old elements)
+    const Fr m = fr_mul(c2, x0);                                                      // lane 0: m00 x0    lanes 1..5: what_j x0
+    st = fr_select(j == 0, fr_reduce_weak(fr_add(m, V)), fr_add(st, m));
+    if ((p & 3) == 3) st = fr_reduce_weak(st);                        // the lazily growing elements stay below ~10 r
+    c1 = c1n; c2 = c2n;
+  }
+  {  // diag(1, A_last): lanes 1..5 take their row of the 5 x 5 block over st[1..5]
+    Fr s[5], row[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { s[k] = grp_get(st, k + 1); row[k] = p5c_const(c_K.PAL, (j ? j - 1 : 0) * 5 + k); }
+    const Fr d = fr_dot<5>(row, s);
+    st = fr_select(j == 0, st, d);
+  }
+#pragma unroll 1
+  for (int r = 4; r < 8; r++) st = p5c_full_round(j, st, r);         // (round 7: only lane 0's row is the hash)
+  return st;
+}
+
+__global__ void __launch_bounds__(BJJ_P5C_BLOCK) bjj_k_poseidon5_coop(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
+  const int lane = threadIdx.x, gl = lane & (BJJ_P5C_GROUP - 1);
+  const int j = gl < 6 ? gl : 5;                                     // the spare lanes shadow lane 5 (their values are never read)
+  const size_t item = (size_t)blockIdx.x * (BJJ_P5C_BLOCK / BJJ_P5C_GROUP) + (size_t)(lane >> 3);
+  const bool live = item < n;
+  const size_t i = live ? item : n - 1;
+  u32 w[8];
+  load_w8(in + i * 160 + (size_t)(j ? j - 1 : 0) * 32, w);
+  const Fr st = p5c_permute(j, gl, fr_select(j == 0, fr_zero(), fr_to_mont_words(w)));   // state = [0, in0 .. in4]
+  if (live && gl == 0) {
+    fr_from_mont_words(st, w);
+    store_w8(out + i * 32, w);
+  }
+}
+
+// =====================================================================================================================================
+// verify(pk, sig, msg) (src/lib.rs:395-412) for SHORT calls: eight lanes per signature.
+//
+// The fast path of K4 (bjj_device.hpp: verify_fast_t<false>) with its two serial parts spread over lanes: the hash runs on six of the group's
+// lanes (p5c_permute), and  u (-8A) + |v| (-+R) + (v s mod l) B8 == O  -- the short odd pair (u, v) of the lattice step, the joint windowed loop, then
+// the fixed-base windows -- runs with X, Y, Z, T of the accumulator on the four lanes of a quad (both quads of the group compute it; the lower one's
+// verdict is stored).  Same scalars, same tables of 0 .. 8 P, same windows, same table entries of B8 as the lane form: the same group element, the
+// same verdict.  An item whose pk or R is off the curve is not this kernel's: the scan has put it on the list and the exact launch owns its
+// verdict, as with K4's bulk workgroups (k_verify.hip).
+// =====================================================================================================================================
+#define BJJ_VS_BLOCK 64
+__device__ __forceinline__ void qtbl_build(int q, u32* tbl, const Fr& c) {    // 0 .. 8 P for P = c (any Z): vb_build_table
+  const PNiels id = pniels_identity();
+  qtbl_store(tbl, 0, q, fr_select(q == 0, id.ymx, fr_select(q == 1, id.ypx, fr_select(q == 2, id.z2, id.t2d))));
+  const Fr p1 = quad_entry(q, c);
+  qtbl_store(tbl, 1, q, p1);
+  Fr cur = c;
+#pragma unroll 1
+  for (int k = 2; k <= 8; k++) {
+    cur = quad_add(q, cur, p1);
+    qtbl_store(tbl, k, q, quad_entry(q, cur));
+  }
+}
+// this lane's component of entry `slot` of the fixed-base table (load_niels: Y-X words 0..8, Y+X 9..17, 2D'xy 18..26; Z = 1: 2Z = 2), with the digit's sign
+__device__ __forceinline__ Fr qfb_load(const u32* __restrict__ table, size_t slot, bool neg, int q) {
+  const int qq = (neg && q < 2) ? (q ^ 1) : q;
+  const u32* e = table + slot * NIELS_WORDS + (qq == 3 ? 18 : qq * 9);
+  Fr n;
+#pragma unroll
+  for (int i = 0; i < NL; i++) n.v[i] = e[i];
+  n = fr_select(q == 2, fr_dbl(fr_one()), n);
+  return fr_select(neg && q == 3, fr_sub_lazy(fr_zero(), n), n);
+}
+__device__ __forceinline__ int wave_max_int(int v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+  return v;
+}
+
+__global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_eddsa_verify_small(const u32* __restrict__ table, int W, int nwin,
+                                                                        const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
+                                                                        const uint8_t* __restrict__ sg, const uint8_t* __restrict__ msg, size_t n,
+                                                                        uint8_t* __restrict__ ok) {
+  __shared__ u32 tbl_all[(BJJ_VS_BLOCK / 4) * 2 * QTBL_ITEM_WORDS];    // two tables per quad: 41.5 KB
+  const int lane = threadIdx.x, gl = lane & 7, q = lane & 3;
+  const int j = gl < 6 ? gl : 5;
+  u32* tbl1 = tbl_all + (lane >> 2) * 2 * QTBL_ITEM_WORDS;
+  u32* tbl2 = tbl1 + QTBL_ITEM_WORDS;
+  const size_t item = (size_t)blockIdx.x * (BJJ_VS_BLOCK / 8) + (size_t)(lane >> 3);
+  const bool live = item < n;
+  const size_t i = live ? item : n - 1;
+  u32 w[8];
+  load_w8(msg + i * 32, w);
+  const bool msg_gt = words_gt_modulus(w);                           // :396-398
+  const Fr m5 = fr_to_mont_words(w);
+  load_w8(rb8 + i * 64, w);      const Fr rx = fr_to_mont_words(w);
+  load_w8(rb8 + i * 64 + 32, w); const Fr ry = fr_to_mont_words(w);
+  load_w8(pk + i * 64, w);       const Fr ax = fr_to_mont_words(w);
+  load_w8(pk + i * 64 + 32, w);  const Fr ay = fr_to_mont_words(w);
+  const bool need_exact = !msg_gt && !(ref_on_curve(rx, ry, c_K) && ref_on_curve(ax, ay, c_K));
+  // hm = H(R.x, R.y, A.x, A.y, msg) (:400-404), six lanes
+  const Fr st0 = fr_select(j == 0, fr_zero(), fr_select(j == 1, rx, fr_select(j == 2, ry, fr_select(j == 3, ax, fr_select(j == 4, ay, m5)))));
+  const Fr hm = grp_get(p5c_permute(j, gl, st0), 0);
+  const Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));
+  // the short odd pair and the fixed-base scalar (verify_fast_t): every lane for itself
+  Fr u, vmag;
+  bool vneg;
+  lattice_short_pair(plain_mod_l(hm_plain, c_K), u, vmag, vneg, c_K);
+  u32 sw[8], cw[8];
+  load_w8(sg + i * 32, sw);
+  {
+    const Fr sl = fl_mul(fr_from_words(sw), c_K.L_R1, c_K);
+    Fr c = fl_canon4(fl_mul(vmag, fl_mul(sl, c_K.L_R2, c_K), c_K), c_K);
+    if (vneg && !limbs_is_zero(c)) { Fr t = c_K.L; limbs_submul(t, 1u, c); c = t; }
+    fr_to_words(c, cw);
+  }
+  // P1 = -8A, P2 = -sign(v) R on the a' = -1 curve, one coordinate per lane; their tables
+  {
+    const Fr X = fr_mul(fr_neg(ax), c_K.F);
+    Fr c = fr_select(q == 0, X, fr_select(q == 1, ay, fr_select(q == 2, fr_one(), fr_mul(X, ay))));
+#pragma unroll 1
+    for (int k = 0; k < 3; k++) c = quad_dbl(q, c);
+    qtbl_build(q, tbl1, c);
+  }
+  {
+    const Fr X = fr_mul(fr_select(vneg, rx, fr_neg(rx)), c_K.F);
+    const Fr c = fr_select(q == 0, X, fr_select(q == 1, ry, fr_select(q == 2, fr_one(), fr_mul(X, ry))));
+    qtbl_build(q, tbl2, c);
+  }
+  __syncthreads();
+  // the joint windowed loop (joint_short_pair / joint_mul_windowed): as many windows as the widest pair of the wave needs
+  const int ub = limbs_bits(u), vb = limbs_bits(vmag);
+  const int mb = ub > vb ? ub : vb;
+  const int need = mb <= 2 ? 1 : (mb + 5) >> 2;
+  const int jw = wave_max_int(need > 64 ? 64 : need);
+  u32 tu[8], tv[8];
+  recode_signed4(u, tu);
+  recode_signed4(vmag, tv);
+  Fr acc;
+  {
+    const int jj = jw - 1;
+    const int du = (int)((tu[jj >> 3] >> ((jj & 7) * 4)) & 15u) - 8;
+    const int dv = (int)((tv[jj >> 3] >> ((jj & 7) * 4)) & 15u) - 8;
+    const Fr e1 = qtbl_load(tbl1, du, q), e2 = qtbl_load(tbl2, dv, q);
+    const Fr ymx = quad_bcast<0>(e1), ypx = quad_bcast<1>(e1);       // pniels_to_ext with T (an addition follows): 2T = (2D'T) / D'
+    acc = fr_select(q == 0, fr_reduce_weak(fr_sub8(ypx, ymx)), fr_select(q == 1, fr_reduce_weak(fr_add(ypx, ymx)),
+                    fr_select(q == 2, fr_reduce_weak(e1), fr_mul(e1, c_K.DPINV))));
+    acc = quad_add(q, acc, e2);
+  }
+#pragma unroll 1
+  for (int jj = jw - 2; jj >= 0; jj--) {
+    const int du = (int)((tu[jj >> 3] >> ((jj & 7) * 4)) & 15u) - 8;
+    const int dv = (int)((tv[jj >> 3] >> ((jj & 7) * 4)) & 15u) - 8;
+    const Fr e1 = qtbl_load(tbl1, du, q), e2 = qtbl_load(tbl2, dv, q);
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) acc = quad_dbl(q, acc);
+    acc = quad_add(q, acc, e1);
+    acc = quad_add(q, acc, e2);
+  }
+  // + (v s mod l) B8: the fixed-base windows (fixed_base_accumulate); window 0 is stored in T form
+  {
+    DigitStream ds = digit_stream(cw, W);
+    bool neg;
+    size_t slot = digit_next(ds, neg);
+    Fr cur = qfb_load(table, slot, neg, q);
+    cur = fr_select(q == 3, fr_mul(cur, c_K.DP), cur);
+#pragma unroll 1
+    for (int k = 0; k + 1 < nwin; k++) {
+      slot = digit_next(ds, neg);
+      const Fr nxt = qfb_load(table, slot, neg, q);                   // in flight during this window's addition
+      acc = quad_add(q, acc, cur);
+      cur = nxt;
+    }
+    acc = quad_add(q, acc, cur);
+  }
+  // the projective identity (0 : z : z)
+  const Fr X = quad_bcast<0>(acc), Y = quad_bcast<1>(acc), Z = quad_bcast<2>(acc);
+  const int verdict = (fr_is_zero(X) && fr_eq(Y, Z)) ? 1 : 0;
+  if (live && !need_exact && gl == 0) ok[i] = (uint8_t)(msg_gt ? 0 : verdict);
+}
+
+namespace bjjk {
+// the bulk of a short verify call; the scan (before) and the exact launch (behind) are K4's (k_verify.hip)
+hipError_t verify_small(hipStream_t st, const u32* table, int W, int nwin, const uint8_t* pk, const uint8_t* rb8, const uint8_t* s, const uint8_t* msg,
+                        size_t n, uint8_t* ok) {
+  const size_t per = BJJ_VS_BLOCK / 8, grid = (n + per - 1) / per;
+  BJJ_LAUNCH(bjj_k_eddsa_verify_small, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok);
+  return hipGetLastError();
+}
+hipError_t poseidon5_coop(hipStream_t st, const uint8_t* in, size_t n, uint8_t* out) {
+  const size_t per = BJJ_P5C_BLOCK / BJJ_P5C_GROUP, grid = (n + per - 1) / per;
+  BJJ_LAUNCH(bjj_k_poseidon5_coop, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_P5C_BLOCK), 0, st, in, n, out);
+  return hipGetLastError();
+}
+}  // namespace bjjk

@@ -314,8 +314,8 @@ typedef struct {
   int signer_constant_time; /* bjj_set_signer_constant_time: 1 = the signer entry points scan a small table (see there) */
   /* since 0.5.0 -- what the context's LAST calls did (-1 = no such call yet); for tests, profiles and the bench line */
   int last_fixed_base_shape;   /* 0 = one 512-lane workgroup per CU (a launch that runs alone), 1 = two of 256 (overlapping launches) */
-  int last_var_base_form;      /* 1 = tiles (alone), 0 = grid-strided (overlapping) */
-  int last_verify_dispatch;    /* 0 = persistent waves (one launch > 2^21 items that runs alone), 1 = one group per workgroup */
+  int last_var_base_form;      /* 1 = tiles (alone), 0 = grid-strided (overlapping), 2 = four lanes per item (short calls, since 0.6.0) */
+  int last_verify_dispatch;    /* 0 = persistent waves (one launch > 2^21 items that runs alone), 1 = one group per workgroup, 2 = eight lanes per signature (short calls, since 0.6.0) */
   uint32_t last_host_direct_arrays;  /* last host-pointer call: arrays copied straight from / to pinned caller memory ... */
   uint32_t last_host_staged_arrays;  /* ... arrays staged through the context's pinned buffers (pageable caller memory) ... */
   uint32_t last_host_chunks;         /* ... and the chunks it was cut into */
@@ -326,6 +326,7 @@ typedef struct {
   int last_var_base_split;     /* variable base, the exact kernel for off-curve points: 0 = behind the batch kernel, 1 = beside it (scan first) */
   uint32_t last_host_zero_copy; /* last host-pointer call, bit 0: the kernels stored their results into the (pinned) output array themselves, no copy-out stage;
                                    bit 1: the kernels read the (pinned) input arrays themselves, no copy-in stage */
+  int last_poseidon_form;      /* 0 = one hash per lane, 1 = six lanes per hash (short calls) */
 } bjj_info;
 int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
 

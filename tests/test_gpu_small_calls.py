@@ -137,3 +137,107 @@ def test_wide_scalars_and_long_calls_keep_k2(gpu_ctx):
     wide = np.concatenate([w.scalars_254(40, offset=1), w.scalars_254(40, offset=2)], axis=1)
     gpu_ctx.mul_var_base_wide(pts, wide, 64)
     assert gpu_ctx.info().last_var_base_form in (0, 1)
+
+
+# ------------------------------------------------------------------------------------------------ Poseidon, six lanes per hash
+P5_COOP_MAX = 1 << 14
+
+
+@pytest.fixture(scope="module")
+def lane_ctx():
+    """a context whose short Poseidon calls still run one hash per lane (BJJ_P5_COOP_MAX=0 is read at bjj_init)"""
+    import os
+    import babyjubjub_rs_amd as bjj
+    old = os.environ.get("BJJ_P5_COOP_MAX")
+    os.environ["BJJ_P5_COOP_MAX"] = "0"
+    try:
+        c = bjj.Context(0, 16)
+    finally:
+        if old is None:
+            del os.environ["BJJ_P5_COOP_MAX"]
+        else:
+            os.environ["BJJ_P5_COOP_MAX"] = old
+    yield c
+    c.close()
+
+
+def test_poseidon_short_calls_against_the_lane_kernel_and_the_oracle(gpu_ctx, lane_ctx, oracle, golden):
+    """POSEIDON.hash(vec![a, b, c, d, e]) (src/lib.rs:400-404) in short calls: every call size around the group / wave / switch-over boundaries, inputs
+    that are 0, 1, r - 1, and -- what the reference never feeds it, but the entry point accepts -- >= r"""
+    rng = np.random.default_rng(0x9051)
+    nmax = P5_COOP_MAX + 9
+    h = rng.integers(0, 256, (nmax, 160), dtype=np.uint8)
+    h[:, 31::32] &= 0x1f                                      # below 2^253 < r
+    edge = [0, 1, 2, Q - 1, Q - 2, Q, Q + 1, (1 << 256) - 1, 1 << 255, (1 << 253)]
+    for k, v in enumerate(edge):
+        h[k, (k % 5) * 32:(k % 5) * 32 + 32] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    h[len(edge)] = np.tile(np.frombuffer((Q - 1).to_bytes(32, "little"), np.uint8), 5)
+    h[len(edge) + 1] = 0
+    want_lane = lane_ctx.poseidon5(h)
+    assert lane_ctx.info().last_poseidon_form == 0
+    want = oracle.poseidon5(h[:3000])
+    assert (want_lane[:3000] == want).all()
+    for n in (1, 2, 7, 8, 9, 63, 64, 65, 1000, P5_COOP_MAX - 1, P5_COOP_MAX, P5_COOP_MAX + 1, nmax):
+        got = gpu_ctx.poseidon5(h[:n])
+        assert gpu_ctx.info().last_poseidon_form == (1 if n <= P5_COOP_MAX else 0), n
+        assert got.shape == (n, 32) and (got == want_lane[:n]).all(), (n, np.nonzero((got != want_lane[:n]).any(axis=1))[0][:8])
+    # the published known answers (tests/golden/reference_kats.json: poseidon_public) one call per hash -- what a single POSEIDON.hash costs and returns
+    for c in golden["reference_kats"]["poseidon_public"]["cases"]:
+        one = np.frombuffer(b"".join(int(v, 16).to_bytes(32, "little") if isinstance(v, str) else int(v).to_bytes(32, "little") for v in c["in"]), np.uint8)
+        out = c["out"]
+        exp = (int(out, 16) if isinstance(out, str) else int(out)).to_bytes(32, "little")
+        assert bytes(gpu_ctx.poseidon5(one.reshape(1, 160))[0]) == exp
+        assert gpu_ctx.info().last_poseidon_form == 1
+
+
+# ------------------------------------------------------------------------------------------------ verify, eight lanes per signature
+VERIFY_SMALL_MAX = 1 << 13
+
+
+@pytest.mark.parametrize("window_bits", [16, 23, 13])
+def test_verify_short_calls_every_verdict_against_the_lane_kernel_and_the_oracle(oracle, monkeypatch, window_bits):
+    """verify(pk, sig, msg) (src/lib.rs:395-412) in short calls: valid signatures, every kind of corruption (a bit in pk, R, s, msg; pk or R off the curve:
+    the exact launch's items; msg > Q; s >= l and s >= 2^255; the identity and small-order points as pk or R), every call size around the group / wave /
+    switch-over boundaries, three table widths (the fixed-base windows are read one component per lane) -- verdicts equal the oracle's and K4's"""
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    ctx = bjj.Context(0, window_bits)
+    monkeypatch.setenv("BJJ_VERIFY_SMALL_MAX", "0")
+    k4 = bjj.Context(0, window_bits)
+    monkeypatch.delenv("BJJ_VERIFY_SMALL_MAX")
+    try:
+        nmax = VERIFY_SMALL_MAX + 37
+        A, R, S, msg = w.make_signatures(oracle.mul_fixed_base, oracle.poseidon5, nmax)
+        bad = w.corrupt(A, R, S, msg, nmax)                     # 1 in 64: a bit in one of the four records, half of those push pk / R off the curve
+        rng = np.random.default_rng(0x7e51f)
+        extra = rng.choice(np.nonzero(~bad)[0], 40, replace=False)
+        S[extra[0:5]] = S[extra[0:5]] + 0                        # (valid)
+        for k in extra[5:10]:                                    # s + l: B8 has order l, the reference multiplies by the raw integer -> still valid
+            v = int.from_bytes(bytes(S[k]), "little") + L
+            S[k] = np.frombuffer(v.to_bytes(32, "little"), np.uint8)
+        msg[extra[10:13], 31] = 0xff                             # msg > Q -> false
+        S[extra[13:16], 31] |= 0x80                              # s >= 2^255: a different integer -> false (unless it happens to be s + k l)
+        A[extra[16]] = np.frombuffer((0).to_bytes(32, "little") + (1).to_bytes(32, "little"), np.uint8)            # pk = identity
+        R[extra[17]] = np.frombuffer((0).to_bytes(32, "little") + (1).to_bytes(32, "little"), np.uint8)            # R = identity
+        A[extra[18]] = np.frombuffer((0).to_bytes(32, "little") + (Q - 1).to_bytes(32, "little"), np.uint8)        # order 2
+        R[extra[19]] = np.frombuffer((0).to_bytes(32, "little") + (Q - 1).to_bytes(32, "little"), np.uint8)
+        A[extra[20:24], 5] ^= 0x10                               # pk off the curve (almost surely): exact path
+        R[extra[24:28], 40] ^= 0x01                              # R.y changed: off the curve
+        A[extra[28], :32] = 0xff                                 # coordinates >= r
+        R[extra[29], 32:] = 0xff
+        S[extra[30]] = 0
+        msg[extra[31]] = 0
+        want = oracle.verify(A, R, S, msg)
+        assert 0 < (want == 0).sum() < nmax // 8 and (want[extra[5:10]] == 1).all()
+        ref = k4.eddsa_verify(A, R, S, msg)
+        assert k4.info().last_verify_dispatch in (0, 1) and (ref == want).all()
+        for n in (1, 2, 7, 8, 9, 63, 64, 65, 1000, VERIFY_SMALL_MAX - 1, VERIFY_SMALL_MAX, VERIFY_SMALL_MAX + 1, nmax):
+            got = ctx.eddsa_verify(A[:n], R[:n], S[:n], msg[:n])
+            assert ctx.info().last_verify_dispatch == (2 if n <= VERIFY_SMALL_MAX else ctx.info().last_verify_dispatch), n
+            assert (n <= VERIFY_SMALL_MAX) == (ctx.info().last_verify_dispatch == 2)
+            assert (got == want[:n]).all(), (n, np.nonzero(got != want[:n])[0][:8])
+        # one call per signature, the crate's `verify(pk, sig, msg)`: the interesting ones
+        for k in list(extra) + list(np.nonzero(bad)[0][:24]):
+            assert ctx.eddsa_verify(A[k:k + 1], R[k:k + 1], S[k:k + 1], msg[k:k + 1])[0] == want[k], k
+    finally:
+        ctx.close(); k4.close()
