@@ -99,6 +99,8 @@ def _host_api(h):
     out = rows(h)
     if isinstance(h.get("pageable"), dict):
         out["pageable"] = {k: v["value"] for k, v in rows(h["pageable"]).items()}
+    if isinstance(h.get("single_call"), dict):      # what ONE call of ONE item costs, microseconds (first table)
+        out["single_call_us"] = _pick(h["single_call"], ("fixed_base", "var_base", "poseidon5", "verify"))
     out.update(_pick(h, ("parity_sample_ok", "copy_threads")))
     out["unit"] = "items/s, PCIe-inclusive (pinned host pointers); never `value`"
     return out

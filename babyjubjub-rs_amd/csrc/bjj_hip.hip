@@ -14,6 +14,8 @@
 //   k_verify.hip      bjj_k_eddsa_verify_scan / bjj_k_eddsa_verify / bjj_k_schnorr_verify
 //                                               K4  verify / verify_schnorr        src/lib.rs:395-412, 375-385
 //   k_sign.hip        bjj_k_sign / bjj_k_sign_schnorr                              src/lib.rs:308-361
+//   k_small.hip       bjj_k_mul_var_base_quad / bjj_k_poseidon5_coop / bjj_k_eddsa_verify_small
+//                                               K2 / K3 / K4 for SHORT calls: four lanes per item, six per hash, eight per signature
 // K5 (batched affine conversion) is the epilogue of K1/K2 (k_common.hpp: block_invert).
 // Multi-GPU: bjj_multi_* (bjj_multi.inc, included at the end of this file) -- one context per device,
 // contiguous ceil(n/G) blocks; the device-resident form scatters inputs / gathers results with RCCL (bound with dlopen on

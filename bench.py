@@ -998,6 +998,53 @@ def host_api_block(ctx, n, orc):
                 ctx.host_free(a)
         return res
 
+    # What ONE call of ONE item costs (the reference's single-item API -- B8.mul_scalar / p.mul_scalar / POSEIDON.hash / verify, src/lib.rs:149, :400,
+    # :395 -- is served by n = 1 calls of the batch entry points): pinned host pointers, median of 40 calls after 0.2 s of them, each result
+    # against the oracle.  Short calls run the several-lanes-per-item kernels (csrc/k_small.hip).
+    def single_calls():
+        import ctypes as C
+        one = C.c_size_t(1)
+        h_p, h_s, h_o = ctx.host_empty(64), ctx.host_empty(32), ctx.host_empty(64)
+        h_5, h_h = ctx.host_empty(160), ctx.host_empty(32)
+        hv = [ctx.host_empty(k) for k in (64, 64, 32, 32)]
+        h_ok = ctx.host_empty(1)
+        h_s[:] = sc[:32]
+        pt = orc.mul_fixed_base(sc.reshape(n, 32)[1:2])
+        h_p[:] = pt.reshape(-1)
+        h_5[:] = np.concatenate([pt.reshape(-1), sc[:96]])
+        h_5[31::32] &= 0x1f
+        good_i = int(np.nonzero(~bad)[0][0])
+        for b, a, wdt in zip(hv, v_host, (64, 64, 32, 32)):
+            b[:] = a[good_i * wdt:(good_i + 1) * wdt]
+        calls = {"fixed_base": lambda: ctx.lib.bjj_mul_fixed_base(ctx.handle, h_s.ctypes.data, one, h_o.ctypes.data),
+                 "var_base": lambda: ctx.lib.bjj_mul_var_base(ctx.handle, h_p.ctypes.data, h_s.ctypes.data, one, h_o.ctypes.data),
+                 "poseidon5": lambda: ctx.lib.bjj_poseidon5(ctx.handle, h_5.ctypes.data, one, h_h.ctypes.data),
+                 "verify": lambda: ctx.lib.bjj_eddsa_verify(ctx.handle, hv[0].ctypes.data, hv[1].ctypes.data, hv[2].ctypes.data, hv[3].ctypes.data, one, h_ok.ctypes.data)}
+        res, good = {}, True
+        for k, f in calls.items():
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.2:
+                ctx._ck(f(), k)
+            ts = []
+            for _ in range(40):
+                t = time.perf_counter()
+                f()
+                ts.append(time.perf_counter() - t)
+            res[k] = float(np.median(ts)) * 1e6
+            if k == "fixed_base":
+                good = good and bool((np.asarray(h_o) == orc.mul_fixed_base(sc.reshape(n, 32)[0:1]).reshape(-1)).all())
+            elif k == "var_base":
+                good = good and bool((np.asarray(h_o) == orc.mul_var_base(pt, sc.reshape(n, 32)[0:1]).reshape(-1)).all())
+            elif k == "poseidon5":
+                good = good and bool((np.asarray(h_h) == orc.poseidon5(np.asarray(h_5).reshape(1, 160)).reshape(-1)).all())
+            else:
+                good = good and int(np.asarray(h_ok)[0]) == 1
+        i = ctx.info()
+        for b in [h_p, h_s, h_o, h_5, h_h, h_ok] + hv:
+            ctx.host_free(b)
+        return dict(res, unit="microseconds per n = 1 call, pinned host pointers, median of 40", parity_ok=good,
+                    forms={"var_base": i.last_var_base_form, "poseidon5": i.last_poseidon_form, "verify": i.last_verify_dispatch})
+
     # the same inputs through the device-pointer entry point, ONE launch at a time: what a synchronous call can be held against
     # (the two-stream rate of `also.verify` lives on the overlap of consecutive launches, which a synchronous call cannot have)
     def one_launch():
@@ -1024,10 +1071,11 @@ def host_api_block(ctx, n, orc):
     try:
         pinned = run("pinned")
         pageable = run("pageable")
+        single = single_calls()
     finally:
         if TELEMETRY:
             TELEMETRY.paused = False
-    return {"telemetry_paused": True,
+    return {"telemetry_paused": True, "single_call": single,
             "note": "PCIe-inclusive: host pointers in, host pointers out, synchronous call.  fixed_base / verify = caller arrays in "
                     "pinned memory (bjj_host_alloc): copied directly, chunked pipeline (2^15 items first, doubling to 2^18; "
                     "verify 2^16 to 2^19, its off-curve items as one launch beside the chunks'), chunk kernels alternating over the context's two "
@@ -1041,7 +1089,7 @@ def host_api_block(ctx, n, orc):
             "pageable": {"fixed_base": pageable["fixed_base"], "fixed_base_compressed": pageable["fixed_base_compressed"],
                          "var_base": pageable["var_base"], "verify": pageable["verify"], "verify_compressed": pageable["verify_compressed"]},
             "copy_threads": ctx.info().host_copy_threads,
-            "parity_sample_ok": pinned["parity_sample_ok"] and pageable["parity_sample_ok"]}
+            "parity_sample_ok": pinned["parity_sample_ok"] and pageable["parity_sample_ok"] and single["parity_ok"]}
 
 
 def all_max(x, world, red_dev):

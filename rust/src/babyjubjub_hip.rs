@@ -147,8 +147,9 @@ impl Point {
         PointProjective { x: self.x, y: self.y, z: Fr::one() }
     }
 
-    /// COST OF THE n = 1 CALL: about 1.3 ms (a kernel launch plus two PCIe round trips) against 0.17 ms for the reference on one
-    /// CPU core -- item by item this drop-in is SLOWER than the crate it replaces; the GPU pays from 4-8 items per call on.
+    /// COST OF THE n = 1 CALL: about 0.5 ms (a kernel launch, two PCIe round trips and the multiplication spread over four lanes; 1.2 ms
+    /// until libbjj_hip 0.6.0) against 0.17 ms for the reference on one CPU core -- item by item this drop-in is SLOWER than the crate
+    /// it replaces; the GPU pays from 3 items per call on.
     /// Use `mul_scalar_batch` / `mul_fixed_base_batch` (first table).
     pub fn mul_scalar(&self, n: &BigInt) -> Point {
         // lib.rs:149-164: abs(n) * P, n of any size, not reduced
@@ -299,8 +300,9 @@ pub fn new_key() -> PrivateKey {
     PrivateKey::import(be[..32].to_vec()).unwrap()
 }
 
-/// COST OF THE n = 1 CALL: about 1.4 ms against 0.44 ms for the reference on one CPU core -- a caller that verifies signature by
-/// signature gets slower; break-even is 4-8 signatures per call.  Use `verify_batch` (first table).
+/// COST OF THE n = 1 CALL: about 0.6 ms (eight lanes per signature; 1.4 ms until libbjj_hip 0.6.0) against 0.46 ms for the reference on one
+/// CPU core -- a caller that verifies signature by signature gets slower; break-even is 2 signatures per call.  Use `verify_batch`
+/// (first table).
 pub fn verify(pk: Point, sig: Signature, msg: BigInt) -> bool {
     // lib.rs:395-412
     if msg > *Q {
