@@ -71,6 +71,7 @@ class BjjInfo(ctypes.Structure):
         ("last_var_base_split", ctypes.c_int),
         ("last_host_zero_copy", ctypes.c_uint32),
         ("last_poseidon_form", ctypes.c_int),
+        ("last_sign_form", ctypes.c_int),
     ]
 
 

@@ -200,6 +200,8 @@ struct bjj_ctx {
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
   // what the last calls did (bjj_get_info; tests and the bench line read these)
   int last_k1 = -1, last_k2 = -1, last_verify_mode = -1;
+  size_t sign_small_max = (size_t)1 << 13;     // sign: calls of at most this many signatures run eight lanes per signature (BJJ_SIGN_SMALL_MAX; 0 = never)
+  int last_sign = -1;
   size_t verify_small_max = (size_t)1 << 13;   // EdDSA verify: calls of at most this many signatures run eight lanes per signature (BJJ_VERIFY_SMALL_MAX; 0 = never)
   size_t p5_coop_max = (size_t)1 << 14;    // Poseidon: calls of at most this many hashes run six lanes per hash (BJJ_P5_COOP_MAX; 0 = never)
   int last_p5 = -1;
@@ -913,12 +915,14 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
     (void)hipGetLastError();
     if (pool) for (size_t ch = 0; ch < nchunks; ch++) { pool->wait(&g_in[ch]); pool->wait(&g_out[ch]); }
   }
-  if (sp.secret) {  // key material went through the staging levels: wipe them (also on the error path)
+  if (sp.secret) {  // key material went through the staging levels: wipe them (also on the error path) -- what THIS call can have used of them: the
+    // rings keep the size of the largest call so far, and wiping all of it made a one-key call after a large one cost 0.3 ms more than its kernel
     hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->s_out);
     if (c->dstage) hipMemsetAsync(c->dstage, 0, dev_tot, c->stream);
-    for (int b = 0; b < BJJ_PIPE_BUFS; b++) {
-      if (c->pin_in[b]) secure_bzero(c->pin_in[b], c->pin_in_bytes);
-      if (c->pin_out[b]) secure_bzero(c->pin_out[b], c->pin_out_bytes);
+    const size_t slots = nchunks < (size_t)BJJ_PIPE_BUFS ? nchunks : (size_t)BJJ_PIPE_BUFS;
+    for (size_t b = 0; b < slots; b++) {
+      if (c->pin_in[b] && in_ring) secure_bzero(c->pin_in[b], in_ring < c->pin_in_bytes ? in_ring : c->pin_in_bytes);
+      if (c->pin_out[b] && out_ring) secure_bzero(c->pin_out[b], out_ring < c->pin_out_bytes ? out_ring : c->pin_out_bytes);
     }
     hipStreamSynchronize(c->stream);
   }
@@ -1075,6 +1079,10 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   }
   if (const char* e = getenv("BJJ_K2_VARIANT")) {
     if (e[0] == '0' || e[0] == '1') c->k2_variant = e[0] - '0';
+  }
+  if (const char* e = getenv("BJJ_SIGN_SMALL_MAX")) {  // tests / A-B
+    char* q = nullptr; const unsigned long long v = strtoull(e, &q, 0);
+    if (q != e && v <= ((unsigned long long)1 << 20)) c->sign_small_max = (size_t)v;
   }
   if (const char* e = getenv("BJJ_VERIFY_SMALL_MAX")) {  // tests / A-B
     char* q = nullptr; const unsigned long long v = strtoull(e, &q, 0);
@@ -1270,6 +1278,7 @@ int bjj_get_info(bjj_ctx* c, bjj_info* out) {
   info->last_var_base_split = c->last_vb_split;
   info->last_host_zero_copy = c->last_host_zero_copy;
   info->last_poseidon_form = c->last_p5;
+  info->last_sign_form = c->last_sign;
   info->last_verify_dispatch = c->last_verify_mode;
   info->last_host_direct_arrays = c->last_host_direct;
   info->last_host_staged_arrays = c->last_host_staged;
@@ -1935,6 +1944,11 @@ int bjj_public_keys_compressed_dev(bjj_ctx* c, const void* d_keys, size_t n, voi
 // d_out_s == NULL: the compressed form -- d_out_r holds 64-byte Signature::compress records (src/lib.rs:245-258)
 static int sign_launch(bjj_ctx* c, const void* d_keys, const void* d_msgs, size_t n, void* d_out_r, void* d_out_s, void* d_ok, void* stream) {
   DEV_ENTER(c, stream);
+  c->last_sign = (!c->ct_signer && n <= c->sign_small_max) ? 1 : 0;
+  if (c->last_sign)   // short calls (a single sk.sign(msg) is one): eight lanes per signature, the hash on six of them (k_small.hip)
+    LAUNCHCK(bjjk::sign_small(st, c->table, c->W, c->nwin, (const uint8_t*)d_keys, (const uint8_t*)d_msgs, n, (uint8_t*)d_out_r, (uint8_t*)d_out_s,
+                              (uint8_t*)d_ok), "bjj_sign_dev (short call)");
+  else
   if (c->ct_signer)
     LAUNCHCK(bjjk::sign_ct(st, grid_for(c, n, c->occ_sign_ct), c->ct_table, BJJ_CT_W, fixed_nwin(BJJ_CT_W), (const uint8_t*)d_keys,
                            (const uint8_t*)d_msgs, n, (uint8_t*)d_out_r, (uint8_t*)d_out_s, (uint8_t*)d_ok), "bjj_sign_dev (constant-time)");

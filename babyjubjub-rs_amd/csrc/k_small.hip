@@ -292,6 +292,23 @@ __device__ __forceinline__ int wave_max_int(int v) {
   return v;
 }
 
+// Touch the table entries a fixed-base multiplication by sc (< l) is going to read -- one word of each, all loads in flight together -- so that the gathers
+// of the multiplication itself, which the compiler sinks to their first use one after the other, find their lines and page-table entries in the caches:
+// a lone lane's gather from the 5.9 GB (or 155 GB) table costs several microseconds when it misses the TLB, 11 to 22 of them in a row per item.
+__device__ __forceinline__ void qfb_prefetch(const u32* __restrict__ table, int W, int nwin, const u32 sc[8]) {
+  DigitStream ds = digit_stream(sc, W);
+  u32 v[32];                                     // (tables of fewer than 32 windows: W >= 8; narrower ones are prefetched in part)
+#pragma unroll
+  for (int k = 0; k < 32; k++) {
+    bool neg;
+    const size_t slot = digit_next(ds, neg);
+    v[k] = k < nwin ? table[slot * NIELS_WORDS] : 0u;
+  }
+  u32 sink = 0;
+#pragma unroll
+  for (int k = 0; k < 32; k++) sink ^= v[k];
+  asm volatile("" ::"v"(sink));
+}
 __global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_eddsa_verify_small(const u32* __restrict__ table, int W, int nwin,
                                                                         const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
                                                                         const uint8_t* __restrict__ sg, const uint8_t* __restrict__ msg, size_t n,
@@ -329,6 +346,7 @@ __global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_eddsa_verify_small(const u
     if (vneg && !limbs_is_zero(c)) { Fr t = c_K.L; limbs_submul(t, 1u, c); c = t; }
     fr_to_words(c, cw);
   }
+  qfb_prefetch(table, W, nwin, cw);
   // P1 = -8A, P2 = -sign(v) R on the a' = -1 curve, one coordinate per lane; their tables
   {
     const Fr X = fr_mul(fr_neg(ax), c_K.F);
@@ -394,12 +412,84 @@ __global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_eddsa_verify_small(const u
   if (live && !need_exact && gl == 0) ok[i] = (uint8_t)(msg_gt ? 0 : verdict);
 }
 
+// =====================================================================================================================================
+// PrivateKey::sign (src/lib.rs:308-342) for SHORT calls: eight lanes per signature.  sign_item (sign.hpp) as it is -- the two Blake-512 digests, r, the two
+// fixed-base multiplications, one inversion -- on every lane of the group for itself, and the Poseidon hash, two thirds of the lane form's time, on six of them
+// (p5c_permute).  Same field elements, same outputs; the constant-time signer option keeps its own kernels.  C64: Signature::compress (k_sign.hip).
+// =====================================================================================================================================
+template <bool C64>
+__device__ __forceinline__ void sign_small_body(const u32* __restrict__ table, int W, int nwin, const uint8_t* __restrict__ keys,
+                                                const uint8_t* __restrict__ msgs, size_t n, uint8_t* __restrict__ out_r, uint8_t* __restrict__ out_s,
+                                                uint8_t* __restrict__ ok) {
+  const int lane = threadIdx.x, gl = lane & 7;
+  const int j = gl < 6 ? gl : 5;
+  const size_t item = (size_t)blockIdx.x * (BJJ_VS_BLOCK / 8) + (size_t)(lane >> 3);
+  const bool live = item < n;
+  const size_t i = live ? item : n - 1;
+  u32 key[8], msg[8];
+  load_w8(keys + i * 32, key); load_w8(msgs + i * 32, msg);
+  const bool good = !words_gt_modulus(msg);                      // :309-311
+  u32 sk[8], pruned[8], buf[16], dig[16];
+  scalar_key_words(key, sk, pruned, buf);                        // :316
+#pragma unroll
+  for (int k = 0; k < 8; k++) buf[8 + k] = msg[k];               // :318-325
+  blake512_words(buf, 16, dig);                                  // :326
+  const Fr r = fl_canon4(fr_add(fl_mul(limbs_from_bits(dig, 16, 0), c_K.L_R1, c_K), fl_mul(limbs_from_bits(dig, 16, 261), c_K.L_R2, c_K)), c_K);   // :327-328
+  u32 rw[8];
+  fr_to_words(r, rw);
+  const GatherPerLane fb = {table};
+  {
+    u32 rl[8], sl[8];
+    scalar_mod_l(rw, rl, c_K); scalar_mod_l(sk, sl, c_K);        // (what fixed_base_mul reduces its scalar to)
+    qfb_prefetch(table, W, nwin, rl); qfb_prefetch(table, W, nwin, sl);
+  }
+  const Ext Rp = fixed_base_mul(fb, W, nwin, rw, c_K);           // :329
+  const Ext Ap = fixed_base_mul(fb, W, nwin, sk, c_K);           // :330
+  const Fr zi = fr_inv(fr_mul(Rp.Z, Ap.Z));
+  const Fr zr = fr_mul(zi, Ap.Z), za = fr_mul(zi, Rp.Z);
+  const Fr h0 = fr_mul(fr_mul(Rp.X, zr), c_K.FINV), h1 = fr_mul(Rp.Y, zr);
+  const Fr h2 = fr_mul(fr_mul(Ap.X, za), c_K.FINV), h3 = fr_mul(Ap.Y, za);
+  const Fr h4 = fr_to_mont_words(msg);                           // :321
+  const Fr st0 = fr_select(j == 0, fr_zero(), fr_select(j == 1, h0, fr_select(j == 2, h1, fr_select(j == 3, h2, fr_select(j == 4, h3, h4)))));
+  const Fr hm = grp_get(p5c_permute(j, gl, st0), 0);             // :332-333
+  const Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));      // :336
+  const Fr t = fl_mul(fr_from_words(pruned), c_K.L_R2, c_K);
+  const Fr s = fl_canon4(fr_add(fl_mul(hm_plain, t, c_K), r), c_K);   // :335-339
+  if (live && gl == 0) {
+    u32 rx[8], ry[8], sw[8];
+    fr_from_mont_words(h0, rx); fr_from_mont_words(h1, ry);
+    fr_to_words(s, sw);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { rx[k] = good ? rx[k] : 0u; ry[k] = good ? ry[k] : 0u; sw[k] = good ? sw[k] : 0u; }
+    if constexpr (C64) {
+      u32 c[8];
+      compress_item(rx, ry, c, c_K);
+      store_w8(out_r + i * 64, c); store_w8(out_r + i * 64 + 32, sw);
+    } else {
+      store_w8(out_r + i * 64, rx); store_w8(out_r + i * 64 + 32, ry); store_w8(out_s + i * 32, sw);
+    }
+    ok[i] = good ? 1 : 0;
+  }
+}
+#define SIGN_SMALL_ARGS const u32* __restrict__ table, int W, int nwin, const uint8_t* __restrict__ keys, const uint8_t* __restrict__ msgs, \
+                        size_t n, uint8_t* __restrict__ out_r, uint8_t* __restrict__ out_s, uint8_t* __restrict__ ok
+__global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_sign_small(SIGN_SMALL_ARGS) { sign_small_body<false>(table, W, nwin, keys, msgs, n, out_r, out_s, ok); }
+__global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_sign_small_c64(SIGN_SMALL_ARGS) { sign_small_body<true>(table, W, nwin, keys, msgs, n, out_r, out_s, ok); }
+
 namespace bjjk {
 // the bulk of a short verify call; the scan (before) and the exact launch (behind) are K4's (k_verify.hip)
 hipError_t verify_small(hipStream_t st, const u32* table, int W, int nwin, const uint8_t* pk, const uint8_t* rb8, const uint8_t* s, const uint8_t* msg,
                         size_t n, uint8_t* ok) {
   const size_t per = BJJ_VS_BLOCK / 8, grid = (n + per - 1) / per;
   BJJ_LAUNCH(bjj_k_eddsa_verify_small, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok);
+  return hipGetLastError();
+}
+// out_s == nullptr: the compressed form (out_r = 64-byte Signature::compress records), as bjjk::sign
+hipError_t sign_small(hipStream_t st, const u32* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_r, uint8_t* out_s,
+                      uint8_t* ok) {
+  const size_t per = BJJ_VS_BLOCK / 8, grid = (n + per - 1) / per;
+  if (out_s) BJJ_LAUNCH(bjj_k_sign_small, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
+  else BJJ_LAUNCH(bjj_k_sign_small_c64, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, keys, msgs, n, out_r, out_s, ok);
   return hipGetLastError();
 }
 hipError_t poseidon5_coop(hipStream_t st, const uint8_t* in, size_t n, uint8_t* out) {

@@ -331,6 +331,7 @@ typedef struct {
   uint32_t last_host_zero_copy; /* last host-pointer call, bit 0: the kernels stored their results into the (pinned) output array themselves, no copy-out stage;
                                    bit 1: the kernels read the (pinned) input arrays themselves, no copy-in stage */
   int last_poseidon_form;      /* 0 = one hash per lane, 1 = six lanes per hash (short calls) */
+  int last_sign_form;          /* bjj_sign / bjj_sign_compressed: 0 = one signature per lane, 1 = eight lanes per signature (short calls) */
 } bjj_info;
 int bjj_get_info(bjj_ctx* ctx, bjj_info* info);
 

@@ -42,6 +42,7 @@ pub struct BjjInfo {
     pub last_var_base_split: c_int,
     pub last_host_zero_copy: u32,
     pub last_poseidon_form: c_int,
+    pub last_sign_form: c_int,
 }
 
 pub const BJJ_OK: c_int = 0;

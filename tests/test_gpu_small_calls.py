@@ -241,3 +241,53 @@ def test_verify_short_calls_every_verdict_against_the_lane_kernel_and_the_oracle
             assert ctx.eddsa_verify(A[k:k + 1], R[k:k + 1], S[k:k + 1], msg[k:k + 1])[0] == want[k], k
     finally:
         ctx.close(); k4.close()
+
+
+# ------------------------------------------------------------------------------------------------ sign, eight lanes per signature
+SIGN_SMALL_MAX = 1 << 13
+
+
+def test_sign_short_calls_against_the_lane_kernel_and_the_oracle(oracle, monkeypatch, golden):
+    """PrivateKey::sign / Signature::compress (src/lib.rs:308-342, 245-258) in short calls: every call size around the group / wave / switch-over boundaries,
+    msg > Q (the reference's Err: ok = 0, zeroed records), both output forms -- byte for byte what the lane kernel and the oracle give; the signatures verify"""
+    import babyjubjub_rs_amd as bjj
+    ctx = bjj.Context(0, 16)
+    monkeypatch.setenv("BJJ_SIGN_SMALL_MAX", "0")
+    lane = bjj.Context(0, 16)
+    monkeypatch.delenv("BJJ_SIGN_SMALL_MAX")
+    try:
+        nmax = SIGN_SMALL_MAX + 21
+        rng = np.random.default_rng(0x5199)
+        keys = rng.integers(0, 256, (nmax, 32), dtype=np.uint8)
+        msgs = rng.integers(0, 256, (nmax, 32), dtype=np.uint8)
+        msgs[:, 31] &= 0x1f
+        msgs[::97, 31] = 0xff                                   # msg > Q
+        msgs[5] = 0
+        keys[6] = 0
+        r0, s0, ok0 = lane.sign(keys, msgs)
+        assert lane.info().last_sign_form == 0
+        sig0, okc0 = lane.sign_compressed(keys, msgs)
+        ro, so, oko = oracle.sign(keys[:600], msgs[:600])
+        assert (ok0[:600] == oko).all() and (r0[:600][oko == 1] == ro[oko == 1]).all() and (s0[:600][oko == 1] == so[oko == 1]).all()
+        for n in (1, 2, 7, 8, 9, 63, 64, 65, 1000, SIGN_SMALL_MAX - 1, SIGN_SMALL_MAX, SIGN_SMALL_MAX + 1, nmax):
+            r, s, ok = ctx.sign(keys[:n], msgs[:n])
+            assert ctx.info().last_sign_form == (1 if n <= SIGN_SMALL_MAX else 0), n
+            assert (ok == ok0[:n]).all() and (r == r0[:n]).all() and (s == s0[:n]).all(), n
+            sig, okc = ctx.sign_compressed(keys[:n], msgs[:n])
+            assert ctx.info().last_sign_form == (1 if n <= SIGN_SMALL_MAX else 0)
+            assert (okc == okc0[:n]).all() and (sig == sig0[:n]).all(), n
+        assert (ok0[::97] == 0).all() and (r0[::97] == 0).all() and (s0[::97] == 0).all()
+        good = ok0[:2000] == 1
+        pk = ctx.public_keys(keys[:2000])
+        r, s, ok = ctx.sign(keys[:2000], msgs[:2000])
+        assert (ctx.eddsa_verify(pk[good], r[good], s[good], msgs[:2000][good]) == 1).all()
+        # the circomlib vector of the reference's own test (src/lib.rs:692-738) through a one-signature call
+        from conftest import ints
+        k = golden["reference_kats"]["circomlib_testvector"]
+        key = np.frombuffer(bytes.fromhex(k["key"]), np.uint8).reshape(1, 32)
+        r1, s1, ok1 = ctx.sign(key, pack([ints(k["msg"])]).reshape(1, 32))
+        assert ctx.info().last_sign_form == 1 and ok1[0] == 1
+        assert bytes(r1[0]) == ints(k["r_b8"][0]).to_bytes(32, "little") + ints(k["r_b8"][1]).to_bytes(32, "little")
+        assert bytes(s1[0]) == ints(k["s"]).to_bytes(32, "little")
+    finally:
+        ctx.close(); lane.close()

@@ -42,6 +42,18 @@ for n in (1, 8, 64, 512, 2048, 4096, 8192, 16384, 32768):
     ts.sort()
     assert (np.asarray(ov[:n]) == 1).all()
     print("%%6d: %%7.1f (%%7.1f) form %%d" %% (n, ts[len(ts) // 2] * 1e6, ts[0] * 1e6, ctx.info().last_verify_dispatch))
+print("# bjj_sign")
+hk, hm_, hr, hs, hok = ctx.host_empty(NV * 32), ctx.host_empty(NV * 32), ctx.host_empty(NV * 64), ctx.host_empty(NV * 32), ctx.host_empty(NV)
+hk[:] = np.random.default_rng(6).integers(0, 256, NV * 32, dtype=np.uint8); hm_[:] = np.ascontiguousarray(M).reshape(-1)
+for n in (1, 8, 64, 512, 2048, 4096, 8192, 16384):
+    f = lambda: ctx._ck(ctx.lib.bjj_sign(ctx.handle, hk.ctypes.data, hm_.ctypes.data, C.c_size_t(n), hr.ctypes.data, hs.ctypes.data, hok.ctypes.data), "s")
+    t0 = time.perf_counter(); f()
+    while time.perf_counter() - t0 < 0.2: f()
+    ts = []
+    for _ in range(15):
+        t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
+    ts.sort()
+    print("%%6d: %%7.1f (%%7.1f) form %%d" %% (n, ts[len(ts) // 2] * 1e6, ts[0] * 1e6, ctx.info().last_sign_form))
 print("# bjj_poseidon5")
 h5 = ctx.host_empty(N * 160); h5[:] = np.random.default_rng(5).integers(0, 32, N * 160, dtype=np.uint8); o5 = ctx.host_empty(N * 32)
 for n in (1, 8, 64, 512, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
@@ -57,5 +69,5 @@ for n in (1, 8, 64, 512, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
 W = sys.argv[1] if len(sys.argv) > 1 else "23"
 for qmax in ("0", "1048576"):
     print("# BJJ_VB_QUAD_MAX = BJJ_P5_COOP_MAX = BJJ_VERIFY_SMALL_MAX = %s: microseconds per call, median (min)" % qmax, flush=True)
-    r = subprocess.run([sys.executable, "-c", CHILD, W], env=dict(os.environ, BJJ_VB_QUAD_MAX=qmax, BJJ_P5_COOP_MAX=qmax, BJJ_VERIFY_SMALL_MAX=qmax), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    r = subprocess.run([sys.executable, "-c", CHILD, W], env=dict(os.environ, BJJ_VB_QUAD_MAX=qmax, BJJ_P5_COOP_MAX=qmax, BJJ_VERIFY_SMALL_MAX=qmax, BJJ_SIGN_SMALL_MAX=qmax), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     print(r.stdout.rstrip() or r.stderr[-800:], flush=True)
