@@ -200,6 +200,7 @@ struct bjj_ctx {
   bool force_staged = false;               // BJJ_HOST_FORCE_STAGED=1: treat every host array as pageable (A/B, tests)
   // what the last calls did (bjj_get_info; tests and the bench line read these)
   int last_k1 = -1, last_k2 = -1, last_verify_mode = -1;
+  size_t fb_quad_max = (size_t)1 << 15;        // fixed base / public keys: calls of at most this many items run four lanes per item (BJJ_FB_QUAD_MAX; 0 = never)
   size_t sign_small_max = (size_t)1 << 13;     // sign: calls of at most this many signatures run eight lanes per signature (BJJ_SIGN_SMALL_MAX; 0 = never)
   int last_sign = -1;
   size_t verify_small_max = (size_t)1 << 13;   // EdDSA verify: calls of at most this many signatures run eight lanes per signature (BJJ_VERIFY_SMALL_MAX; 0 = never)
@@ -1080,6 +1081,10 @@ int bjj_init(int device, int window_bits, bjj_ctx** out_ctx) {
   if (const char* e = getenv("BJJ_K2_VARIANT")) {
     if (e[0] == '0' || e[0] == '1') c->k2_variant = e[0] - '0';
   }
+  if (const char* e = getenv("BJJ_FB_QUAD_MAX")) {  // tests / A-B
+    char* q = nullptr; const unsigned long long v = strtoull(e, &q, 0);
+    if (q != e && v <= ((unsigned long long)1 << 20)) c->fb_quad_max = (size_t)v;
+  }
   if (const char* e = getenv("BJJ_SIGN_SMALL_MAX")) {  // tests / A-B
     char* q = nullptr; const unsigned long long v = strtoull(e, &q, 0);
     if (q != e && v <= ((unsigned long long)1 << 20)) c->sign_small_max = (size_t)v;
@@ -1358,6 +1363,12 @@ static int fixed_base_launch(bjj_ctx* c, const void* d_scalars, size_t n, void* 
   CHECK_N(n);
   if (!d_scalars || !d_out || !aligned16(d_scalars) || !aligned16(d_out))
     return set_err(BJJ_E_INVALID, std::string(who) + ": NULL or not 16-byte aligned device pointer");
+  if (n <= c->fb_quad_max && c->k1_variant < 0) {   // short calls (a single B8.mul_scalar is one): four lanes per item, no scratch (k_small.hip)
+    DEV_ENTER(c, stream);
+    c->last_k1 = 2;
+    LAUNCHCK_S(bjjk::mul_fixed_base_quad(st, c->table, c->W, c->nwin, (const uint8_t*)d_scalars, n, (uint8_t*)d_out, compressed), who);
+    DEV_LEAVE(c);
+  }
   SET_ENTER(c, stream, n, false);
   if (compressed) { int rc_ = ensure_xy(c, S, n); if (rc_) return rc_; }
   const int kv = fixed_base_variant(c, S);
@@ -1927,6 +1938,9 @@ static int public_keys_launch(bjj_ctx* c, const void* d_keys, size_t n, void* d_
   if (c->ct_signer) {
     LAUNCHCK(bjjk::mul_fixed_base_scan(st, c->cus, c->ct_table, BJJ_CT_W, fixed_nwin(BJJ_CT_W), S->codec, n, (uint8_t*)d_out_xy, S->scratch, xy),
              "mul_fixed_base_scan");
+  } else if (n <= c->fb_quad_max && c->k1_variant < 0) {   // short calls: four lanes per key (k_small.hip)
+    c->last_k1 = 2;
+    LAUNCHCK(bjjk::mul_fixed_base_quad(st, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy, compressed), "mul_fixed_base (short call)");
   } else {
     const int kv = fixed_base_variant(c, S);
     LAUNCHCK(bjjk::mul_fixed_base(st, c->cus, fixed_base_lanes(c, kv), kv, c->table, c->W, c->nwin, S->codec, n, (uint8_t*)d_out_xy,

@@ -64,6 +64,7 @@ int occ_var_base_scan();
 // ... Poseidon with six lanes per hash, and the bulk of verify with eight lanes per signature (scan and exact launch: k_verify.hip)
 hipError_t verify_small(hipStream_t st, const uint32_t* table, int W, int nwin, const uint8_t* pk, const uint8_t* rb8, const uint8_t* s, const uint8_t* msg,
                         size_t n, uint8_t* ok);
+hipError_t mul_fixed_base_quad(hipStream_t st, const uint32_t* table, int W, int nwin, const uint8_t* scalars, size_t n, uint8_t* out, bool compressed);   // B8.mul_scalar, four lanes per item
 hipError_t sign_small(hipStream_t st, const uint32_t* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_r, uint8_t* out_s,
                       uint8_t* ok);   // PrivateKey::sign, eight lanes per signature (out_s == nullptr: compressed records)
 hipError_t poseidon5_coop(hipStream_t st, const uint8_t* in, size_t n, uint8_t* out);

@@ -476,12 +476,78 @@ __device__ __forceinline__ void sign_small_body(const u32* __restrict__ table, i
 __global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_sign_small(SIGN_SMALL_ARGS) { sign_small_body<false>(table, W, nwin, keys, msgs, n, out_r, out_s, ok); }
 __global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_sign_small_c64(SIGN_SMALL_ARGS) { sign_small_body<true>(table, W, nwin, keys, msgs, n, out_r, out_s, ok); }
 
+// =====================================================================================================================================
+// B8.mul_scalar(n) / PrivateKey::public (src/lib.rs:149-164, 304-306) for SHORT calls: four lanes per item.  fixed_base_mul (bjj_device.hpp) with the accumulator on a
+// quad: window 0's entry lifted to a point, one quad addition per further window (each table entry read one component per lane, all of them touched up front), then the
+// affine conversion of THIS item alone -- no workgroup-wide inversion, no stash -- and, with COMPRESS, Point::compress (src/lib.rs:166-178) of it.
+// =====================================================================================================================================
+template <bool COMPRESS>
+__device__ __forceinline__ void fixed_base_quad_body(const u32* __restrict__ table, int W, int nwin, const uint8_t* __restrict__ scalars, size_t n,
+                                                     uint8_t* __restrict__ out) {
+  constexpr u32 R1[NL] = {BJJ_N0, BJJ_N1, BJJ_N2, BJJ_N3, BJJ_N4, BJJ_N5, BJJ_N6, BJJ_N7, BJJ_N8};
+  const int lane = threadIdx.x, q = lane & 3;
+  const size_t item = (size_t)blockIdx.x * BJJ_QUAD_ITEMS + (size_t)(lane >> 2);
+  const bool live = item < n;
+  const size_t i = live ? item : n - 1;
+  u32 raw[8], sc[8], w[8];
+  load_w8(scalars + i * 32, raw);
+  scalar_mod_l(raw, sc, c_K);
+  qfb_prefetch(table, W, nwin, sc);
+  DigitStream ds = digit_stream(sc, W);
+  bool neg;
+  size_t slot = digit_next(ds, neg);
+  Fr c;
+  {  // window 0 is stored in T form: (2x' : 2y : 2 : 2x'y) costs no multiplication (fixed_base_mul)
+    const Fr e0 = qfb_load(table, slot, neg, q);
+    const Fr ymx = quad_bcast<0>(e0), ypx = quad_bcast<1>(e0);
+    c = fr_select(q == 0, fr_reduce_weak(fr_sub(ypx, ymx)), fr_select(q == 1, fr_add(ypx, ymx), fr_select(q == 2, fr_add(fr_one(), fr_one()), fr_add(e0, fr_zero()))));
+  }
+  slot = digit_next(ds, neg);
+  Fr cur = qfb_load(table, slot, neg, q);
+#pragma unroll 1
+  for (int k = 1; k + 1 < nwin; k++) {
+    slot = digit_next(ds, neg);
+    const Fr nxt = qfb_load(table, slot, neg, q);
+    c = quad_add(q, c, cur);
+    cur = nxt;
+  }
+  c = quad_add(q, c, cur);
+  const Fr zi = fr_mul(fr_inv(quad_bcast<2>(c)), fr_one_plain());
+  const Fr m = fr_select(q == 0, fr_mul(zi, c_K.FINV), zi);
+  const Fr v = fr_cond_sub_kr(fr_mul(c, m), R1);                     // lane 0: x, lane 1: y, canonical
+  if (COMPRESS) {
+    const int big = __builtin_amdgcn_mov_dpp((int)plain_gt_halfq(v, c_K), 0x00, 0xf, 0xf, true);   // lane 0's x > (Q - 1) / 2, on the quad
+    if (live && q == 1) {
+      fr_to_words(v, w);
+      if (big) w[7] |= 0x80000000u;
+      store_w8(out + i * 32, w);
+    }
+  } else if (live && q < 2) {
+    fr_to_words(v, w);
+    store_w8(out + i * 64 + (size_t)q * 32, w);
+  }
+}
+__global__ void __launch_bounds__(BJJ_QUAD_BLOCK) bjj_k_mul_fixed_base_quad(const u32* __restrict__ table, int W, int nwin, const uint8_t* __restrict__ scalars,
+                                                                        size_t n, uint8_t* __restrict__ out) {
+  fixed_base_quad_body<false>(table, W, nwin, scalars, n, out);
+}
+__global__ void __launch_bounds__(BJJ_QUAD_BLOCK) bjj_k_mul_fixed_base_quad_c32(const u32* __restrict__ table, int W, int nwin, const uint8_t* __restrict__ scalars,
+                                                                            size_t n, uint8_t* __restrict__ out32) {
+  fixed_base_quad_body<true>(table, W, nwin, scalars, n, out32);
+}
+
 namespace bjjk {
 // the bulk of a short verify call; the scan (before) and the exact launch (behind) are K4's (k_verify.hip)
 hipError_t verify_small(hipStream_t st, const u32* table, int W, int nwin, const uint8_t* pk, const uint8_t* rb8, const uint8_t* s, const uint8_t* msg,
                         size_t n, uint8_t* ok) {
   const size_t per = BJJ_VS_BLOCK / 8, grid = (n + per - 1) / per;
   BJJ_LAUNCH(bjj_k_eddsa_verify_small, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok);
+  return hipGetLastError();
+}
+hipError_t mul_fixed_base_quad(hipStream_t st, const u32* table, int W, int nwin, const uint8_t* scalars, size_t n, uint8_t* out, bool compressed) {
+  const size_t grid = (n + BJJ_QUAD_ITEMS - 1) / BJJ_QUAD_ITEMS;
+  if (compressed) BJJ_LAUNCH(bjj_k_mul_fixed_base_quad_c32, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_QUAD_BLOCK), 0, st, table, W, nwin, scalars, n, out);
+  else BJJ_LAUNCH(bjj_k_mul_fixed_base_quad, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_QUAD_BLOCK), 0, st, table, W, nwin, scalars, n, out);
   return hipGetLastError();
 }
 // out_s == nullptr: the compressed form (out_r = 64-byte Signature::compress records), as bjjk::sign

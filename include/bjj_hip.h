@@ -110,10 +110,11 @@
  * The verifiers on host pointers run the items whose pk or R is off the curve (the reference's exact formula sequence, ~3x as
  * long) as ONE launch for the whole call beside the chunks' launches, and their verdicts leave the device once, at the end:
  * 2^20 signatures of which 1 in 128 is off the curve take about 19 ms pinned, 18.2 ms as one device-pointer launch.
- * Short calls -- at most 2^14 variable-base multiplications (32-byte scalars) or Poseidon hashes, 2^13 EdDSA verifications -- run kernels that
- * spread one item over four / six / eight lanes (csrc/k_small.hip): identical results, 0.50 / 0.22 / 0.58 ms per call instead of 1.2 / 0.55 / 1.45
+ * Short calls -- at most 2^15 fixed-base multiplications or public keys, 2^14 variable-base multiplications (32-byte scalars) or Poseidon hashes, 2^13 EdDSA
+ * verifications -- run kernels that spread one item over four / six / eight lanes (csrc/k_small.hip): identical results, 0.10 / 0.50 / 0.22 / 0.59 ms per call instead of
+ * 0.13 / 1.2 / 0.55 / 1.45
  * (a single Point::mul_scalar, POSEIDON.hash or verify of the reference is such a call); bjj_sign / bjj_sign_compressed of at most 2^13 signatures likewise
- * (0.38 ms per call instead of 0.7).  BJJ_VB_QUAD_MAX, BJJ_P5_COOP_MAX, BJJ_VERIFY_SMALL_MAX, BJJ_SIGN_SMALL_MAX (items, read at bjj_init; 0 = never) move the
+ * (0.38 ms per call instead of 0.7).  BJJ_FB_QUAD_MAX, BJJ_VB_QUAD_MAX, BJJ_P5_COOP_MAX, BJJ_VERIFY_SMALL_MAX, BJJ_SIGN_SMALL_MAX (items, read at bjj_init; 0 = never) move the
  * switch-overs.
  * More environment knobs (read when the context first runs a host-pointer call): BJJ_PIPE_CHUNK / BJJ_PIPE_FIRST_CHUNK
  * (items per pipeline chunk: the first chunk, doubling up to the cap; defaults 32768 / 131072 -- 65536 / 131072 (262144 beyond 1.5 M items) for the compressed fixed-base and key forms, whose chunk launches take one workgroup slot per CU each --, for the verifiers 65536 /
@@ -318,7 +319,7 @@ typedef struct {
   double init_ms;           /* wall time of bjj_init (allocation + table build on the GPU) */
   int signer_constant_time; /* bjj_set_signer_constant_time: 1 = the signer entry points scan a small table (see there) */
   /* since 0.5.0 -- what the context's LAST calls did (-1 = no such call yet); for tests, profiles and the bench line */
-  int last_fixed_base_shape;   /* 0 = one 512-lane workgroup per CU (a launch that runs alone), 1 = two of 256 (overlapping launches) */
+  int last_fixed_base_shape;   /* 0 = one 512-lane workgroup per CU (a launch that runs alone), 1 = two of 256 (overlapping launches), 2 = four lanes per item (short calls, since 0.6.0) */
   int last_var_base_form;      /* 1 = tiles (alone), 0 = grid-strided (overlapping), 2 = four lanes per item (short calls, since 0.6.0) */
   int last_verify_dispatch;    /* 0 = persistent waves (one launch > 2^21 items that runs alone), 1 = one group per workgroup, 2 = eight lanes per signature (short calls, since 0.6.0) */
   uint32_t last_host_direct_arrays;  /* last host-pointer call: arrays copied straight from / to pinned caller memory ... */

@@ -291,3 +291,42 @@ def test_sign_short_calls_against_the_lane_kernel_and_the_oracle(oracle, monkeyp
         assert bytes(s1[0]) == ints(k["s"]).to_bytes(32, "little")
     finally:
         ctx.close(); lane.close()
+
+
+# ------------------------------------------------------------------------------------------------ fixed base / public keys, four lanes per item
+FB_QUAD_MAX = 1 << 15
+
+
+@pytest.mark.parametrize("window_bits", [16, 23, 13, 8])
+def test_fixed_base_and_public_keys_short_calls(oracle, monkeypatch, window_bits, golden):
+    """B8.mul_scalar(n) / PrivateKey::public (src/lib.rs:149-164, 304-306) and their Point::compress forms in short calls: every call size around the quad / wave /
+    switch-over boundaries, scalars 0, 1, l - 1, l, l + 1, 2^256 - 1, four table widths -- byte for byte what K1 and the oracle give"""
+    import babyjubjub_rs_amd as bjj
+    from babyjubjub_rs_amd import workload as w
+    ctx = bjj.Context(0, window_bits)
+    monkeypatch.setenv("BJJ_FB_QUAD_MAX", "0")
+    k1 = bjj.Context(0, window_bits)
+    monkeypatch.delenv("BJJ_FB_QUAD_MAX")
+    try:
+        nmax = FB_QUAD_MAX + 19
+        sc = w.random_u256(w.SEED_SCALARS, nmax, offset=31)
+        for k, v in enumerate([0, 1, 2, L - 1, L, L + 1, 8 * L, (1 << 256) - 1, 1 << 255, Q - 1]):
+            sc[k] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+        keys = w.random_u256(w.SEED_KEYS, nmax, offset=5)
+        want, want_pk = k1.mul_fixed_base(sc), k1.public_keys(keys)
+        assert k1.info().last_fixed_base_shape in (0, 1)
+        want_c, want_pkc = k1.compress_points(want), k1.compress_points(want_pk)
+        assert (want[:300] == oracle.mul_fixed_base(sc[:300])).all() and (want_pk[:300] == oracle.public_keys(keys[:300])).all()
+        for n in (1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 1000, FB_QUAD_MAX - 1, FB_QUAD_MAX, FB_QUAD_MAX + 1, nmax):
+            form = 2 if n <= FB_QUAD_MAX else None
+            for got, exp in ((ctx.mul_fixed_base(sc[:n]), want), (ctx.mul_fixed_base_compressed(sc[:n]), want_c),
+                             (ctx.public_keys(keys[:n]), want_pk), (ctx.public_keys_compressed(keys[:n]), want_pkc)):
+                f = ctx.info().last_fixed_base_shape
+                assert (f == 2) == (form == 2), (n, f)
+                assert (got == exp[:n]).all(), (n, np.nonzero((got != exp[:n]).any(axis=1))[0][:8])
+        from conftest import ints
+        k = golden["reference_kats"]["circomlib_testvector"]
+        key = np.frombuffer(bytes.fromhex(k["key"]), np.uint8).reshape(1, 32)
+        assert bytes(ctx.public_keys(key)[0]) == ints(k["pk"][0]).to_bytes(32, "little") + ints(k["pk"][1]).to_bytes(32, "little")
+    finally:
+        ctx.close(); k1.close()
