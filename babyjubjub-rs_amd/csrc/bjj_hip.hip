@@ -191,6 +191,7 @@ struct bjj_ctx {
   size_t pipe_chunk = 0, pipe_first = 0;   // chunk schedule (items): first chunk, doubling up to pipe_chunk
   bool pipe_env_schedule = false;          // ... given in the environment: it overrides the entry points' own schedules too
   bool pipe_ready = false;                 // ensure_pipe's first-use block ran to its end
+  bool pipe_small_direct = true;           // BJJ_PIPE_SMALL_DIRECT=0: short calls on pinned memory keep their copies (A/B, tests)
   bool pipe_zero_copy_in = true;           // BJJ_PIPE_ZERO_COPY_IN=0: inputs always arrive through the copy engines (A/B, tests)
   bool k1_half_now = false;                // a host-pointer call is enqueueing chunk launches of K1 that take ONE workgroup slot per CU each
   bool pipe_zero_copy = true;              // BJJ_PIPE_ZERO_COPY=0: results always leave through the copy engines (A/B, tests)
@@ -498,6 +499,11 @@ struct PipeSpec {
   // pacing of the copies, and the fixed part of one is covered by the main loop of the other -- as on two caller streams
   // (profiles/r03_ab_k1_2x256_two_streams.txt).  Calls of >= 2 chunks only (profiles/r06_fb_host_half_slots.txt).
   bool k1_half = false;
+  // Short calls (a call of ONE item is the reference's single-item API): with at most this many items, one chunk and every array pinned and 16-byte aligned,
+  // the kernels read the inputs AND store the results through the arrays' device mappings -- no copy, no event hop, the host does not come back between
+  // the kernel and a copy-out: launch and synchronise (20-30 us of a 100-600 us call).  Only for entry points whose short calls run kernels that write every
+  // output byte once and read none of it back (csrc/k_small.hip).  0 = never.
+  size_t small_direct_max = 0;
 };
 // Work of a pipelined call that does not belong to ONE chunk.  All three run on the calling thread while it enqueues:
 //   begin          once per super-batch, before the first copy; d_in / d_out = the staging arrays of the whole super-batch
@@ -620,6 +626,7 @@ static int ensure_pipe(bjj_ctx* c, size_t chunks, size_t dev_bytes, size_t in_ri
     if (const char* e = getenv("BJJ_PIPE_SCAN")) c->pipe_scan_inline = e[0] != 'p';
     if (const char* e = getenv("BJJ_PIPE_ZERO_COPY")) c->pipe_zero_copy = e[0] != '0';
     if (const char* e = getenv("BJJ_PIPE_ZERO_COPY_IN")) c->pipe_zero_copy_in = e[0] != '0';
+    if (const char* e = getenv("BJJ_PIPE_SMALL_DIRECT")) c->pipe_small_direct = e[0] != '0';
     { int rc = ensure_pipe_streams(c); if (rc) return rc; }
     c->pipe_ready = true;
   }
@@ -735,7 +742,8 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
   const bool chunk_out_ring = out_ring && !sp.out_at_end;   // pageable outputs travel chunk by chunk through the ring
   // zero-copy outputs: every output array pinned AND mapped into the device's address space
   uint8_t* mapped_out[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool zc = sp.zero_copy_out && !out_ring && sp.n_out > 0 && !sp.out_at_end && c->pipe_zero_copy;
+  const bool small_direct = sp.small_direct_max && n <= sp.small_direct_max && nchunks == 1 && !sp.extra && c->pipe_small_direct;
+  bool zc = (sp.zero_copy_out || small_direct) && !out_ring && sp.n_out > 0 && !sp.out_at_end && c->pipe_zero_copy;
   for (int i = 0; i < sp.n_out && zc; i++) {
     void* dp = nullptr;
     if (!out_direct[i] || ((uintptr_t)sp.out[i] & 15u) || hipHostGetDevicePointer(&dp, sp.out[i], 0) != hipSuccess || !dp) { (void)hipGetLastError(); zc = false; }   // (the kernels move 16-byte words)
@@ -744,13 +752,14 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
   uint8_t* mapped_in[4] = {nullptr, nullptr, nullptr, nullptr};
   // Calls of one or two chunks: every chunk.  Longer calls: the FIRST chunk only -- the head of the chain of launches starts at once instead
   // of behind its copy, and the copy-in of the chunks behind it, which keeps the two lanes' launches out of phase, starts earlier too.
-  bool zi = sp.zero_copy_in && !in_ring && sp.n_in > 0 && !sp.extra && c->pipe_zero_copy_in;
+  bool zi = (sp.zero_copy_in || small_direct) && !in_ring && sp.n_in > 0 && !sp.extra && c->pipe_zero_copy_in;
   for (int i = 0; i < sp.n_in && zi; i++) {
     void* dp = nullptr;
     if (!in_direct[i] || ((uintptr_t)sp.in[i] & 15u) || hipHostGetDevicePointer(&dp, (void*)sp.in[i], 0) != hipSuccess || !dp) { (void)hipGetLastError(); zi = false; }   // (the kernels move 16-byte words)
     mapped_in[i] = (uint8_t*)dp;
   }
   static const int zi_first_env = [] { const char* e = getenv("BJJ_PIPE_ZERO_COPY_IN_FIRST"); return e ? atoi(e) : 1; }();   // developer A/B: leading chunks of a long call that read in place
+  if (small_direct && !(zi && zc)) { zi = zi && sp.zero_copy_in; zc = zc && sp.zero_copy_out; }   // both directions or the entry point's own rule
   const size_t zi_chunks = !zi ? 0 : (nchunks <= 2 ? nchunks : (size_t)zi_first_env);
   c->last_host_zero_copy = (zc ? 1u : 0u) | (zi_chunks == nchunks ? 2u : 0u);
   c->k1_half_now = sp.k1_half && nchunks >= 2;
@@ -930,6 +939,8 @@ static int run_super_batch_body(bjj_ctx* c, size_t n, const PipeSpec& sp, const 
   (void)n_staged;
   return rc;
 }
+// Short calls on pinned memory without copies (PipeSpec::small_direct_max): as long as the entry point's short-call kernel is the one that runs
+static size_t small_direct_items(size_t kernel_max) { return kernel_max < 256 ? kernel_max : 256; }
 template <typename Launch>
 static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch) {
   ENTER_DEVICE(c->device);
@@ -958,8 +969,8 @@ static int run_pipelined(bjj_ctx* c, size_t n, const PipeSpec& sp, Launch launch
   c->in_pipeline = false;
   c->k1_half_now = false;
   c->last_host_direct = n_direct; c->last_host_staged = n_staged; c->last_host_chunks = chunks;
-  if (!sp.zero_copy_out) c->last_host_zero_copy &= ~1u;
-  if (!sp.zero_copy_in) c->last_host_zero_copy &= ~2u;
+  if (!sp.zero_copy_out && !sp.small_direct_max) c->last_host_zero_copy &= ~1u;
+  if (!sp.zero_copy_in && !sp.small_direct_max) c->last_host_zero_copy &= ~2u;
   // the call has synchronised for the caller: a verify / variable-base workgroup that gave up waiting for a table slot makes
   // it an error here, not at some later bjj_sync.  Only the pipeline's OWN streams have been waited for: while a
   // device-pointer launch of the caller is still in flight on one of the sets, its workgroups are popping and pushing the rings --
@@ -1538,6 +1549,7 @@ struct VarBasePipe : PipeExtra {
 };
 static int var_base_host(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t scalar_bytes, size_t n, uint8_t* out) {
   PipeSpec sp = {2, 1, {pts, scalars}, {64, scalar_bytes}, {out}, {64}, false};
+  if (scalar_bytes == 32 && c->k2_variant < 0) sp.small_direct_max = small_direct_items(c->vb_quad_max);
   sp.first_chunk = (size_t)1 << 16;   // 14 ms of kernels over 3 ms of copies: a 2^15-item launch holds its lane for a whole round with a quarter of the chip
   sp.max_chunk = (size_t)1 << 18;
   static const bool per_chunk = [] { const char* e = getenv("BJJ_PIPE_VAR_BASE_SPLIT"); return e && e[0] == '0'; }();   // developer: the round-5 form
@@ -1705,6 +1717,7 @@ struct VerifyPipe : PipeExtra {
 };
 static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok) {
   PipeSpec sp = {4, 1, {pk, r, s, msg}, {64, 64, 32, 32}, {ok}, {1}, false};
+  if (!schnorr && c->verify_mode < 0) sp.small_direct_max = small_direct_items(c->verify_small_max);
   static const bool per_chunk = [] { const char* e = getenv("BJJ_PIPE_VERIFY_SPLIT"); return e && e[0] == '0'; }();   // developer: the round-5 form
   // a call of ONE chunk is a device-pointer launch with copies around it: its exact groups start first inside the launch, nothing
   // waits behind them, and three launches instead of two would only add latency (a single `verify`, src/lib.rs:395, is such a call)
@@ -2032,12 +2045,14 @@ int bjj_mul_fixed_base(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* ou
   HOST_PROLOGUE("bjj_mul_fixed_base", !scalars || !out);
   PipeSpec sp = {1, 1, {scalars}, {32}, {out}, {64}, false};
   sp.zero_copy_in = true;
+  if (c->k1_variant < 0) sp.small_direct_max = small_direct_items(c->fb_quad_max);
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_mul_fixed_base_dev(c, i[0], cnt, o[0], st); });
 }
 // 32 bytes per result across PCIe instead of 64: the copy-out is what bounds the affine form (1.19 ms of 1.58 per 2^20 items)
 int bjj_mul_fixed_base_compressed(bjj_ctx* c, const uint8_t* scalars, size_t n, uint8_t* out32) {
   HOST_PROLOGUE("bjj_mul_fixed_base_compressed", !scalars || !out32);
   PipeSpec sp = {1, 1, {scalars}, {32}, {out32}, {32}, false};
+  if (c->k1_variant < 0) sp.small_direct_max = small_direct_items(c->fb_quad_max);
   k1_chunk_schedule(&sp, n);
   static const bool zc = [] { const char* e = getenv("BJJ_FB_COMPRESSED_ZERO_COPY"); return e && e[0] == '1'; }();   // experiment (tools/fb_compressed_sweep.py)
   if (zc) { sp.zero_copy_out = true; sp.tail_chunk = 0; }
@@ -2057,6 +2072,7 @@ int bjj_mul_var_base_wide(bjj_ctx* c, const uint8_t* pts, const uint8_t* scalars
 int bjj_poseidon5(bjj_ctx* c, const uint8_t* in, size_t n, uint8_t* out) {
   HOST_PROLOGUE("bjj_poseidon5", !in || !out);
   PipeSpec sp = {1, 1, {in}, {160}, {out}, {32}, false};
+  sp.small_direct_max = small_direct_items(c->p5_coop_max);
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_poseidon5_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_eddsa_verify(bjj_ctx* c, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n,
@@ -2108,12 +2124,14 @@ int bjj_scalar_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out) {
 int bjj_public_keys(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out_xy) {
   HOST_PROLOGUE("bjj_public_keys", !keys || !out_xy);
   PipeSpec sp = {1, 1, {keys}, {32}, {out_xy}, {64}, true};
+  if (c->k1_variant < 0 && !c->ct_signer) sp.small_direct_max = small_direct_items(c->fb_quad_max);
   sp.zero_copy_in = true;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_public_keys_dev(c, i[0], cnt, o[0], st); });
 }
 int bjj_public_keys_compressed(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_t* out32) {
   HOST_PROLOGUE("bjj_public_keys_compressed", !keys || !out32);
   PipeSpec sp = {1, 1, {keys}, {32}, {out32}, {32}, true};
+  if (c->k1_variant < 0 && !c->ct_signer) sp.small_direct_max = small_direct_items(c->fb_quad_max);
   k1_chunk_schedule(&sp, n);
   sp.zero_copy_in = true;
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_public_keys_compressed_dev(c, i[0], cnt, o[0], st); });
@@ -2121,11 +2139,13 @@ int bjj_public_keys_compressed(bjj_ctx* c, const uint8_t* keys, size_t n, uint8_
 int bjj_sign_compressed(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_sig64, uint8_t* ok) {
   HOST_PROLOGUE("bjj_sign_compressed", !keys || !msgs || !out_sig64 || !ok);
   PipeSpec sp = {2, 2, {keys, msgs}, {32, 32}, {out_sig64, ok}, {64, 1}, true};
+  if (!c->ct_signer) sp.small_direct_max = small_direct_items(c->sign_small_max);
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_sign_compressed_dev(c, i[0], i[1], cnt, o[0], o[1], st); });
 }
 int bjj_sign(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_r, uint8_t* out_s, uint8_t* ok) {
   HOST_PROLOGUE("bjj_sign", !keys || !msgs || !out_r || !out_s || !ok);
   PipeSpec sp = {2, 3, {keys, msgs}, {32, 32}, {out_r, out_s, ok}, {64, 32, 1}, true};
+  if (!c->ct_signer) sp.small_direct_max = small_direct_items(c->sign_small_max);
   return run_pipelined(c, n, sp, [&](void** i, void** o, size_t cnt, void* st) { return bjj_sign_dev(c, i[0], i[1], cnt, o[0], o[1], o[2], st); });
 }
 int bjj_sign_schnorr(bjj_ctx* c, const uint8_t* keys, const uint8_t* msgs, const uint8_t* nonces, size_t n, uint8_t* out_r,

@@ -330,3 +330,72 @@ def test_fixed_base_and_public_keys_short_calls(oracle, monkeypatch, window_bits
         assert bytes(ctx.public_keys(key)[0]) == ints(k["pk"][0]).to_bytes(32, "little") + ints(k["pk"][1]).to_bytes(32, "little")
     finally:
         ctx.close(); k1.close()
+
+
+# ------------------------------------------------------------------------------------------------ short calls on pinned memory: no copies at all
+def test_short_calls_on_pinned_memory_run_without_copies(gpu_ctx, oracle):
+    """PipeSpec::small_direct_max (bjj_hip.hip): a call of at most 256 items whose arrays are all pinned and 16-byte aligned is launch + synchronise -- the short-call
+    kernels read the caller's inputs and store into the caller's outputs through the device mappings (bjj_info.last_host_zero_copy == 3).  Results as ever; a pageable
+    or misaligned array, or one item more, brings the copies back."""
+    import ctypes as C
+    from babyjubjub_rs_amd import workload as w
+    ctx = gpu_ctx
+    n = 200
+    A, R, S, M = w.make_signatures(oracle.mul_fixed_base, oracle.poseidon5, 300)
+    R[3, 2] ^= 1                                                  # one off-curve R: the exact launch stores its verdict into the host array too
+    S[5, 0] ^= 1
+    keys = w.random_u256(w.SEED_KEYS, 300, offset=9)
+    h5 = np.concatenate([A, R, M], axis=1)
+
+    def pinned(a):
+        p = ctx.host_empty(a.size)
+        p[:] = np.ascontiguousarray(a).reshape(-1)
+        return p
+
+    def call(name, ins, outs, count):
+        args = [ctx.handle] + [b.ctypes.data for b in ins] + [C.c_size_t(count)] + [b.ctypes.data for b in outs]
+        ctx._ck(getattr(ctx.lib, name)(*args), name)
+        return ctx.info().last_host_zero_copy
+
+    cases = [("bjj_mul_fixed_base", [S], [64], lambda k: [oracle.mul_fixed_base(S[:k])]),
+             ("bjj_mul_fixed_base_compressed", [S], [32], lambda k: [oracle.compress(oracle.mul_fixed_base(S[:k]))]),
+             ("bjj_mul_var_base", [A, S], [64], lambda k: [oracle.mul_var_base(A[:k], S[:k])]),
+             ("bjj_poseidon5", [h5], [32], lambda k: [oracle.poseidon5(h5[:k])]),
+             ("bjj_eddsa_verify", [A, R, S, M], [1], lambda k: [oracle.verify(A[:k], R[:k], S[:k], M[:k]).reshape(k, 1)]),
+             ("bjj_public_keys", [keys], [64], lambda k: [oracle.public_keys(keys[:k])]),
+             ("bjj_public_keys_compressed", [keys], [32], lambda k: [oracle.compress(oracle.public_keys(keys[:k]))])]
+    for name, ins, widths, expect in cases:
+        p_in = [pinned(a) for a in ins]
+        p_out = [ctx.host_empty(300 * wd + 64) for wd in widths]
+        for count, want_bits in ((1, 3), (n, 3), (256, 3), (257, None)):
+            for b in p_out:
+                b[:] = 0xEE
+            bits = call(name, p_in, p_out, count)
+            assert want_bits is None or bits == want_bits, (name, count, bits)
+            assert want_bits is not None or not (bits & 1), (name, count, bits)       # one item more: the copy-out is back
+            for b, wd, exp in zip(p_out, widths, expect(count)):
+                got = np.asarray(b[:count * wd]).reshape(count, wd)
+                assert (got == exp).all(), (name, count, np.nonzero((got != exp).any(axis=1))[0][:8])
+                assert (np.asarray(b[count * wd:count * wd + 48]) == 0xEE).all(), (name, count)
+        # a misaligned pinned input: copies (and the same bytes)
+        raw = ctx.host_empty(p_in[0].size + 16)
+        mis = raw[8:8 + p_in[0].size]
+        mis[:] = p_in[0]
+        bits = call(name, [mis] + p_in[1:], p_out, 7)
+        assert bits == 0, (name, bits)
+        for b, wd, exp in zip(p_out, widths, expect(7)):
+            assert (np.asarray(b[:7 * wd]).reshape(7, wd) == exp).all(), name
+        for b in p_in + p_out + [raw]:
+            ctx.host_free(b)
+    # sign: three outputs; the Err row stays zero
+    msgs = M.copy()
+    msgs[2, 31] = 0xff
+    p_k, p_m = pinned(keys), pinned(msgs)
+    p_r, p_s, p_ok = ctx.host_empty(300 * 64), ctx.host_empty(300 * 32), ctx.host_empty(304)
+    assert call("bjj_sign", [p_k, p_m], [p_r, p_s, p_ok], 9) == 3
+    ro, so, oko = oracle.sign(keys[:9], msgs[:9])
+    ro[oko == 0] = 0; so[oko == 0] = 0
+    assert (np.asarray(p_ok[:9]) == oko).all() and oko[2] == 0
+    assert (np.asarray(p_r[:9 * 64]).reshape(9, 64) == ro).all() and (np.asarray(p_s[:9 * 32]).reshape(9, 32) == so).all()
+    for b in (p_k, p_m, p_r, p_s, p_ok):
+        ctx.host_free(b)
