@@ -1600,12 +1600,12 @@ static int enqueue_verify(bjj_ctx* c, ScratchSet* S, hipStream_t st, bool schnor
   const int scan_grid = grid_for(c, n, c->occ_scan, 64) * 64 / bjjk::verify_scan_block();   // occ_scan counts waves
   // Short calls (a single `verify` is one): the bulk with eight lanes per signature (k_small.hip) between K4's scan and K4's exact
   // launch -- the hash on six lanes, the curve arithmetic on four, instead of one lane's serial chain (profiles/r06_small_calls.txt)
-  if (!schnorr && n <= c->verify_small_max && c->verify_mode < 0) {
+  if (n <= c->verify_small_max && c->verify_mode < 0) {
     c->last_verify_mode = 2;
     c->rings_used = true;               // the exact launch takes its table scratch from the slot queues
     LAUNCHCK(bjjk::verify_scan(st, scan_grid, pk, r, msg, n, S->slow), "verify scan");
-    LAUNCHCK(bjjk::verify_small(st, c->table, c->W, c->nwin, pk, r, s, msg, n, ok), "verify (short call)");
-    LAUNCHCK(bjjk::verify_main(st, 1, 0, false, c->table, c->W, c->nwin, pk, r, s, msg, n, ok, S->vb_tables, S->slow, S->slotq,
+    LAUNCHCK(bjjk::verify_small(st, schnorr, c->table, c->W, c->nwin, pk, r, s, msg, n, ok), "verify (short call)");
+    LAUNCHCK(bjjk::verify_main(st, 1, 0, schnorr, c->table, c->W, c->nwin, pk, r, s, msg, n, ok, S->vb_tables, S->slow, S->slotq,
                                S->slot_cap | ((u32)c->xccs << 16), bjjk::VERIFY_EXACT), "verify (exact)");
     return BJJ_OK;
   }
@@ -1717,7 +1717,7 @@ struct VerifyPipe : PipeExtra {
 };
 static int verify_host(bjj_ctx* c, bool schnorr, const uint8_t* pk, const uint8_t* r, const uint8_t* s, const uint8_t* msg, size_t n, uint8_t* ok) {
   PipeSpec sp = {4, 1, {pk, r, s, msg}, {64, 64, 32, 32}, {ok}, {1}, false};
-  if (!schnorr && c->verify_mode < 0) sp.small_direct_max = small_direct_items(c->verify_small_max);
+  if (c->verify_mode < 0) sp.small_direct_max = small_direct_items(c->verify_small_max);
   static const bool per_chunk = [] { const char* e = getenv("BJJ_PIPE_VERIFY_SPLIT"); return e && e[0] == '0'; }();   // developer: the round-5 form
   // a call of ONE chunk is a device-pointer launch with copies around it: its exact groups start first inside the launch, nothing
   // waits behind them, and three launches instead of two would only add latency (a single `verify`, src/lib.rs:395, is such a call)

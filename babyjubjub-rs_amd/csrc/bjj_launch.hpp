@@ -62,7 +62,7 @@ hipError_t mul_var_base_exact(hipStream_t st, int grid_exact, const uint8_t* pts
 int occ_var_base_scan();
 // k_small.hip: four lanes per item, for calls that do not fill the chip one item per lane (32-byte scalars); slow as for mul_var_base_main
 // ... Poseidon with six lanes per hash, and the bulk of verify with eight lanes per signature (scan and exact launch: k_verify.hip)
-hipError_t verify_small(hipStream_t st, const uint32_t* table, int W, int nwin, const uint8_t* pk, const uint8_t* rb8, const uint8_t* s, const uint8_t* msg,
+hipError_t verify_small(hipStream_t st, bool schnorr, const uint32_t* table, int W, int nwin, const uint8_t* pk, const uint8_t* rb8, const uint8_t* s, const uint8_t* msg,
                         size_t n, uint8_t* ok);
 hipError_t mul_fixed_base_quad(hipStream_t st, const uint32_t* table, int W, int nwin, const uint8_t* scalars, size_t n, uint8_t* out, bool compressed);   // B8.mul_scalar, four lanes per item
 hipError_t sign_small(hipStream_t st, const uint32_t* table, int W, int nwin, const uint8_t* keys, const uint8_t* msgs, size_t n, uint8_t* out_r, uint8_t* out_s,

@@ -412,6 +412,81 @@ __global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_eddsa_verify_small(const u
   if (live && !need_exact && gl == 0) ok[i] = (uint8_t)(msg_gt ? 0 : verdict);
 }
 
+// verify_schnorr (src/lib.rs:364-385) for SHORT calls: the fast path of verify_fast_t<true> on eight lanes -- hash input order (pk, R, msg), the hash NOT multiplied by 8,
+// hm (-A) over 64 signed windows with the accumulator on a quad, + (s mod l) B8, compared with R on the a' = -1 curve; verdict 2 = Err (msg > Q).
+__global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_schnorr_verify_small(const u32* __restrict__ table, int W, int nwin,
+                                                                          const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
+                                                                          const uint8_t* __restrict__ sg, const uint8_t* __restrict__ msg, size_t n,
+                                                                          uint8_t* __restrict__ ok) {
+  __shared__ u32 tbl_all[(BJJ_VS_BLOCK / 4) * QTBL_ITEM_WORDS];
+  const int lane = threadIdx.x, gl = lane & 7, q = lane & 3;
+  const int j = gl < 6 ? gl : 5;
+  u32* tbl = tbl_all + (lane >> 2) * QTBL_ITEM_WORDS;
+  const size_t item = (size_t)blockIdx.x * (BJJ_VS_BLOCK / 8) + (size_t)(lane >> 3);
+  const bool live = item < n;
+  const size_t i = live ? item : n - 1;
+  u32 w[8];
+  load_w8(msg + i * 32, w);
+  const bool msg_gt = words_gt_modulus(w);                           // :365-367
+  const Fr m5 = fr_to_mont_words(w);
+  load_w8(rb8 + i * 64, w);      const Fr rx = fr_to_mont_words(w);
+  load_w8(rb8 + i * 64 + 32, w); const Fr ry = fr_to_mont_words(w);
+  load_w8(pk + i * 64, w);       const Fr ax = fr_to_mont_words(w);
+  load_w8(pk + i * 64 + 32, w);  const Fr ay = fr_to_mont_words(w);
+  const bool need_exact = !msg_gt && !(ref_on_curve(rx, ry, c_K) && ref_on_curve(ax, ay, c_K));
+  const Fr st0 = fr_select(j == 0, fr_zero(), fr_select(j == 1, ax, fr_select(j == 2, ay, fr_select(j == 3, rx, fr_select(j == 4, ry, m5)))));   // :369
+  const Fr hm = grp_get(p5c_permute(j, gl, st0), 0);
+  u32 kw[8], sw[8], sl[8];
+  fr_to_words(fr_canon(fr_mul(hm, fr_one_plain())), kw);             // hm < r < 2^254: no reduction
+  load_w8(sg + i * 32, sw);
+  scalar_mod_l(sw, sl, c_K);                                         // B8 has order l
+  qfb_prefetch(table, W, nwin, sl);
+  {
+    const Fr X = fr_mul(fr_neg(ax), c_K.F);                          // -A on the a' = -1 curve
+    qtbl_build(q, tbl, fr_select(q == 0, X, fr_select(q == 1, ay, fr_select(q == 2, fr_one(), fr_mul(X, ay)))));
+  }
+  __syncthreads();
+  u32 t[8];
+  {
+    u64 cy = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cy += (u64)kw[k] + 0x88888888u; t[k] = (u32)cy; cy >>= 32; }
+  }
+  Fr acc;
+  {
+    const int d = (int)((t[7] >> 28) & 15u) - 8;
+    const Fr e = qtbl_load(tbl, d, q);
+    const Fr ymx = quad_bcast<0>(e), ypx = quad_bcast<1>(e);
+    acc = fr_select(q == 0, fr_reduce_weak(fr_sub8(ypx, ymx)), fr_select(q == 1, fr_reduce_weak(fr_add(ypx, ymx)), fr_select(q == 2, fr_reduce_weak(e), fr_zero())));
+  }
+#pragma unroll 1
+  for (int jj = 62; jj >= 0; jj--) {
+    const int d = (int)((t[jj >> 3] >> ((jj & 7) * 4)) & 15u) - 8;
+    const Fr e = qtbl_load(tbl, d, q);
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) acc = quad_dbl(q, acc);
+    acc = quad_add(q, acc, e);
+  }
+  {  // + (s mod l) B8 (:377)
+    DigitStream ds = digit_stream(sl, W);
+    bool neg;
+    size_t slot = digit_next(ds, neg);
+    Fr cur = qfb_load(table, slot, neg, q);
+    cur = fr_select(q == 3, fr_mul(cur, c_K.DP), cur);
+#pragma unroll 1
+    for (int k = 0; k + 1 < nwin; k++) {
+      slot = digit_next(ds, neg);
+      const Fr nxt = qfb_load(table, slot, neg, q);
+      acc = quad_add(q, acc, cur);
+      cur = nxt;
+    }
+    acc = quad_add(q, acc, cur);
+  }
+  const Fr X = quad_bcast<0>(acc), Y = quad_bcast<1>(acc), Z = quad_bcast<2>(acc);
+  const int verdict = (fr_eq(X, fr_mul(fr_mul(rx, c_K.F), Z)) && fr_eq(Y, fr_mul(ry, Z))) ? 1 : 0;
+  if (live && !need_exact && gl == 0) ok[i] = (uint8_t)(msg_gt ? 2 : verdict);
+}
+
 // =====================================================================================================================================
 // PrivateKey::sign (src/lib.rs:308-342) for SHORT calls: eight lanes per signature.  sign_item (sign.hpp) as it is -- the two Blake-512 digests, r, the two
 // fixed-base multiplications, one inversion -- on every lane of the group for itself, and the Poseidon hash, two thirds of the lane form's time, on six of them
@@ -538,9 +613,11 @@ __global__ void __launch_bounds__(BJJ_QUAD_BLOCK) bjj_k_mul_fixed_base_quad_c32(
 
 namespace bjjk {
 // the bulk of a short verify call; the scan (before) and the exact launch (behind) are K4's (k_verify.hip)
-hipError_t verify_small(hipStream_t st, const u32* table, int W, int nwin, const uint8_t* pk, const uint8_t* rb8, const uint8_t* s, const uint8_t* msg,
+hipError_t verify_small(hipStream_t st, bool schnorr, const u32* table, int W, int nwin, const uint8_t* pk, const uint8_t* rb8, const uint8_t* s, const uint8_t* msg,
                         size_t n, uint8_t* ok) {
   const size_t per = BJJ_VS_BLOCK / 8, grid = (n + per - 1) / per;
+  if (schnorr) BJJ_LAUNCH(bjj_k_schnorr_verify_small, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok);
+  else
   BJJ_LAUNCH(bjj_k_eddsa_verify_small, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok);
   return hipGetLastError();
 }

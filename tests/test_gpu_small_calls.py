@@ -399,3 +399,41 @@ def test_short_calls_on_pinned_memory_run_without_copies(gpu_ctx, oracle):
     assert (np.asarray(p_r[:9 * 64]).reshape(9, 64) == ro).all() and (np.asarray(p_s[:9 * 32]).reshape(9, 32) == so).all()
     for b in (p_k, p_m, p_r, p_s, p_ok):
         ctx.host_free(b)
+
+
+# ------------------------------------------------------------------------------------------------ verify_schnorr, eight lanes per signature
+def test_schnorr_verify_short_calls_against_the_lane_kernel_and_the_oracle(oracle, monkeypatch):
+    """verify_schnorr (src/lib.rs:364-385) in short calls: signatures from the device signer (s reduced mod 8l for the 32-byte record), corrupted in every record, pk or R
+    off the curve (the exact launch's), msg > Q (verdict 2 = the reference's Err) -- every call size around the boundaries against K4's Schnorr kernel and the oracle"""
+    import babyjubjub_rs_amd as bjj
+    ctx = bjj.Context(0, 16)
+    monkeypatch.setenv("BJJ_VERIFY_SMALL_MAX", "0")
+    k4 = bjj.Context(0, 16)
+    monkeypatch.delenv("BJJ_VERIFY_SMALL_MAX")
+    try:
+        nmax = VERIFY_SMALL_MAX + 11
+        rng = np.random.default_rng(0x5c4)
+        keys = rng.integers(0, 256, (nmax, 32), dtype=np.uint8)
+        msgs = rng.integers(0, 256, (nmax, 32), dtype=np.uint8)
+        msgs[:, 31] &= 0x1f
+        nonces = rng.integers(0, 256, (nmax, 128), dtype=np.uint8)
+        r, s, ok = ctx.sign_schnorr(keys, msgs, nonces)
+        assert ok.all()
+        sv = pack([int.from_bytes(s[i].tobytes(), "little") % (8 * L) for i in range(nmax)]).reshape(-1, 32)
+        pk = ctx.public_keys(keys).copy()
+        r = r.copy()
+        sv[::7, 0] ^= 1
+        msgs[3::41, 31] = 0xff                                   # msg > Q -> Err (2)
+        pk[5::53, 3] ^= 0x04                                     # pk off the curve
+        r[9::59, 35] ^= 0x20                                     # R off the curve
+        msgs[11::61, 0] ^= 1
+        want = k4.schnorr_verify(pk, r, sv, msgs)
+        assert k4.info().last_verify_dispatch in (0, 1)
+        assert (want[:1500] == oracle.verify_schnorr(pk[:1500], r[:1500], sv[:1500], msgs[:1500])).all()
+        assert (want[3::41] == 2).all() and 0 < (want == 0).sum() and (want == 1).sum() > nmax // 2
+        for n in (1, 2, 7, 8, 9, 63, 64, 65, 1000, VERIFY_SMALL_MAX - 1, VERIFY_SMALL_MAX, VERIFY_SMALL_MAX + 1, nmax):
+            got = ctx.schnorr_verify(pk[:n], r[:n], sv[:n], msgs[:n])
+            assert (ctx.info().last_verify_dispatch == 2) == (n <= VERIFY_SMALL_MAX), n
+            assert (got == want[:n]).all(), (n, np.nonzero(got != want[:n])[0][:8])
+    finally:
+        ctx.close(); k4.close()
