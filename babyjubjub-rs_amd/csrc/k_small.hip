@@ -309,7 +309,118 @@ __device__ __forceinline__ void qfb_prefetch(const u32* __restrict__ table, int 
   for (int k = 0; k < 32; k++) sink ^= v[k];
   asm volatile("" ::"v"(sink));
 }
-__global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_eddsa_verify_small(const u32* __restrict__ table, int W, int nwin,
+// TWO waves per workgroup share the curve arithmetic of their eight signatures (they are on different SIMDs: truly side by side, not in lock-step): both hash and
+// derive the scalars (the same work at the same time costs no time), then wave 0 builds the table of -8A and walks u over it, wave 1 builds the table of -+R, walks |v|
+// over it and adds the fixed-base windows; wave 1's sum goes through LDS to wave 0, which adds it to its own and tests for the identity.  One scalar per wave instead of
+// two in a joint loop: 128 doublings + 33 additions in sequence instead of 128 + 66, 11 table operations instead of 19 (profiles/r06_small_calls.txt).
+__global__ void __launch_bounds__(2 * BJJ_VS_BLOCK) bjj_k_eddsa_verify_small(const u32* __restrict__ table, int W, int nwin,
+                                                                            const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
+                                                                            const uint8_t* __restrict__ sg, const uint8_t* __restrict__ msg, size_t n,
+                                                                            uint8_t* __restrict__ ok) {
+  __shared__ u32 tbl_all[2 * (BJJ_VS_BLOCK / 4) * QTBL_ITEM_WORDS];    // one table per quad and wave: 41.5 KB
+  __shared__ u32 xch[(BJJ_VS_BLOCK / 4) * 4 * NL];                     // wave 1's sum, one coordinate per lane
+  const int role = threadIdx.x >> 6, lane = threadIdx.x & 63, gl = lane & 7, q = lane & 3;
+  const int j = gl < 6 ? gl : 5;
+  u32* tbl = tbl_all + (role * (BJJ_VS_BLOCK / 4) + (lane >> 2)) * QTBL_ITEM_WORDS;
+  u32* mine = xch + ((lane >> 2) * 4 + q) * NL;
+  const size_t item = (size_t)blockIdx.x * (BJJ_VS_BLOCK / 8) + (size_t)(lane >> 3);
+  const bool live = item < n;
+  const size_t i = live ? item : n - 1;
+  u32 w[8];
+  load_w8(msg + i * 32, w);
+  const bool msg_gt = words_gt_modulus(w);                           // :396-398
+  const Fr m5 = fr_to_mont_words(w);
+  load_w8(rb8 + i * 64, w);      const Fr rx = fr_to_mont_words(w);
+  load_w8(rb8 + i * 64 + 32, w); const Fr ry = fr_to_mont_words(w);
+  load_w8(pk + i * 64, w);       const Fr ax = fr_to_mont_words(w);
+  load_w8(pk + i * 64 + 32, w);  const Fr ay = fr_to_mont_words(w);
+  const bool need_exact = !msg_gt && !(ref_on_curve(rx, ry, c_K) && ref_on_curve(ax, ay, c_K));
+  // hm = H(R.x, R.y, A.x, A.y, msg) (:400-404), six lanes
+  const Fr st0 = fr_select(j == 0, fr_zero(), fr_select(j == 1, rx, fr_select(j == 2, ry, fr_select(j == 3, ax, fr_select(j == 4, ay, m5)))));
+  const Fr hm = grp_get(p5c_permute(j, gl, st0), 0);
+  const Fr hm_plain = fr_canon(fr_mul(hm, fr_one_plain()));
+  // the short odd pair and the fixed-base scalar (verify_fast_t): every lane for itself
+  Fr u, vmag;
+  bool vneg;
+  lattice_short_pair(plain_mod_l(hm_plain, c_K), u, vmag, vneg, c_K);
+  u32 sw[8], cw[8];
+  load_w8(sg + i * 32, sw);
+  {
+    const Fr sl = fl_mul(fr_from_words(sw), c_K.L_R1, c_K);
+    Fr c = fl_canon4(fl_mul(vmag, fl_mul(sl, c_K.L_R2, c_K), c_K), c_K);
+    if (vneg && !limbs_is_zero(c)) { Fr t = c_K.L; limbs_submul(t, 1u, c); c = t; }
+    fr_to_words(c, cw);
+  }
+  if (role) qfb_prefetch(table, W, nwin, cw);
+  // this wave's point on the a' = -1 curve, one coordinate per lane, and its table: wave 0 -8A, wave 1 -sign(v) R
+  {
+    const Fr px = role ? fr_select(vneg, rx, fr_neg(rx)) : fr_neg(ax), py = role ? ry : ay;
+    const Fr X = fr_mul(px, c_K.F);
+    Fr c = fr_select(q == 0, X, fr_select(q == 1, py, fr_select(q == 2, fr_one(), fr_mul(X, py))));
+    if (!role) {
+#pragma unroll 1
+      for (int k = 0; k < 3; k++) c = quad_dbl(q, c);
+    }
+    qtbl_build(q, tbl, c);
+  }
+  __syncthreads();
+  // this wave's scalar over its table, as many windows as the widest pair of the wave needs (joint_short_pair: the same count for both waves)
+  const int ub = limbs_bits(u), vb = limbs_bits(vmag);
+  const int mb = ub > vb ? ub : vb;
+  const int need = mb <= 2 ? 1 : (mb + 5) >> 2;
+  const int jw = wave_max_int(need > 64 ? 64 : need);
+  u32 t[8];
+  recode_signed4(role ? vmag : u, t);
+  Fr acc;
+  {
+    const int jj = jw - 1;
+    const int d = (int)((t[jj >> 3] >> ((jj & 7) * 4)) & 15u) - 8;
+    const Fr e = qtbl_load(tbl, d, q);
+    const Fr ymx = quad_bcast<0>(e), ypx = quad_bcast<1>(e);         // pniels_to_ext with T (additions may follow at once): 2T = (2D'T) / D'
+    acc = fr_select(q == 0, fr_reduce_weak(fr_sub8(ypx, ymx)), fr_select(q == 1, fr_reduce_weak(fr_add(ypx, ymx)),
+                    fr_select(q == 2, fr_reduce_weak(e), fr_mul(e, c_K.DPINV))));
+  }
+#pragma unroll 1
+  for (int jj = jw - 2; jj >= 0; jj--) {
+    const int d = (int)((t[jj >> 3] >> ((jj & 7) * 4)) & 15u) - 8;
+    const Fr e = qtbl_load(tbl, d, q);
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) acc = quad_dbl(q, acc);
+    acc = quad_add(q, acc, e);
+  }
+  if (role) {  // + (v s mod l) B8: the fixed-base windows (fixed_base_accumulate); window 0 is stored in T form
+    DigitStream ds = digit_stream(cw, W);
+    bool neg;
+    size_t slot = digit_next(ds, neg);
+    Fr cur = qfb_load(table, slot, neg, q);
+    cur = fr_select(q == 3, fr_mul(cur, c_K.DP), cur);
+#pragma unroll 1
+    for (int k = 0; k + 1 < nwin; k++) {
+      slot = digit_next(ds, neg);
+      const Fr nxt = qfb_load(table, slot, neg, q);                   // in flight during this window's addition
+      acc = quad_add(q, acc, cur);
+      cur = nxt;
+    }
+    acc = quad_add(q, acc, cur);
+#pragma unroll
+    for (int k = 0; k < NL; k++) mine[k] = acc.v[k];
+  }
+  __syncthreads();
+  if (!role) {
+    Fr other;
+#pragma unroll
+    for (int k = 0; k < NL; k++) other.v[k] = mine[k];
+    acc = quad_add(q, acc, quad_entry(q, other));
+    // the projective identity (0 : z : z)
+    const Fr X = quad_bcast<0>(acc), Y = quad_bcast<1>(acc), Z = quad_bcast<2>(acc);
+    const int verdict = (fr_is_zero(X) && fr_eq(Y, Z)) ? 1 : 0;
+    if (live && !need_exact && gl == 0) ok[i] = (uint8_t)(msg_gt ? 0 : verdict);
+  }
+}
+
+// ONE wave per eight signatures, both scalars in a joint loop (joint_mul_windowed): eight lanes per signature instead of sixteen -- the form for calls that put more than a
+// wave or two on every CU (2^12 ... 2^13 signatures), where lanes are what is scarce: 643 us per call at 2^12 against 897 for the two-wave form, which wins below (587 vs 627 at 2^11).
+__global__ void __launch_bounds__(BJJ_VS_BLOCK) bjj_k_eddsa_verify_small_joint(const u32* __restrict__ table, int W, int nwin,
                                                                         const uint8_t* __restrict__ pk, const uint8_t* __restrict__ rb8,
                                                                         const uint8_t* __restrict__ sg, const uint8_t* __restrict__ msg, size_t n,
                                                                         uint8_t* __restrict__ ok) {
@@ -617,8 +728,10 @@ hipError_t verify_small(hipStream_t st, bool schnorr, const u32* table, int W, i
                         size_t n, uint8_t* ok) {
   const size_t per = BJJ_VS_BLOCK / 8, grid = (n + per - 1) / per;
   if (schnorr) BJJ_LAUNCH(bjj_k_schnorr_verify_small, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok);
+  else if (n <= ((size_t)1 << 11))
+    BJJ_LAUNCH(bjj_k_eddsa_verify_small, dim3((unsigned)(grid ? grid : 1)), dim3(2 * BJJ_VS_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok);
   else
-  BJJ_LAUNCH(bjj_k_eddsa_verify_small, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok);
+    BJJ_LAUNCH(bjj_k_eddsa_verify_small_joint, dim3((unsigned)(grid ? grid : 1)), dim3(BJJ_VS_BLOCK), 0, st, table, W, nwin, pk, rb8, s, msg, n, ok);
   return hipGetLastError();
 }
 hipError_t mul_fixed_base_quad(hipStream_t st, const u32* table, int W, int nwin, const uint8_t* scalars, size_t n, uint8_t* out, bool compressed) {
